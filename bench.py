@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the kriging / FFTGS hot path on MI355X.
+
+A "step" is one whole pass of BASELINE.json configs[1] on each GPU: Ordinary Kriging of 1 000
+scattered 3-D samples onto 10^6 domain points with a Matern-3/2 variogram (global neighbourhood) --
+fit (device factorisation of the 1001^2 system) + predict, with every input already resident in
+HBM when the timed region starts.  Multi-GPU is weak scaling: each rank owns its own block of 10^6
+domain points (independent given the factor, which every rank recomputes because that is cheaper
+than a broadcast at n = 1000; `--factor-broadcast` exercises the RCCL broadcast path instead).
+
+Prints ONE JSON line on rank 0.  Extra keys: `roofline` (dominant kernel: the FP64-MFMA quadratic
+form), `cpu_baseline` (oracle C restatement, single thread like the reference's loop krig.jl:180,
+bounded sample) and `fftgs` (second headline metric, 512^3 realisations/s on this GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (public spec)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ndata", type=int, default=1000)
+    ap.add_argument("--npoints", type=int, default=1_000_000, help="domain points per GPU per step")
+    ap.add_argument("--factor-broadcast", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=12000, help="points of the CPU baseline sample")
+    ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the extra leg)")
+    ap.add_argument("--fftgs-reals", type=int, default=8)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the gfx950 path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+
+    import gss
+    from gss import _lib
+    from gss.engine import KrigHandle, OK
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic inputs ---------------------------------
+    n, m = a.ndata, a.npoints
+    x = np.random.default_rng(2).uniform(0.0, 100.0, (n, 3))
+    z = np.random.default_rng(2 + 1000).normal(size=n)
+    x0 = np.random.default_rng(3 + 7919 * rank).uniform(0.0, 100.0, (m, 3))
+    x0_dev = torch.as_tensor(x0, device="cuda")
+    vg = gss.MaternVariogram(range=30.0, sill=1.0, nugget=0.0, order=1.5)
+
+    def step():
+        if a.factor_broadcast and world > 1:
+            h = KrigHandle(vg, OK, x, z, factor=(rank == 0))
+            t = h.factor_tensor()
+            dist.broadcast(t, src=0)
+            h.adopt_factor()
+        else:
+            h = KrigHandle(vg, OK, x, z)
+        out = h.predict_global(x0_dev)
+        return h, out
+
+    for _ in range(a.warmup):
+        h, out = step()
+        torch.cuda.synchronize()
+        h.close()
+
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    keep = None
+    for _ in range(a.steps):
+        h, out = step()
+        if keep is not None:
+            keep[0].close()
+        keep = (h, out)
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    q_ms, q_n = _lib.profile_read("krig_quadform")
+    r_ms, r_n = _lib.profile_read("krig_rhs")
+    mu, var, st = keep[1]
+    keep[0].close()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = world * m * a.steps / dt
+
+    # ---- roofline of the dominant kernel (quadratic form: (n+nc)^2 flop per point) ----------
+    N1 = n + 1
+    flops_per_launch = float(N1) * N1 * (m * a.steps / max(q_n, 1))
+    q_avg_ms = q_ms / max(q_n, 1)
+    achieved = flops_per_launch / (q_avg_ms * 1e-3) / 1e12 if q_n else 0.0
+    roofline = {"kernel": "krig_quadform_kernel", "bound": "mfma", "achieved": round(achieved, 3),
+                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(q_avg_ms, 4), "launches": q_n,
+                "assembly": {"kernel": "krig_rhs_kernel", "bound": "hbm",
+                             "achieved": round(8.0 * n * m * a.steps / (r_ms * 1e-3) / 1e9, 1) if r_n else 0.0,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(r_ms / max(r_n, 1), 4),
+                             "launches": r_n}}
+
+    line = {"metric": "kriged domain points/sec (OK, 1000 3-D data, Matern-3/2, global neighbourhood)",
+            "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: OK, %d 3-D data -> %d domain points per GPU, Matern-3/2 range 30, "
+                                   "global neighbourhood; step = device fit + predict" % (n, m),
+                       "points_per_gpu": m, "ndata": n, "factor": "broadcast" if a.factor_broadcast else "replicated"},
+            "roofline": roofline}
+
+    if rank == 0:
+        # sanity: a handful of points against the oracle so a wrong-but-fast kernel cannot post a number
+        from oracle import kriging as K
+        from oracle.variogram import Variogram
+        ovg = Variogram("matern", range=30.0, nu=1.5)
+        sel = np.linspace(0, m - 1, 64).astype(np.int64)
+        rmu, rvar = K.exactsolve(K.OK, ovg, x, z, x0[sel])
+        err = max(float(np.max(np.abs(mu[sel].cpu().numpy() - rmu))), float(np.max(np.abs(var[sel].cpu().numpy() - rvar))))
+        line["parity_max_abs_err_64pts"] = err
+        assert err < 1e-8 and int(st.sum().item()) == 0, f"parity check failed: {err}"
+
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import cbind
+            ns = min(a.cpu_sample, m)
+            t1 = time.perf_counter()
+            cbind.krig_global(ovg, 1, x, z, x0[:ns], nthreads=1)
+            cdt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(ns / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                                    "sample": "oracle/krig_oracle.c (fit + per-point solves as krig.jl:176,180), "
+                                              "first %d of the 10^6 points, %.1f s, single thread like the "
+                                              "reference loop; host has %d cores" % (ns, cdt, os.cpu_count())}
+
+    if world == 1 and a.fftgs > 0:
+        line["fftgs"] = fftgs_leg(a, gss, _lib)
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def fftgs_leg(a, gss, _lib):
+    """Second headline metric: unconditional FFTGS realisations/s on an edge^3 grid (configs[2])."""
+    from gss.engine import FFTGSHandle
+    e = a.fftgs
+    try:
+        f = FFTGSHandle(gss.ExponentialVariogram(range=50.0 * e / 512.0), (e, e, e))
+    except _lib.GSSError as err:
+        return {"error": str(err)}
+    N = e ** 3
+    out = torch.empty((1, N), dtype=torch.float64, device="cuda")
+    f.realize(4, 0, 1, out=out)
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for r in range(a.fftgs_reals):
+        f.realize(4, r, 1, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv")}
+    zc = out[0]
+    res = {"metric": "FFTGS %d^3 realisations/sec" % e, "value": round(a.fftgs_reals / dt, 2), "unit": "realisations/s",
+           "ms_per_realisation": round(dt / a.fftgs_reals * 1e3, 3),
+           "roofline": {"bound": "hbm", "achieved": round(32.0 * N * a.fftgs_reals / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(32.0 * N * a.fftgs_reals / dt / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": None},
+           "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items()},
+           "sample_variance": float((zc * zc).sum().item() / (N - 1))}
+    f.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

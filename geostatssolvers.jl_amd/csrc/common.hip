@@ -1,0 +1,243 @@
+// Library context, error reporting, memory staging, variogram validation.
+#include "gss_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace gss {
+
+// ---- profiling registry --------------------------------------------------------------------
+struct ProfEntry {
+  std::vector<hipEvent_t> start, stop;
+  double ms = 0.0;
+  int64_t launches = 0;
+};
+static bool g_prof_on = false;
+static std::map<std::string, ProfEntry> g_prof;
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin(const char* name, hipStream_t s) {
+  ProfEntry& e = g_prof[name];
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  if (hipEventCreate(&b) != hipSuccess) {
+    (void)hipEventDestroy(a);
+    return;
+  }
+  e.start.push_back(a);
+  e.stop.push_back(b);
+  (void)hipEventRecord(a, s);
+}
+
+void prof_end(const char* name, hipStream_t s) {
+  ProfEntry& e = g_prof[name];
+  if (e.stop.size() == e.start.size() && !e.stop.empty()) (void)hipEventRecord(e.stop.back(), s);
+}
+
+static void prof_collect(ProfEntry& e) {
+  for (size_t i = 0; i < e.start.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, e.start[i], e.stop[i]) == hipSuccess) {
+      e.ms += ms;
+      e.launches += 1;
+    }
+    (void)hipEventDestroy(e.start[i]);
+    (void)hipEventDestroy(e.stop[i]);
+  }
+  e.start.clear();
+  e.stop.clear();
+}
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int32_t DevBuf::alloc(size_t nbytes) {
+  release();
+  if (nbytes == 0) nbytes = 8;
+  hipError_t e = hipMalloc(&p, nbytes);
+  if (e != hipSuccess) {
+    p = nullptr;
+    set_error("hipMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
+    return GSS_ERR_ALLOC;
+  }
+  bytes = nbytes;
+  return GSS_OK;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+int32_t Staged::in(const void* src, size_t bytes, int32_t mem, hipStream_t s) {
+  if (src == nullptr) {
+    p = nullptr;
+    return GSS_OK;
+  }
+  if (mem == GSS_MEM_DEVICE) {
+    p = const_cast<void*>(src);
+    return GSS_OK;
+  }
+  GSS_TRY(own.alloc(bytes));
+  p = own.p;
+  GSS_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s));
+  return GSS_OK;
+}
+
+int32_t Staged::out(void* dst, size_t bytes, int32_t mem) {
+  if (dst == nullptr) {
+    p = nullptr;
+    return GSS_OK;
+  }
+  if (mem == GSS_MEM_DEVICE) {
+    p = dst;
+    return GSS_OK;
+  }
+  GSS_TRY(own.alloc(bytes));
+  p = own.p;
+  return GSS_OK;
+}
+
+int32_t Staged::back(void* dst, size_t bytes, int32_t mem, hipStream_t s) {
+  if (dst == nullptr || mem == GSS_MEM_DEVICE) return GSS_OK;
+  GSS_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
+  GSS_REQUIRE(vg != nullptr, "variogram is NULL");
+  GSS_REQUIRE(vg->dim >= 1 && vg->dim <= 3, "variogram dim %d outside 1..3", vg->dim);
+  GSS_REQUIRE(vg->sill > 0.0 && vg->nugget >= 0.0 && vg->nugget <= vg->sill, "invalid sill/nugget %g/%g",
+              vg->sill, vg->nugget);
+  VgDev v;
+  v.kind = vg->kind;
+  v.dim = vg->dim;
+  v.aniso = vg->aniso ? 1 : 0;
+  v.sill = vg->sill;
+  v.cs = vg->sill - vg->nugget;
+  v.mscale = 0.0;
+  for (int k = 0; k < 3; ++k) v.ir[k] = 1.0;
+  if (v.aniso) {
+    for (int k = 0; k < vg->dim; ++k) {
+      GSS_REQUIRE(vg->inv_radii[k] > 0.0, "anisotropic ball needs positive radii");
+      v.ir[k] = vg->inv_radii[k];
+    }
+    v.inv_range = 1.0;
+  } else {
+    GSS_REQUIRE(vg->range > 0.0, "variogram range must be positive (got %g)", vg->range);
+    v.inv_range = 1.0 / vg->range;
+  }
+  switch (vg->kind) {
+    case GSS_VG_GAUSSIAN:
+    case GSS_VG_EXPONENTIAL:
+    case GSS_VG_SPHERICAL:
+    case GSS_VG_CUBIC:
+    case GSS_VG_PENTASPHERICAL:
+      break;
+    case GSS_VG_MATERN:
+      if (vg->nu == 0.5) v.kind = VG_MATERN12;
+      else if (vg->nu == 1.5) v.kind = VG_MATERN32;
+      else if (vg->nu == 2.5) v.kind = VG_MATERN52;
+      else {
+        set_error("Matern order nu=%g is not available on the device (0.5, 1.5, 2.5 only)", vg->nu);
+        return GSS_ERR_UNSUPPORTED;
+      }
+      v.mscale = std::sqrt(2.0 * vg->nu) * 3.0;
+      break;
+    default:
+      set_error("unknown variogram kind %d", vg->kind);
+      return GSS_ERR_INVALID;
+  }
+  *out = v;
+  return GSS_OK;
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+extern "C" {
+
+int32_t gss_version(void) { return GSS_VERSION; }
+
+int32_t gss_device_count(int32_t* count) {
+  GSS_REQUIRE(count != nullptr, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  *count = n;
+  return GSS_OK;
+}
+
+int32_t gss_init(int32_t device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    set_error("no HIP device visible: the gfx950 kernels cannot run (there is no CPU fallback)");
+    return GSS_ERR_NO_DEVICE;
+  }
+  GSS_REQUIRE(device >= 0 && device < n, "device %d outside 0..%d", device, n - 1);
+  GSS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  GSS_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; libgss_hip.so carries gfx950 code objects only", device, prop.gcnArchName);
+    return GSS_ERR_NO_DEVICE;
+  }
+  return GSS_OK;
+}
+
+int32_t gss_shutdown(void) { return GSS_OK; }
+
+int32_t gss_last_error(char* buf, int32_t len) {
+  if (buf == nullptr || len <= 0) return GSS_ERR_INVALID;
+  std::strncpy(buf, g_err, (size_t)len - 1);
+  buf[len - 1] = '\0';
+  return GSS_OK;
+}
+
+int32_t gss_profile_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return GSS_OK;
+}
+
+int32_t gss_profile_reset(void) {
+  for (auto& kv : g_prof) prof_collect(kv.second);
+  g_prof.clear();
+  return GSS_OK;
+}
+
+int32_t gss_profile_read(const char* name, double* total_ms, int64_t* launches) {
+  GSS_REQUIRE(name != nullptr && total_ms != nullptr && launches != nullptr, "gss_profile_read: NULL argument");
+  auto it = g_prof.find(name);
+  if (it == g_prof.end()) {
+    *total_ms = 0.0;
+    *launches = 0;
+    return GSS_OK;
+  }
+  prof_collect(it->second);
+  *total_ms = it->second.ms;
+  *launches = it->second.launches;
+  return GSS_OK;
+}
+
+int32_t gss_synchronize(void* stream) {
+  GSS_HIP(hipStreamSynchronize(to_stream(stream)));
+  return GSS_OK;
+}
+
+}  // extern "C"

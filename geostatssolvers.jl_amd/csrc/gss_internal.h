@@ -1,0 +1,206 @@
+// Internal declarations shared by the translation units of libgss_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "gss.h"
+
+namespace gss {
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define GSS_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      ::gss::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return GSS_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define GSS_TRY(call)                 \
+  do {                                \
+    int32_t s__ = (call);             \
+    if (s__ != GSS_OK) return s__;    \
+  } while (0)
+
+#define GSS_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::gss::set_error(__VA_ARGS__);    \
+      return GSS_ERR_INVALID;           \
+    }                                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// optional per-kernel timing with HIP events (gss_profile_*)
+// ---------------------------------------------------------------------------------------------
+bool prof_enabled();
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(const char* name, hipStream_t s);
+struct ProfScope {
+  const char* name;
+  hipStream_t s;
+  bool on;
+  ProfScope(const char* n, hipStream_t st) : name(n), s(st), on(prof_enabled()) {
+    if (on) prof_begin(name, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(name, s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device buffers
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  int32_t alloc(size_t nbytes);
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// A pointer that is either borrowed (caller's device memory) or a staged copy of host memory.
+struct Staged {
+  DevBuf own;
+  void* p = nullptr;
+  // input array: copy host->device when mem == HOST
+  int32_t in(const void* src, size_t bytes, int32_t mem, hipStream_t s);
+  // output array: allocate device scratch when mem == HOST
+  int32_t out(void* dst, size_t bytes, int32_t mem);
+  // copy back to host destination (no-op for DEVICE)
+  int32_t back(void* dst, size_t bytes, int32_t mem, hipStream_t s);
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+// ---------------------------------------------------------------------------------------------
+// variogram on device
+// ---------------------------------------------------------------------------------------------
+struct VgDev {
+  int kind;      // GSS_VG_* ; MATERN split into 30/31/32 for nu = 1/2, 3/2, 5/2
+  int dim;
+  int aniso;
+  double sill;
+  double cs;         // sill - nugget
+  double inv_range;  // 1 / range (1 when aniso)
+  double mscale;     // Matern: sqrt(2 nu) * 3
+  double ir[3];      // inverse radii (aniso) or 1
+};
+enum { VG_MATERN12 = 30, VG_MATERN32 = 31, VG_MATERN52 = 32 };
+
+int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out);
+
+// squared (possibly Mahalanobis) distance, dimension order, no FMA contraction (kNN tie contract)
+template <int DIM>
+__device__ __forceinline__ double sqdist_nofma(const double* a, const double* b, const double* ir, bool aniso) {
+#pragma clang fp contract(off)
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    double t = a[k] - b[k];
+    if (aniso) t = t * ir[k];
+    double tt = t * t;
+    acc = acc + tt;
+  }
+  return acc;
+}
+
+// C(h) = sill - gamma(h) from the squared distance; evaluated as cs * g(h/range) for h > 0, which is
+// algebraically identical to sill - ((sill-nugget) f + nugget) and avoids the cancellation.
+__device__ __forceinline__ double cov_from_d2(const VgDev& v, double d2) {
+  if (d2 <= 0.0) return v.sill;
+  double g;
+  switch (v.kind) {
+    case GSS_VG_GAUSSIAN: {
+      double x2 = d2 * v.inv_range * v.inv_range;
+      g = exp(-3.0 * x2);
+      break;
+    }
+    case GSS_VG_EXPONENTIAL: {
+      double x = sqrt(d2) * v.inv_range;
+      g = exp(-3.0 * x);
+      break;
+    }
+    case GSS_VG_SPHERICAL: {
+      double x = sqrt(d2) * v.inv_range;
+      g = x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
+      break;
+    }
+    case VG_MATERN12: {
+      double d = v.mscale * (sqrt(d2) * v.inv_range);
+      g = exp(-d);
+      break;
+    }
+    case VG_MATERN32: {
+      double d = v.mscale * (sqrt(d2) * v.inv_range);
+      g = (1.0 + d) * exp(-d);
+      break;
+    }
+    case VG_MATERN52: {
+      double d = v.mscale * (sqrt(d2) * v.inv_range);
+      g = (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
+      break;
+    }
+    case GSS_VG_CUBIC: {
+      double x = sqrt(d2) * v.inv_range;
+      double x2 = x * x, x3 = x2 * x;
+      g = x < 1.0 ? 1.0 - (7.0 * x2 - 8.75 * x3 + 3.5 * x3 * x2 - 0.75 * x3 * x3 * x) : 0.0;
+      break;
+    }
+    default: {  // GSS_VG_PENTASPHERICAL
+      double x = sqrt(d2) * v.inv_range;
+      double x2 = x * x, x3 = x2 * x;
+      g = x < 1.0 ? 1.0 - (1.875 * x - 1.25 * x3 + 0.375 * x3 * x2) : 0.0;
+      break;
+    }
+  }
+  return v.cs * g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense FP64 toolkit (dense_la.hip, gemm_f64.hip)
+// ---------------------------------------------------------------------------------------------
+// D(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * D(i,j), arbitrary element strides.
+int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
+                 const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
+                 int64_t sd_j, bool lower_only, hipStream_t s);
+// y = op(A) x for column-major A (m x n, lda); trans: y = A' x.  Optional sign flip of rows >= flip_from.
+int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda, const double* x, double* y,
+                 hipStream_t s);
+// in-place Cholesky of the lower triangle (column-major); *d_info (device int) set to 1+row on failure
+int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, hipStream_t s);
+// W = inv(L), lower, column-major; W's strict upper triangle must be zero on entry; T is scratch of
+// at least (n/2+64)^2 doubles
+int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, hipStream_t s);
+// X <- X * inv(L)' (X is m x n column-major); scratch >= 64*64 doubles
+int32_t trsm_right_lt_f64(double* X, int64_t m, int64_t n, int64_t ldx, const double* L, int64_t ldl,
+                          double* scratch, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// covariance assembly (cov_kernels.hip)
+// ---------------------------------------------------------------------------------------------
+// out[i * ldo + j] = C(a_i, b_j); device pointers
+int32_t cov_pairwise_dev(const VgDev& vg, const double* a, int64_t na, const double* b, int64_t nb, double* out,
+                         int64_t ldo, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// noise (noise.hip)
+// ---------------------------------------------------------------------------------------------
+int32_t philox_uniform_dev(uint64_t seed, int64_t real, int64_t n, double* out, int64_t ld_pad_n1, int64_t n1,
+                           hipStream_t s);
+int32_t philox_normal_dev(uint64_t seed, int64_t real, int64_t n, double* out, hipStream_t s);
+
+}  // namespace gss

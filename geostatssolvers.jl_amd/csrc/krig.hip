@@ -1,0 +1,582 @@
+// KrigingSolver, global neighbourhood: fit once, predict every domain point.
+// Replaces GeoStatsModels.fit + the predictprob loop of exactsolve
+// (/root/reference/src/estimation/krig.jl:166-186) and preprocess (krig.jl:76-128).
+//
+// Mathematics.  The kriging system K = [C F; F' 0] (covariance form, size
+// N1 = n + nc) has the block factorisation K = M D M' with M = [L 0; B L_S] lower triangular,
+// L L' = C, B = (L^-1 F)', L_S L_S' = B B', D = diag(I_n, -I_nc).  With W' = M^-1 precomputed,
+//     y       = W' [c0; f0]                    (one triangular GEMM over all points of a chunk)
+//     sigma^2 = max(0, sill - sum_{i<n} y_i^2 + sum_{i>=n} y_i^2)
+//     mu      = wd . [c0; f0] ,  wd = K^-1 [z; 0] = W'' D W' [z; 0]     (dual form)
+// so that per point the work is exactly the (n+nc)^2 flop of one triangular solve plus n covariance
+// evaluations, and nothing of size n x m ever returns to the host.
+//
+// Kernels:
+//   krig_rhs_kernel       K1+K2: assembles R = [c0; f0] for a chunk of points (coalesced HBM stores)
+//                         and accumulates the dual-form mean on the fly
+//   krig_quadform_kernel  K3: FP64 MFMA triangular GEMM W' * R fused with the signed column norms
+#include "gss_internal.h"
+#include "mfma_f64.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace gss {
+
+constexpr int MAX_NC = 64;
+constexpr int NSEG = 4;  // row segments of the RHS assembly (mean partials are summed in fixed order)
+
+struct DriftSpec {
+  int variant;
+  int nc;
+  int dim;
+  signed char e[MAX_NC][3];
+  double center[3];
+  double inv_scale[3];
+};
+
+// out[c * ld + p] = f_c(x_p) for c < nc, zero rows up to nrows; optionally dotted with wd into mean_part
+template <int DIM>
+__global__ __launch_bounds__(256) void drift_rows_kernel(DriftSpec ds, const double* __restrict__ x,
+                                                         const double* __restrict__ drift_vals, int64_t npts,
+                                                         int64_t ncols_pad, double* __restrict__ out, int64_t ld,
+                                                         int nrows, const double* __restrict__ wd,
+                                                         double* __restrict__ mean_part) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= ncols_pad) return;
+  const int64_t pc = p < npts ? p : npts - 1;
+  double xs[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) xs[k] = (x[pc * DIM + k] - ds.center[k]) * ds.inv_scale[k];
+  double acc = 0.0;
+  for (int c = 0; c < nrows; ++c) {
+    double f = 0.0;
+    if (c < ds.nc) {
+      if (ds.variant == GSS_KRIG_ORDINARY) {
+        f = 1.0;
+      } else if (ds.variant == GSS_KRIG_UNIVERSAL) {
+        f = 1.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          for (int q = 0; q < ds.e[c][k]; ++q) f *= xs[k];
+      } else {
+        f = drift_vals[pc * ds.nc + c];
+      }
+      if (wd) acc = fma(wd[c], f, acc);
+    }
+    out[(int64_t)c * ld + p] = f;
+  }
+  if (mean_part) mean_part[p] = acc;
+}
+
+// R[j * ldr + p] = C(x_j, x0_p) for the j rows of segment blockIdx.y; mean_part[seg][p] = sum wd_j C
+template <int DIM>
+__global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* __restrict__ xd, int n,
+                                                       const double* __restrict__ x0, int64_t m_valid,
+                                                       const double* __restrict__ wd, double* __restrict__ R,
+                                                       int64_t ldr, double* __restrict__ mean_part, int seg_len) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pc = p < m_valid ? p : m_valid - 1;
+  double c[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) c[k] = x0[pc * DIM + k];
+  const int j0 = blockIdx.y * seg_len;
+  const int j1 = j0 + seg_len < n ? j0 + seg_len : n;
+  double acc = 0.0;
+  double* rp = R + (int64_t)j0 * ldr + p;
+#pragma unroll 4
+  for (int j = j0; j < j1; ++j) {
+    double x[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
+    const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
+    const double cv = cov_from_d2(vg, d2);
+    *rp = cv;
+    rp += ldr;
+    acc = fma(wd[j], cv, acc);
+  }
+  mean_part[(int64_t)blockIdx.y * ldr + p] = acc;
+}
+
+// K3.  One workgroup owns a strip of BN = 128 points and walks the row blocks I of W' (lower
+// triangular, column-major, zero padded to ldw x N1pad).  For row block I only k < (I+1)*BM
+// contributes.  Global -> register -> LDS staging is double buffered: one barrier per BK stage.
+constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
+
+__global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
+    const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
+    int64_t ldr, const double* __restrict__ mean_part, int nparts, double sill, double mean0, int64_t m_valid,
+    double* __restrict__ mean_out, double* __restrict__ var_out, uint8_t* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                 // [2][TILE_LDS]
+  double* Bs = smem + 2 * TILE_LDS;  // [2][TILE_LDS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t p0 = (int64_t)blockIdx.x * BN;
+
+  // staging map: thread moves 2 consecutive doubles of rows kq, kq+4, kq+8, kq+12 of each operand
+  const int i2 = (tid & 63) * 2;
+  const int kq = tid >> 6;
+
+  double qacc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int nI = (N1 + BM - 1) / BM;
+
+  for (int I = 0; I < nI; ++I) {
+    const int i0 = I * BM;
+    const int kend = (i0 + BM < N1pad) ? i0 + BM : N1pad;
+    const int ntile = kend / BK;
+
+    d4 acc[4][4];
+    zero_acc(acc);
+
+    d2v ra[4], rb[4];
+    const double* wp = W + (int64_t)kq * ldw + i0 + i2;
+    const double* rp = R + (int64_t)kq * ldr + p0 + i2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ra[r] = *reinterpret_cast<const d2v*>(wp + (int64_t)(4 * r) * ldw);
+      rb[r] = *reinterpret_cast<const d2v*>(rp + (int64_t)(4 * r) * ldr);
+    }
+    __syncthreads();  // previous row block finished reading both LDS stages
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<d2v*>(As + (kq + 4 * r) * LDS_LD + i2) = ra[r];
+      *reinterpret_cast<d2v*>(Bs + (kq + 4 * r) * LDS_LD + i2) = rb[r];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+      const int cur = t & 1;
+      const bool more = (t + 1) < ntile;
+      if (more) {
+        const double* wq = wp + (int64_t)(t + 1) * BK * ldw;
+        const double* rq = rp + (int64_t)(t + 1) * BK * ldr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ra[r] = *reinterpret_cast<const d2v*>(wq + (int64_t)(4 * r) * ldw);
+          rb[r] = *reinterpret_cast<const d2v*>(rq + (int64_t)(4 * r) * ldr);
+        }
+      }
+      mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+      if (more) {
+        double* an = As + (cur ^ 1) * TILE_LDS;
+        double* bn = Bs + (cur ^ 1) * TILE_LDS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          *reinterpret_cast<d2v*>(an + (kq + 4 * r) * LDS_LD + i2) = ra[r];
+          *reinterpret_cast<d2v*>(bn + (kq + 4 * r) * LDS_LD + i2) = rb[r];
+        }
+      }
+      __syncthreads();
+    }
+
+    // signed squares: rows < n count +, constraint rows n..N1-1 count -, padding rows are zero
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      double s = 0.0;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + wm * 64 + tm * 16 + lk + 4 * r;
+          const double v = acc[tm][tn][r];
+          const double vv = v * v;
+          s += (row < n) ? vv : -vv;
+        }
+      qacc[tn] += s;
+    }
+  }
+
+  // reduce over the 4 lane groups (rows) of the wave, then over the two wave rows of the workgroup
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    qacc[tn] += __shfl_xor(qacc[tn], 16);
+    qacc[tn] += __shfl_xor(qacc[tn], 32);
+  }
+  __syncthreads();
+  double* red = smem;  // [2][BN]
+  if (lk == 0) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
+  }
+  __syncthreads();
+  if (tid < BN) {
+    const int64_t p = p0 + tid;
+    if (p < m_valid) {
+      const double q = red[tid] + red[BN + tid];
+      double mu = mean0;
+      for (int s = 0; s < nparts; ++s) mu += mean_part[(int64_t)s * ldr + p];
+      const double v = sill - q;
+      mean_out[p] = mu;
+      var_out[p] = v > 0.0 ? v : 0.0;
+      if (status_out) status_out[p] = GSS_PT_OK;
+    }
+  }
+}
+
+__global__ void flip_tail_kernel(double* u, int64_t from, int64_t to) {
+  const int64_t i = from + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < to) u[i] = -u[i];
+}
+
+__global__ void sub_scalar_kernel(double* z, int64_t n, double mu) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] -= mu;
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+struct gss_krig {
+  VgDev vg;
+  int variant = GSS_KRIG_ORDINARY;
+  double sk_mean = 0.0;
+  int degree = 0;
+  int ndrift = 0;
+  int dim = 0;
+  int64_t n = 0;
+  int nc = 0;
+  int64_t N1 = 0, N1pad = 0, ldw = 0;
+  DriftSpec ds;
+  DevBuf xdata, z, drift_data;
+  DevBuf factor;  // W' (ldw x N1pad, column-major) followed by wd (N1pad)
+  bool factored = false;
+  // prediction workspace
+  DevBuf R, mean_part;
+  int64_t mc = 0, ldr = 0;
+  double* Wp() const { return factor.as<double>(); }
+  double* wd() const { return factor.as<double>() + ldw * N1pad; }
+};
+
+static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
+  // graded order: total degree 0, 1, ..., `degree`; column order does not change the weights
+  e.clear();
+  for (int total = 0; total <= degree; ++total) {
+    int idx[3] = {0, 0, 0};
+    // enumerate tuples in lexicographic order with the first coordinate slowest
+    const int lim = total + 1;
+    const int cnt = (dim == 1) ? lim : (dim == 2 ? lim * lim : lim * lim * lim);
+    for (int t = 0; t < cnt; ++t) {
+      int r = t;
+      for (int k = dim - 1; k >= 0; --k) {
+        idx[k] = r % lim;
+        r /= lim;
+      }
+      int sum = 0;
+      for (int k = 0; k < dim; ++k) sum += idx[k];
+      if (sum == total) {
+        for (int k = 0; k < 3; ++k) e.push_back((signed char)(k < dim ? idx[k] : 0));
+      }
+    }
+  }
+}
+
+static int32_t launch_drift_rows(const gss_krig* h, const double* x, const double* drift_vals, int64_t npts,
+                                 int64_t ncols_pad, double* out, int64_t ld, int nrows, const double* wd,
+                                 double* mean_part, hipStream_t s) {
+  dim3 grid((unsigned)((ncols_pad + 255) / 256));
+  switch (h->dim) {
+    case 1:
+      hipLaunchKernelGGL((drift_rows_kernel<1>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
+                         ld, nrows, wd, mean_part);
+      break;
+    case 2:
+      hipLaunchKernelGGL((drift_rows_kernel<2>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
+                         ld, nrows, wd, mean_part);
+      break;
+    default:
+      hipLaunchKernelGGL((drift_rows_kernel<3>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
+                         ld, nrows, wd, mean_part);
+      break;
+  }
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
+  const int64_t n = h->n, N1 = h->N1, N1pad = h->N1pad, ldw = h->ldw;
+  const int nc = h->nc;
+  // M: working matrix (column-major, ld = ldw) whose top-left n x n receives C then L
+  DevBuf M, T, info, scratch;
+  GSS_TRY(M.alloc(sizeof(double) * (size_t)(ldw * N1pad)));
+  GSS_HIP(hipMemsetAsync(M.p, 0, M.bytes, s));
+  GSS_HIP(hipMemsetAsync(h->factor.p, 0, h->factor.bytes, s));
+  GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M.as<double>(), ldw, s));
+  GSS_TRY(info.alloc(sizeof(int)));
+  GSS_TRY(potrf_f64(M.as<double>(), n, ldw, info.as<int>(), s));
+  int hinfo = 0;
+  GSS_HIP(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (hinfo != 0) {
+    set_error("kriging covariance matrix is not positive definite (pivot %d of %lld); add a nugget or remove "
+              "duplicate samples", hinfo - 1, (long long)n);
+    return GSS_ERR_NOT_POSDEF;
+  }
+  const int64_t hh = n / 2 + 64;
+  GSS_TRY(T.alloc(sizeof(double) * (size_t)(hh * hh > (int64_t)MAX_NC * n ? hh * hh : (int64_t)MAX_NC * n)));
+  double* Wp = h->Wp();
+  GSS_TRY(trtri_f64(M.as<double>(), n, ldw, Wp, ldw, T.as<double>(), s));
+
+  if (nc > 0) {
+    DevBuf Fd, Bm, S, WS;
+    GSS_TRY(Fd.alloc(sizeof(double) * (size_t)(n * nc)));
+    GSS_TRY(Bm.alloc(sizeof(double) * (size_t)(n * nc)));
+    GSS_TRY(S.alloc(sizeof(double) * MAX_NC * MAX_NC));
+    GSS_TRY(WS.alloc(sizeof(double) * MAX_NC * MAX_NC));
+    GSS_HIP(hipMemsetAsync(S.p, 0, S.bytes, s));
+    GSS_HIP(hipMemsetAsync(WS.p, 0, WS.bytes, s));
+    // Fd (n x nc, column-major): drift functions at the data locations
+    GSS_TRY(launch_drift_rows(h, h->xdata.as<double>(), h->drift_data.as<double>(), n, n, Fd.as<double>(), n, nc,
+                              nullptr, nullptr, s));
+    // Bm (nc x n row-major) = F' W'   i.e. Bm(c,i) = sum_k F(k,c) W(i,k)
+    GSS_TRY(gemm_f64(nc, n, n, 1.0, Fd.as<double>(), n, 1, Wp, ldw, 1, 0.0, Bm.as<double>(), n, 1, false, s));
+    // S (nc x nc, column-major ld = MAX_NC) = Bm Bm'
+    GSS_TRY(gemm_f64(nc, nc, n, 1.0, Bm.as<double>(), n, 1, Bm.as<double>(), 1, n, 0.0, S.as<double>(), 1, MAX_NC,
+                     false, s));
+    GSS_TRY(potrf_f64(S.as<double>(), nc, MAX_NC, info.as<int>(), s));
+    GSS_HIP(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (hinfo != 0) {
+      set_error("drift functions are linearly dependent on the sample locations (constraint %d)", hinfo - 1);
+      return GSS_ERR_NOT_POSDEF;
+    }
+    // W'[n:, n:] = inv(L_S)
+    GSS_TRY(trtri_f64(S.as<double>(), nc, MAX_NC, Wp + n + n * ldw, ldw, T.as<double>(), s));
+    // T (nc x n row-major) = Bm * W        T(c,j) = sum_k Bm(c,k) W(k,j)
+    GSS_TRY(gemm_f64(nc, n, n, 1.0, Bm.as<double>(), n, 1, Wp, 1, ldw, 0.0, T.as<double>(), n, 1, false, s));
+    // W'[n:, 0:n] = -inv(L_S) * T
+    GSS_TRY(gemm_f64(nc, n, nc, -1.0, Wp + n + n * ldw, 1, ldw, T.as<double>(), n, 1, 0.0, Wp + n, 1, ldw, false,
+                     s));
+    GSS_HIP(hipStreamSynchronize(s));
+  }
+
+  // dual weights wd = W'' D W' [z - mean; 0]
+  DevBuf zz, u;
+  GSS_TRY(zz.alloc(sizeof(double) * (size_t)ldw));
+  GSS_TRY(u.alloc(sizeof(double) * (size_t)ldw));
+  GSS_HIP(hipMemsetAsync(zz.p, 0, zz.bytes, s));
+  GSS_HIP(hipMemcpyAsync(zz.p, h->z.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
+    hipLaunchKernelGGL(sub_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zz.as<double>(), n,
+                       h->sk_mean);
+  }
+  GSS_TRY(gemv_f64(false, N1, N1, Wp, ldw, zz.as<double>(), u.as<double>(), s));
+  if (nc > 0) {
+    hipLaunchKernelGGL(flip_tail_kernel, dim3(1), dim3(256), 0, s, u.as<double>(), n, N1);
+  }
+  GSS_TRY(gemv_f64(true, N1, N1, Wp, ldw, u.as<double>(), h->wd(), s));
+  GSS_HIP(hipGetLastError());
+  GSS_HIP(hipStreamSynchronize(s));
+  (void)N1pad;
+  h->factored = true;
+  return GSS_OK;
+}
+
+extern "C" {
+
+int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t variant, double sk_mean,
+                        int32_t degree, int32_t ndrift, const double* xdata, const double* z,
+                        const double* drift_data, int64_t n, int32_t flags, void* stream) {
+  GSS_REQUIRE(out != nullptr, "gss_krig_create: out is NULL");
+  *out = nullptr;
+  GSS_REQUIRE(xdata != nullptr && z != nullptr, "gss_krig_create: NULL data");
+  // krig.jl:100-102: at least one non-missing sample
+  GSS_REQUIRE(n >= 1, "all samples are missing, aborting...");
+  GSS_REQUIRE(n < (1 << 30), "too many samples");
+  gss_krig* h = new (std::nothrow) gss_krig();
+  if (!h) return GSS_ERR_ALLOC;
+  struct Guard {
+    gss_krig* h;
+    ~Guard() { delete h; }
+  } guard{h};
+  GSS_TRY(make_vgdev(vg, &h->vg));
+  h->variant = variant;
+  h->sk_mean = sk_mean;
+  h->degree = degree;
+  h->ndrift = ndrift;
+  h->dim = h->vg.dim;
+  h->n = n;
+  std::memset(&h->ds, 0, sizeof(h->ds));
+  h->ds.variant = variant;
+  h->ds.dim = h->dim;
+  for (int k = 0; k < 3; ++k) {
+    h->ds.center[k] = 0.0;
+    h->ds.inv_scale[k] = 1.0;
+  }
+  switch (variant) {
+    case GSS_KRIG_SIMPLE: h->nc = 0; break;
+    case GSS_KRIG_ORDINARY: h->nc = 1; break;
+    case GSS_KRIG_UNIVERSAL: {
+      GSS_REQUIRE(degree >= 0 && degree <= 3, "universal kriging degree %d outside 0..3", degree);
+      std::vector<signed char> e;
+      uk_exponents(h->dim, degree, e);
+      h->nc = (int)(e.size() / 3);
+      GSS_REQUIRE(h->nc <= MAX_NC, "too many drift terms");
+      for (int c = 0; c < h->nc; ++c)
+        for (int k = 0; k < 3; ++k) h->ds.e[c][k] = e[3 * c + k];
+      // centre / scale the monomials' coordinates (same polynomial space, better conditioning)
+      for (int k = 0; k < h->dim; ++k) {
+        double lo = xdata[k], hi = xdata[k];
+        for (int64_t i = 1; i < n; ++i) {
+          const double v = xdata[i * h->dim + k];
+          lo = v < lo ? v : lo;
+          hi = v > hi ? v : hi;
+        }
+        h->ds.center[k] = 0.5 * (lo + hi);
+        const double half = 0.5 * (hi - lo);
+        h->ds.inv_scale[k] = half > 0.0 ? 1.0 / half : 1.0;
+      }
+      break;
+    }
+    case GSS_KRIG_EXTDRIFT:
+      GSS_REQUIRE(ndrift >= 1 && ndrift <= MAX_NC && drift_data != nullptr, "external drift needs 1..%d drifts",
+                  MAX_NC);
+      h->nc = ndrift;
+      break;
+    default:
+      GSS_REQUIRE(false, "unknown kriging variant %d", variant);
+  }
+  h->ds.nc = h->nc;
+  if ((flags & GSS_KRIG_NO_FACTOR) == 0)
+    GSS_REQUIRE(n + h->nc >= 1 && n >= h->nc, "fewer samples (%lld) than drift constraints (%d)", (long long)n,
+                h->nc);
+  h->N1 = n + h->nc;
+  h->N1pad = round_up(h->N1, BK);
+  h->ldw = round_up(h->N1, BM);
+
+  hipStream_t s = to_stream(stream);
+  GSS_TRY(h->xdata.alloc(sizeof(double) * (size_t)(n * h->dim)));
+  GSS_TRY(h->z.alloc(sizeof(double) * (size_t)n));
+  GSS_HIP(hipMemcpyAsync(h->xdata.p, xdata, sizeof(double) * n * h->dim, hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(h->z.p, z, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  if (variant == GSS_KRIG_EXTDRIFT) {
+    GSS_TRY(h->drift_data.alloc(sizeof(double) * (size_t)(n * ndrift)));
+    GSS_HIP(hipMemcpyAsync(h->drift_data.p, drift_data, sizeof(double) * n * ndrift, hipMemcpyHostToDevice, s));
+  }
+  GSS_HIP(hipStreamSynchronize(s));
+  // the factor buffer always exists so that a broadcast can land in it
+  GSS_TRY(h->factor.alloc(sizeof(double) * (size_t)(h->ldw * h->N1pad + h->N1pad)));
+  if ((flags & GSS_KRIG_NO_FACTOR) == 0) GSS_TRY(krig_factorize(h, s));
+  guard.h = nullptr;
+  *out = h;
+  return GSS_OK;
+}
+
+int32_t gss_krig_destroy(gss_krig_t* h) {
+  delete h;
+  return GSS_OK;
+}
+
+int32_t gss_krig_info(const gss_krig_t* h, int64_t* n, int32_t* nc) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  if (n) *n = h->n;
+  if (nc) *nc = h->nc;
+  return GSS_OK;
+}
+
+int32_t gss_krig_factor_buffer(gss_krig_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
+  *dev_ptr = h->factor.p;
+  *bytes = (int64_t)(sizeof(double) * (size_t)(h->ldw * h->N1pad + h->N1pad));
+  return GSS_OK;
+}
+
+int32_t gss_krig_adopt_factor(gss_krig_t* h) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  h->factored = true;
+  return GSS_OK;
+}
+
+int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
+                                double* mean, double* var, uint8_t* status, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_REQUIRE(h->factored, "handle has no factor (created with GSS_KRIG_NO_FACTOR and never adopted one)");
+  GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_global: NULL array");
+  GSS_REQUIRE(h->variant != GSS_KRIG_EXTDRIFT || drift_dom != nullptr, "external drift values missing");
+  if (m == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  const int dim = h->dim;
+
+  static bool attr_set = false;
+  if (!attr_set) {
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
+    attr_set = true;
+  }
+
+  // chunk size from the workspace budget (default 1.5 GiB of RHS tiles; GSS_KRIG_WS_MB overrides)
+  size_t ws = (size_t)1536 << 20;
+  if (const char* e = std::getenv("GSS_KRIG_WS_MB")) {
+    const long v = std::atol(e);
+    if (v > 0) ws = (size_t)v << 20;
+  }
+  int64_t cap = (int64_t)(ws / (sizeof(double) * (size_t)h->N1pad)) / 256 * 256;
+  if (cap < 256) cap = 256;
+  const int64_t mc = round_up(m, 256) < cap ? round_up(m, 256) : cap;
+  if (h->mc < mc) {
+    GSS_HIP(hipStreamSynchronize(s));
+    GSS_TRY(h->R.alloc(sizeof(double) * (size_t)(h->N1pad * mc)));
+    GSS_TRY(h->mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
+    h->mc = mc;
+  }
+  const int64_t ldr = h->mc;
+  const int seg_len = (int)((h->n + NSEG - 1) / NSEG);
+
+  Staged sx, sd, smean, svar, sstat;
+  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  if (h->variant == GSS_KRIG_EXTDRIFT) GSS_TRY(sd.in(drift_dom, sizeof(double) * m * h->ndrift, mem, s));
+  GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
+  GSS_TRY(svar.out(var, sizeof(double) * m, mem));
+  GSS_TRY(sstat.out(status, (size_t)m, mem));
+
+  for (int64_t off = 0; off < m; off += mc) {
+    const int64_t mv = (m - off) < mc ? (m - off) : mc;
+    const int64_t cols = round_up(mv, 256);  // multiple of BN as well
+    const double* x0 = sx.as<double>() + off * dim;
+    dim3 g1((unsigned)(cols / 256), NSEG);
+    const int nrows = (int)(h->N1pad - h->n);
+    {
+      ProfScope ps("krig_rhs", s);
+      switch (dim) {
+      case 1:
+        hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
+                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+      case 2:
+        hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
+                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+      default:
+        hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
+                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+    }
+    GSS_HIP(hipGetLastError());
+    // drift rows n..N1-1 and zero rows up to N1pad, plus their share of the mean
+    if (nrows > 0) {
+      const double* dv = h->variant == GSS_KRIG_EXTDRIFT ? sd.as<double>() + off * h->ndrift : nullptr;
+      GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, h->R.as<double>() + h->n * ldr, ldr, nrows, h->wd() + h->n,
+                                h->mean_part.as<double>() + (int64_t)NSEG * ldr, s));
+    }
+    }
+    const int nparts = nrows > 0 ? NSEG + 1 : NSEG;
+    ProfScope pq("krig_quadform", s);
+    hipLaunchKernelGGL(krig_quadform_kernel, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
+                       h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, h->R.as<double>(), ldr,
+                       h->mean_part.as<double>(), nparts, h->vg.sill,
+                       h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
+                       svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
+  GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
+  GSS_TRY(sstat.back(status, (size_t)m, mem, s));
+  return GSS_OK;
+}
+
+}  // extern "C"

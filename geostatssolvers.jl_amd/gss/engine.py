@@ -1,0 +1,275 @@
+"""Array-level engine over the C-ABI: the one place where Python touches libgss_hip.so.
+
+Every method takes numpy arrays (host: the library stages them through PCIe) or CUDA torch tensors
+(device: zero-copy, asynchronous on torch's current stream) and returns the same kind.
+`HipEngine` is the only engine the product ships; the solver front-ends take an `engine=` argument
+so that the CPU-only multi-process tests can exercise the sharding/host logic with a stand-in.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import MEM_DEVICE, MEM_HOST, check, current_stream, is_torch, make_variogram, ptr
+
+SK, OK, UK, EDK = 0, 1, 2, 3
+
+
+def _vg_struct(vg, dim):
+    return make_variogram(vg.kind, dim, vg.sill, vg.nugget, vg.range, vg.nu, vg.radii)
+
+
+def _space(x):
+    return MEM_DEVICE if is_torch(x) else MEM_HOST
+
+
+def _empty_like_space(ref, shape, dtype):
+    if is_torch(ref):
+        import torch
+        tdt = {np.float64: torch.float64, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+        return torch.empty(shape, dtype=tdt, device=ref.device)
+    return np.empty(shape, dtype=dtype)
+
+
+def _prep_in(x, dtype=np.float64):
+    """Contiguous array of the right dtype in the space it already lives in."""
+    if x is None:
+        return None
+    if is_torch(x):
+        import torch
+        tdt = {np.float64: torch.float64, np.int64: torch.int64}[dtype]
+        if not x.is_cuda:
+            return np.ascontiguousarray(x.numpy(), dtype=dtype)
+        return x.to(tdt).contiguous()
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+class KrigHandle:
+    """gss_krig_t*: fitted kriging system living in HBM."""
+
+    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True):
+        self._l = _lib.lib()
+        x = np.ascontiguousarray(xdata, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        self.n, self.dim = x.shape
+        zz = np.ascontiguousarray(z, dtype=np.float64)
+        dd = None if drift_data is None else np.ascontiguousarray(drift_data, dtype=np.float64).reshape(self.n, -1)
+        self.ndrift = 0 if dd is None else dd.shape[1]
+        self.variant = variant
+        h = C.c_void_p()
+        v = _vg_struct(vg, self.dim)
+        check(self._l.gss_krig_create(C.byref(h), C.byref(v), variant, float(mean or 0.0), int(degree or 0),
+                                      self.ndrift, ptr(x), ptr(zz), ptr(dd), self.n,
+                                      0 if factor else _lib.KRIG_NO_FACTOR, current_stream()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.gss_krig_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def factor_tensor(self):
+        """CUDA tensor aliasing the factor state (for torch.distributed.broadcast over RCCL)."""
+        import torch
+        p, nb = C.c_void_p(), C.c_int64()
+        check(self._l.gss_krig_factor_buffer(self._h, C.byref(p), C.byref(nb)))
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (nb.value // 8,), "typestr": "<f8", "data": (p.value, False),
+                                        "version": 3, "strides": None}
+        t = torch.as_tensor(_Alias(), device=f"cuda:{torch.cuda.current_device()}")
+        t._gss_keepalive = self
+        return t
+
+    def adopt_factor(self):
+        check(self._l.gss_krig_adopt_factor(self._h))
+
+    def predict_global(self, xdom, drift_dom=None):
+        xdom = _prep_in(xdom)
+        m = xdom.shape[0]
+        mem = _space(xdom)
+        mean = _empty_like_space(xdom, (m,), np.float64)
+        var = _empty_like_space(xdom, (m,), np.float64)
+        status = _empty_like_space(xdom, (m,), np.uint8)
+        dd = _prep_in(drift_dom)
+        check(self._l.gss_krig_predict_global(self._h, ptr(xdom), ptr(dd), m, ptr(mean), ptr(var), ptr(status),
+                                              mem, current_stream()))
+        return mean, var, status
+
+    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False):
+        xdom = _prep_in(xdom)
+        m = xdom.shape[0]
+        mem = _space(xdom)
+        mean = _empty_like_space(xdom, (m,), np.float64)
+        var = _empty_like_space(xdom, (m,), np.float64)
+        status = _empty_like_space(xdom, (m,), np.uint8)
+        idx = _empty_like_space(xdom, (m, k), np.int32) if return_idx else None
+        cnt = _empty_like_space(xdom, (m,), np.int32) if return_idx else None
+        ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
+        r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
+        dd = _prep_in(drift_dom)
+        check(self._l.gss_krig_predict_knn(self._h, ptr(xdom), ptr(dd), m, int(k), int(minneighbors), r, ptr(ir),
+                                           ptr(mean), ptr(var), ptr(status), ptr(idx), ptr(cnt), mem,
+                                           current_stream()))
+        if return_idx:
+            return mean, var, status, idx, cnt
+        return mean, var, status
+
+    def predict_global_batch(self, xdom, zbatch):
+        xdom = _prep_in(xdom)
+        zb = _prep_in(zbatch)
+        if _space(zb) != _space(xdom):
+            raise ValueError("xdom and zbatch must live in the same memory space")
+        nb = zb.shape[0]
+        m = xdom.shape[0]
+        out = _empty_like_space(xdom, (nb, m), np.float64)
+        check(self._l.gss_krig_predict_global_batch(self._h, ptr(xdom), m, ptr(zb), nb, ptr(out), _space(xdom),
+                                                    current_stream()))
+        return out
+
+
+class FFTGSHandle:
+    """gss_fftgs_t*: spectral amplitude + rocFFT plans for one variable."""
+
+    def __init__(self, vg, dims, spacing=None, mean=0.0):
+        self._l = _lib.lib()
+        self.dims = tuple(int(d) for d in dims)
+        nd = len(self.dims)
+        d = (C.c_int64 * 3)(*(list(self.dims) + [1] * (3 - nd)))
+        sp = (C.c_double * 3)(*([float(s) for s in (spacing if spacing is not None else [1.0] * nd)] + [1.0] * (3 - nd)))
+        v = _vg_struct(vg, nd)
+        h = C.c_void_p()
+        check(self._l.gss_fftgs_create(C.byref(h), C.byref(v), nd, d, sp, float(mean), 0, current_stream()))
+        self._h = h
+        self.N = int(np.prod(self.dims))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.gss_fftgs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def spectrum(self):
+        out = np.empty(self.N)
+        check(self._l.gss_fftgs_spectrum(self._h, ptr(out), MEM_HOST, current_stream()))
+        return out
+
+    def realize(self, seed, first_real, nreals, noise=None, inds=None, out=None, device=False):
+        """nreals x npts realisations; `device=True` (or a CUDA `out`/`noise`) keeps them in HBM."""
+        noise = _prep_in(noise)
+        npts = self.N if inds is None else len(inds)
+        if out is None:
+            if device or is_torch(noise):
+                import torch
+                out = torch.empty((nreals, npts), dtype=torch.float64, device="cuda")
+            else:
+                out = np.empty((nreals, npts))
+        mem = _space(out)
+        if noise is not None and _space(noise) != mem:
+            raise ValueError("noise and out must live in the same memory space")
+        ii = None
+        if inds is not None:
+            if mem == MEM_DEVICE:
+                import torch
+                ii = torch.as_tensor(np.asarray(inds, dtype=np.int64), device=out.device)
+            else:
+                ii = np.ascontiguousarray(inds, dtype=np.int64)
+        check(self._l.gss_fftgs_realize(self._h, int(seed), int(first_real), int(nreals), ptr(noise), ptr(ii),
+                                        0 if inds is None else npts, ptr(out), mem, current_stream()))
+        return out
+
+
+class LUGSHandle:
+    """gss_lugs_t*: d2 and L22 in HBM for one variable."""
+
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0):
+        self._l = _lib.lib()
+        c = np.ascontiguousarray(centroids, dtype=np.float64)
+        if c.ndim == 1:
+            c = c[:, None]
+        self.N, dim = c.shape
+        dl = np.ascontiguousarray(dlocs, dtype=np.int64)
+        zz = np.ascontiguousarray(z1, dtype=np.float64)
+        v = _vg_struct(vg, dim)
+        h = C.c_void_p()
+        check(self._l.gss_lugs_create(C.byref(h), C.byref(v), ptr(c), self.N, ptr(dl), ptr(zz), dl.size,
+                                      float(mean), 0, current_stream()))
+        self._h = h
+        self.nd = int(dl.size)
+        self.ns = self.N - self.nd
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.gss_lugs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def factor(self):
+        l22 = np.empty((self.ns, self.ns))
+        d2 = np.empty(self.ns)
+        check(self._l.gss_lugs_factor(self._h, ptr(l22), ptr(d2), MEM_HOST, current_stream()))
+        return l22.T.copy(), d2          # column-major on the wire -> numpy (row, col)
+
+    def realize(self, seed, first_real, nreals, noise=None, rho=None, w1=None, device=False):
+        noise = _prep_in(noise)
+        w1 = _prep_in(w1)
+        if device or is_torch(noise) or is_torch(w1):
+            import torch
+            out = torch.empty((nreals, self.N), dtype=torch.float64, device="cuda")
+            wout = torch.empty((nreals, self.ns), dtype=torch.float64, device="cuda")
+        else:
+            out = np.empty((nreals, self.N))
+            wout = np.empty((nreals, self.ns))
+        check(self._l.gss_lugs_realize(self._h, int(seed), int(first_real), int(nreals), ptr(noise),
+                                       0.0 if rho is None else float(rho), ptr(w1), ptr(out), ptr(wout), _space(out),
+                                       current_stream()))
+        return out, wout
+
+
+class HipEngine:
+    """The product engine: every call lands in a gfx950 kernel."""
+    name = "hip"
+    Krig = KrigHandle
+    FFTGS = FFTGSHandle
+    LUGS = LUGSHandle
+
+    @staticmethod
+    def cov_pairwise(vg, a, b=None):
+        l = _lib.lib()
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[:, None]
+        bb = a if b is None else np.ascontiguousarray(b, dtype=np.float64).reshape(-1, a.shape[1])
+        out = np.empty((a.shape[0], bb.shape[0]))
+        v = _vg_struct(vg, a.shape[1])
+        check(l.gss_cov_pairwise(C.byref(v), ptr(a), a.shape[0], None if b is None else ptr(bb), bb.shape[0],
+                                 ptr(out), bb.shape[0], MEM_HOST, current_stream()))
+        return out
+
+    @staticmethod
+    def knn_search(xdata, centers, k, radius=None, radii=None):
+        l = _lib.lib()
+        x = np.ascontiguousarray(xdata, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        c = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, x.shape[1])
+        m = c.shape[0]
+        idx = np.empty((m, k), dtype=np.int32)
+        cnt = np.empty(m, dtype=np.int32)
+        ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
+        r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
+        check(l.gss_knn_search(ptr(x), x.shape[0], x.shape[1], ptr(c), m, int(k), r, ptr(ir), ptr(idx), ptr(cnt),
+                               MEM_HOST, current_stream()))
+        return idx, cnt
+
+
+def default_engine():
+    return HipEngine

@@ -1,0 +1,350 @@
+"""Solver front-ends with the reference's parameter surface and `solve(problem, solver)` entry.
+
+    KrigingSolver  <- /root/reference/src/estimation/krig.jl:64-234  (+ ui.jl:11-50)
+    FFTGS          <- /root/reference/src/simulation/fft.jl:51-198
+    LUGS           <- /root/reference/src/simulation/lu.jl:67-224
+
+This is host logic only (parameter handling, missing values, model choice, sharding); all
+arithmetic is delegated to the engine (gfx950 kernels through the C-ABI).  Julia's
+`Solver(:z => (variogram=..., maxneighbors=3))` becomes `Solver(("z", dict(variogram=..., maxneighbors=3)))`
+or `Solver(z=dict(...))`; joint parameters `(:z, :y) => (correlation=0.95,)` become
+`(("z", "y"), dict(correlation=0.95))`.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import parallel
+from .engine import EDK, OK, SK, UK, default_engine
+from .geo import Ensemble, GeoTable, PointSet, georef, parent, parentindices
+from .problems import EstimationProblem, SimulationProblem
+from .variograms import GaussianVariogram, MetricBall
+
+_GLOBAL_KEYS = {"rng", "threads", "init", "engine"}
+
+
+class _Solver:
+    PARAMS: Dict[str, object] = {}
+    JPARAMS: Dict[str, object] = {}
+    GLOBALS: Dict[str, object] = {}
+
+    def __init__(self, *pairs, **kw):
+        self.vparams: Dict[str, dict] = {}
+        self.jparams: Dict[frozenset, dict] = {}
+        self.globals = dict(self.GLOBALS)
+        for k in list(kw):
+            if k in self.GLOBALS or k in _GLOBAL_KEYS:
+                self.globals[k] = kw.pop(k)
+        items = list(pairs) + list(kw.items())
+        for key, val in items:
+            val = dict(val)
+            if isinstance(key, (tuple, list, frozenset)):
+                bad = set(val) - set(self.JPARAMS)
+                if bad:
+                    raise ValueError(f"invalid joint parameters {sorted(bad)}")
+                self.jparams[frozenset(key)] = {**self.JPARAMS, **val}
+                self._jorder = getattr(self, "_jorder", {})
+                self._jorder[frozenset(key)] = tuple(key)
+            else:
+                bad = set(val) - set(self.PARAMS)
+                if bad:
+                    raise ValueError(f"invalid parameters {sorted(bad)} for variable {key}")
+                self.vparams[key] = {**self.PARAMS, **val}
+
+    def params(self, var: str) -> dict:
+        return self.vparams.get(var, dict(self.PARAMS))
+
+    def covariables(self, problem):
+        """[DEP] GeoStatsBase.covariables: variables tied by joint parameters form one group."""
+        names = list(problem.variables)
+        groups, seen = [], set()
+        for key in self.jparams:
+            grp = tuple(v for v in getattr(self, "_jorder", {}).get(key, tuple(key)) if v in names)
+            if len(grp) == len(key):
+                groups.append(grp)
+                seen.update(grp)
+        for v in names:
+            if v not in seen:
+                groups.append((v,))
+        return groups
+
+    @property
+    def engine(self):
+        return self.globals.get("engine") or default_engine()
+
+
+def _seed_from(rng) -> int:
+    """`rng` may be an int seed, a numpy Generator (consumed once per solve) or None."""
+    if rng is None:
+        return int(np.random.default_rng().integers(0, 2 ** 63 - 1))
+    if isinstance(rng, (int, np.integer)):
+        return int(rng)
+    return int(rng.integers(0, 2 ** 63 - 1))
+
+
+def _ball(neighborhood):
+    if neighborhood is None:
+        return None, None
+    if not isinstance(neighborhood, MetricBall):
+        raise TypeError("neighborhood must be a MetricBall")
+    if neighborhood.isotropic:
+        return neighborhood.radii[0], None
+    return None, neighborhood.radii
+
+
+# ------------------------------------------------------------------------------------------
+# ui.jl
+# ------------------------------------------------------------------------------------------
+def kriging_ui(domain, variogram, mean, degree, drifts):
+    """ui.jl:40-50: drifts > degree > mean > ordinary."""
+    if drifts is not None:
+        return EDK
+    if degree is not None:
+        return UK
+    if mean is not None:
+        return SK
+    return OK
+
+
+def searcher_ui(domain, maxneighbors, metric, neighborhood):
+    """ui.jl:11-32 -> (kind, nmax) with the reference's warning text."""
+    nelem = domain.nelements()
+    if maxneighbors is None:
+        nmax = nelem
+    elif maxneighbors < 1 or maxneighbors > nelem:
+        warnings.warn(f"Invalid maximum number of neighbors. Adjusting to {nelem}...")
+        nmax = nelem
+    else:
+        nmax = maxneighbors
+    return ("KNearestSearch" if neighborhood is None else "KBallSearch"), nmax
+
+
+# ------------------------------------------------------------------------------------------
+# KrigingSolver
+# ------------------------------------------------------------------------------------------
+class KrigingSolver(_Solver):
+    PARAMS = dict(variogram=GaussianVariogram(), mean=None, degree=None, drifts=None, minneighbors=1,
+                  maxneighbors=None, neighborhood=None, distance="euclidean", path="linear")   # krig.jl:64-74
+
+    def preprocess(self, problem: EstimationProblem):
+        """krig.jl:76-128."""
+        pre = {}
+        ddom = problem.data.domain
+        coords = ddom.centroids()
+        for var in problem.variables:
+            p = self.params(var)
+            z = np.asarray(problem.data[var], dtype=np.float64)
+            inds = np.flatnonzero(~np.isnan(z))                       # krig.jl:97
+            if inds.size == 0:
+                raise AssertionError(f"all samples of {var} are missing, aborting...")   # krig.jl:100-102
+            if p["distance"] not in ("euclidean", None):
+                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            if p["path"] not in ("linear", None):
+                raise NotImplementedError("only LinearPath is available (results are per-point independent)")
+            vdom = PointSet(coords[inds])
+            variant = kriging_ui(problem.domain, p["variogram"], p["mean"], p["degree"], p["drifts"])
+            kind, nmax = searcher_ui(vdom, p["maxneighbors"], p["distance"], p["neighborhood"])
+            pre[var] = dict(x=vdom.coords, z=z[inds], variant=variant, minneighbors=p["minneighbors"],
+                            maxneighbors=p["maxneighbors"], nmax=nmax, searcher=kind, params=p)
+        return pre
+
+    def solve(self, problem: EstimationProblem, gather: bool = True):
+        """krig.jl:130-164 with the domain points sharded over ranks (parallel.shard_range)."""
+        pre = self.preprocess(problem)
+        pdom = problem.domain
+        xdom_all = pdom.centroids()
+        m = xdom_all.shape[0]
+        rank, ws = parallel.world()
+        lo, hi = parallel.shard_range(m, rank, ws)
+        xdom = xdom_all[lo:hi]
+        cols = {}
+        for var in problem.variables:
+            q = pre[var]
+            p = q["params"]
+            drift_data = drift_dom = None
+            if q["variant"] == EDK:
+                drift_data = np.stack([[f(c) for f in p["drifts"]] for c in q["x"]]).astype(np.float64)
+                drift_dom = np.stack([[f(c) for f in p["drifts"]] for c in xdom]).astype(np.float64)
+            exact = q["maxneighbors"] is None                          # krig.jl:151
+            h = self.engine.Krig(p["variogram"], q["variant"], q["x"], q["z"], mean=p["mean"], degree=p["degree"],
+                                 drift_data=drift_data, factor=exact)
+            try:
+                if hi > lo:
+                    if exact:
+                        mu, var_, st = h.predict_global(xdom, drift_dom)                 # krig.jl:166-186
+                    else:
+                        radius, radii = _ball(p["neighborhood"])
+                        mu, var_, st = h.predict_knn(xdom, q["nmax"], q["minneighbors"], radius, radii, drift_dom)
+                else:
+                    mu, var_, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
+            finally:
+                h.close()
+            mu = np.where(st == 0, mu, np.nan)                         # `missing` krig.jl:213-214
+            var_ = np.where(st == 0, var_, np.nan)
+            if gather and ws > 1:
+                mu = parallel.all_gather_concat(mu, m)
+                var_ = parallel.all_gather_concat(var_, m)
+            cols[var] = mu
+            cols[f"{var}_variance"] = var_                             # krig.jl:160
+        if gather or ws == 1:
+            return georef(cols, pdom)                                  # krig.jl:163
+        return georef(cols, PointSet(xdom))
+
+
+# ------------------------------------------------------------------------------------------
+# FFTGS
+# ------------------------------------------------------------------------------------------
+class FFTGS(_Solver):
+    PARAMS = dict(variogram=GaussianVariogram(), mean=0.0, minneighbors=1, maxneighbors=None, neighborhood=None,
+                  distance="euclidean")                                                        # fft.jl:51-60
+    GLOBALS = dict(threads=None, rng=None)
+
+    def preprocess(self, problem: SimulationProblem):
+        """fft.jl:62-143."""
+        pdom = problem.domain
+        pgrid = parent(pdom)
+        if not hasattr(pgrid, "dims"):
+            raise ValueError("FFTGS is limited to simulations on Cartesian grids")
+        pre = {}
+        for (var,) in [g for g in self.covariables(problem)]:
+            p = self.params(var)
+            vg = p["variogram"]
+            if not vg.isstationary():
+                raise ValueError("variogram model must be stationary")              # fft.jl:91-93
+            h = self.engine.FFTGS(vg, pgrid.dims, pgrid.spacing, p["mean"])         # fft.jl:96-103
+            zbar = krig = dinds = None
+            pdata = problem.data
+            if pdata is not None and var in pdata.table:                             # fft.jl:106-135
+                xd = pdata.domain.centroids()
+                zd = np.asarray(pdata[var], dtype=np.float64)
+                kdom = PointSet(pdom.centroids())
+                krig = KrigingSolver((var, dict(variogram=vg, mean=p["mean"], minneighbors=p["minneighbors"],
+                                                maxneighbors=p["maxneighbors"], neighborhood=p["neighborhood"],
+                                                distance=p["distance"])), engine=self.globals.get("engine"))
+                ksol = _solve_local(krig, georef({var: zd}, xd), kdom, var)           # fft.jl:125
+                zbar = ksol[var]
+                idx, _ = self.engine.knn_search(kdom.coords, xd, 1)                   # fft.jl:129-132
+                found = idx[:, 0]
+                _, first = np.unique(found, return_index=True)
+                dinds = found[np.sort(first)]
+            pre[var] = dict(vg=vg, mean=p["mean"], handle=h, zbar=zbar, krig=krig, dinds=dinds)
+        return pre
+
+    def solve(self, problem: SimulationProblem, gather: bool = True):
+        """GeoStatsBase's realisation loop ([DEP]) batched: realisations are sharded
+        over ranks, each rank produces its block in one device call (fft.jl:145-198)."""
+        pre = self.preprocess(problem)
+        seed = _seed_from(self.globals.get("rng"))
+        pdom = problem.domain
+        inds = parentindices(pdom)
+        rank, ws = parallel.world()
+        lo, hi = parallel.shard_range(problem.nreals, rank, ws)
+        reals = {}
+        for vi, var in enumerate(problem.variables):
+            q = pre[var]
+            zu = q["handle"].realize(seed + vi, lo, hi - lo, inds=inds) if hi > lo else \
+                np.empty((0, pdom.nelements()))
+            if q["krig"] is not None and hi > lo:                                     # fft.jl:176-192
+                cent = pdom.centroids()
+                out = np.empty_like(zu)
+                for r in range(zu.shape[0]):
+                    kdat = georef({var: zu[r, q["dinds"]]}, cent[q["dinds"]])
+                    zbar_u = _solve_local(q["krig"], kdat, PointSet(cent), var)[var]
+                    out[r] = q["zbar"] + (zu[r] - zbar_u)
+                zu = out
+            q["handle"].close()
+            if gather and ws > 1:
+                zu = parallel.all_gather_concat(zu, problem.nreals)
+            reals[var] = [zu[r] for r in range(zu.shape[0])]
+        return Ensemble(pdom, reals)
+
+
+def _solve_local(krig: KrigingSolver, data: GeoTable, dom, var):
+    """Nested kriging solve of the conditional path: every rank needs the full field, so no sharding."""
+    saved = parallel.world
+    parallel.world = lambda: (0, 1)
+    try:
+        return krig.solve(EstimationProblem(data, dom, var))
+    finally:
+        parallel.world = saved
+
+
+# ------------------------------------------------------------------------------------------
+# LUGS
+# ------------------------------------------------------------------------------------------
+class LUGS(_Solver):
+    PARAMS = dict(variogram=GaussianVariogram(), mean=None, factorization="cholesky")          # lu.jl:67-74
+    JPARAMS = dict(correlation=0.0)
+    GLOBALS = dict(init="nearest", rng=None)
+
+    def preprocess(self, problem: SimulationProblem):
+        """lu.jl:76-169."""
+        pdom = problem.domain
+        cent = pdom.centroids()
+        N = cent.shape[0]
+        if self.globals.get("init", "nearest") != "nearest":
+            raise NotImplementedError("only NearestInit is available")
+        pre = {}
+        for conames in self.covariables(problem):
+            assert len(conames) in (1, 2), "invalid number of covariables"          # lu.jl:96
+            co = {}
+            for var in conames:
+                p = self.params(var)
+                vg = p["variogram"]
+                assert vg.isstationary(), "variogram model must be stationary"      # lu.jl:110
+                if p["factorization"] != "cholesky":
+                    raise NotImplementedError(
+                        "factorization=lu: the reference uses only `.L` of a pivoted LU (lu.jl:128,134,139), "
+                        "which is not a square root of the covariance; the device path implements cholesky")
+                buff = np.zeros(N)
+                mask = np.zeros(N, dtype=bool)
+                pdata = problem.data
+                if pdata is not None and var in pdata.table:                         # initbuff, lu.jl:86
+                    xd = pdata.domain.centroids()
+                    zd = np.asarray(pdata[var], dtype=np.float64)
+                    keep = ~np.isnan(zd)
+                    idx, _ = self.engine.knn_search(cent, xd[keep], 1)
+                    for j, v in zip(idx[:, 0], zd[keep]):
+                        buff[j] = v
+                        mask[j] = True
+                dlocs = np.flatnonzero(mask)                                          # lu.jl:113
+                z1 = buff[dlocs]                                                      # lu.jl:114
+                if p["mean"] is not None and dlocs.size > 0:
+                    warnings.warn("mean can only be specified in unconditional simulation")   # lu.jl:142-144
+                mu = 0.0 if p["mean"] is None else float(p["mean"])                   # lu.jl:147
+                co[var] = self.engine.LUGS(vg, cent, dlocs, z1, mu)
+            rho = None
+            if len(conames) == 2:
+                rho = self.jparams[frozenset(conames)]["correlation"]                 # lu.jl:154-163
+            pre[conames] = dict(handles=co, rho=rho)
+        return pre
+
+    def solve(self, problem: SimulationProblem, gather: bool = True):
+        pre = self.preprocess(problem)
+        seed = _seed_from(self.globals.get("rng"))
+        rank, ws = parallel.world()
+        lo, hi = parallel.shard_range(problem.nreals, rank, ws)
+        reals = {}
+        vindex = {v: i for i, v in enumerate(problem.variables)}
+        for conames, q in pre.items():
+            v1 = conames[0]
+            y1, w1 = q["handles"][v1].realize(seed + vindex[v1], lo, hi - lo)          # lu.jl:183-185
+            out = {v1: y1}
+            if len(conames) == 2:
+                v2 = conames[1]
+                y2, _ = q["handles"][v2].realize(seed + vindex[v2], lo, hi - lo, rho=q["rho"], w1=w1)  # :188-193
+                out[v2] = y2
+            for v, y in out.items():
+                q["handles"][v].close()
+                if gather and ws > 1:
+                    y = parallel.all_gather_concat(y, problem.nreals)
+                reals[v] = [y[r] for r in range(y.shape[0])]
+        return Ensemble(problem.domain, {v: reals[v] for v in problem.variables})
+
+
+def solve(problem, solver, **kw):
+    """solve(problem, solver) -- the GeoStatsBase entry point extended at GeoStatsSolvers.jl:28."""
+    return solver.solve(problem, **kw)

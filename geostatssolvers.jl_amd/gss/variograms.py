@@ -1,0 +1,73 @@
+"""Variogram model constructors with the reference's keyword surface
+(`GaussianVariogram(range=35., nugget=0.)`, `SphericalVariogram(range=10.)`,
+`GaussianVariogram(MetricBall((20., 5.)))` -- /root/reference/test/estimation/krig.jl:10,
+test/simulation/lu.jl:11,59-60, test/simulation/fft.jl:11).  They only carry parameters;
+evaluation happens on the device (csrc/gss_internal.h cov_from_d2)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+
+@dataclass(frozen=True)
+class MetricBall:
+    radii: Tuple[float, ...]
+
+    def __init__(self, radii):
+        if not isinstance(radii, (tuple, list)):
+            radii = (radii,)
+        object.__setattr__(self, "radii", tuple(float(r) for r in radii))
+
+    @property
+    def isotropic(self):
+        return len(self.radii) == 1
+
+
+@dataclass(frozen=True)
+class VariogramModel:
+    kind: str
+    sill: float = 1.0
+    nugget: float = 0.0
+    range: float = 1.0
+    nu: float = 1.0
+    radii: Optional[Tuple[float, ...]] = None
+
+    def isstationary(self):
+        return True
+
+
+def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=None):
+    radii = None
+    if ball is not None:
+        if not isinstance(ball, MetricBall):
+            raise TypeError("positional argument must be a MetricBall")
+        if ball.isotropic:
+            range = ball.radii[0]
+        else:
+            radii, range = ball.radii, 1.0
+    o = order if order is not None else (nu if nu is not None else 1.0)
+    return VariogramModel(kind, float(sill), float(nugget), float(range), float(o), radii)
+
+
+def GaussianVariogram(ball=None, **kw):
+    return _make("gaussian", ball, **kw)
+
+
+def ExponentialVariogram(ball=None, **kw):
+    return _make("exponential", ball, **kw)
+
+
+def SphericalVariogram(ball=None, **kw):
+    return _make("spherical", ball, **kw)
+
+
+def MaternVariogram(ball=None, **kw):
+    return _make("matern", ball, **kw)
+
+
+def CubicVariogram(ball=None, **kw):
+    return _make("cubic", ball, **kw)
+
+
+def PentasphericalVariogram(ball=None, **kw):
+    return _make("pentaspherical", ball, **kw)

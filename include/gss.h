@@ -1,0 +1,213 @@
+/*
+ * gss.h -- C-ABI of libgss_hip.so: MI355X (gfx950) kernels for the kriging-estimation and
+ * Gaussian-simulation hot path of juliohm/GeoStatsSolvers.jl (KrigingSolver, FFTGS, LUGS).
+ *
+ * This is the drop-in boundary.  The reference is
+ * pure Julia and has no FFI of its own; each entry point below replaces the arithmetic that the
+ * cited reference lines delegate to their Julia dependencies, and is what a `ccall` from the
+ * reference's `solve` / `preprocess` / `solvesingle` methods binds.
+ *
+ * Conventions
+ *   - every function returns an int32 status (GSS_OK == 0); no C++ exception crosses the ABI;
+ *     gss_last_error() returns the message of the last failure on the calling thread.
+ *   - coordinates are "point-major": point i occupies d consecutive doubles.  This is the memory
+ *     layout of a Julia d x n column-major matrix (PointSet coordinates), so Julia passes them
+ *     without a copy.
+ *   - all floating point is FP64, indices are int32/int64 as declared, 0-based on this side.
+ *   - `mem` says where the LARGE arrays of the call live: GSS_MEM_HOST (library copies through
+ *     PCIe) or GSS_MEM_DEVICE (pointers are HBM addresses on the current device; nothing is
+ *     copied and the call is asynchronous on `stream`).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - handles are opaque, owned by the library, not thread-safe; the caller owns every buffer it
+ *     passes and the library never returns memory it allocated.
+ */
+#ifndef GSS_H
+#define GSS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSS_VERSION 100
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+  GSS_OK = 0,
+  GSS_ERR_INVALID = 1,      /* bad argument (maps to ArgumentError / AssertionError in the shim) */
+  GSS_ERR_HIP = 2,          /* HIP / rocFFT runtime failure                                      */
+  GSS_ERR_NOT_POSDEF = 3,   /* covariance factorisation hit a non-positive pivot                  */
+  GSS_ERR_UNSUPPORTED = 4,  /* feature outside the hot-path scope           */
+  GSS_ERR_NO_DEVICE = 5,
+  GSS_ERR_ALLOC = 6
+};
+
+enum { GSS_MEM_HOST = 0, GSS_MEM_DEVICE = 1 };
+
+/* ---- variogram model: replaces Variography.jl objects at fft.jl:91,98; lu.jl:110,124,131,132;
+ *      krig.jl:65 (solver parameter `variogram`) -------------------------------------------- */
+enum {
+  GSS_VG_GAUSSIAN = 0,
+  GSS_VG_EXPONENTIAL = 1,
+  GSS_VG_SPHERICAL = 2,
+  GSS_VG_MATERN = 3,         /* nu in {0.5, 1.5, 2.5} on device */
+  GSS_VG_CUBIC = 4,
+  GSS_VG_PENTASPHERICAL = 5
+};
+
+typedef struct gss_variogram {
+  int32_t kind;        /* GSS_VG_*                                                   */
+  int32_t dim;         /* embedding dimension d, 1..3                                */
+  double sill;
+  double nugget;
+  double range;        /* isotropic range; ignored (==1) when aniso != 0             */
+  double nu;           /* Matern order                                               */
+  int32_t aniso;       /* 1: Mahalanobis distance with inv_radii (MetricBall((a,b))) */
+  int32_t reserved;
+  double inv_radii[3]; /* 1 / ball radii                                             */
+} gss_variogram_t;
+
+/* ---- kriging variant: replaces ui.jl:40-50 (kriging_ui) model choice ---------------------- */
+enum { GSS_KRIG_SIMPLE = 0, GSS_KRIG_ORDINARY = 1, GSS_KRIG_UNIVERSAL = 2, GSS_KRIG_EXTDRIFT = 3 };
+
+/* per-point status byte written by the predict calls (krig.jl:213-214 `missing, missing`) */
+enum { GSS_PT_OK = 0, GSS_PT_MISSING = 1, GSS_PT_SINGULAR = 2 };
+
+typedef struct gss_krig gss_krig_t;
+typedef struct gss_fftgs gss_fftgs_t;
+typedef struct gss_lugs gss_lugs_t;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int32_t gss_version(void);
+int32_t gss_device_count(int32_t* count);
+int32_t gss_init(int32_t device);          /* bind the calling process to `device` (one process per GPU) */
+int32_t gss_shutdown(void);
+int32_t gss_last_error(char* buf, int32_t len);
+int32_t gss_synchronize(void* stream);
+
+/* ---- kernel timing (bench.py's roofline leg): when enabled every launch of a named hot kernel is
+ *      bracketed by HIP events on the stream it is launched on; gss_profile_read synchronises
+ *      those events and returns the summed duration and the launch count for `name`
+ *      ("krig_rhs", "krig_quadform", "fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", ...). */
+int32_t gss_profile_enable(int32_t on);
+int32_t gss_profile_reset(void);
+int32_t gss_profile_read(const char* name, double* total_ms, int64_t* launches);
+
+/* ---- pairwise covariance: replaces `sill(g) .- Variography.pairwise(g, A, B)` at
+ *      fft.jl:98, lu.jl:124,131,132.  out is na x nb, row-major with leading dimension ldo.
+ *      b == NULL computes the symmetric na x na matrix. ---------------------------------------- */
+int32_t gss_cov_pairwise(const gss_variogram_t* vg, const double* a, int64_t na, const double* b,
+                         int64_t nb, double* out, int64_t ldo, int32_t mem, void* stream);
+
+/* ---- neighbour search: replaces `search!(neighbors, center, searcher)` krig.jl:210 and the
+ *      KNearestSearch / KBallSearch construction ui.jl:27,30.  Exact; neighbours ordered by
+ *      ascending (FP64 squared distance accumulated in dimension order without FMA, index).
+ *      radius < 0: plain k-NN.  radius >= 0: only neighbours with d^2 <= radius^2 (isotropic) or
+ *      Mahalanobis d^2 <= 1 when inv_radii != NULL.  idx is m x k (int32, -1 padded). ---------- */
+int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double* centers, int64_t m,
+                       int32_t k, double radius, const double* inv_radii, int32_t* idx, int32_t* count,
+                       int32_t mem, void* stream);
+
+/* ---- KrigingSolver ------------------------------------------------------------------------
+ * gss_krig_create replaces preprocess (krig.jl:76-128) + GeoStatsModels.fit of exactsolve
+ * (krig.jl:176): it uploads the non-missing samples and, unless GSS_KRIG_NO_FACTOR is set,
+ * factorises the (n+nc)^2 kriging system on the device.
+ *   xdata n x d point-major, z n values, drift_data n x ndrift (EXTDRIFT only, row per point).
+ */
+enum { GSS_KRIG_NO_FACTOR = 1 /* moving-neighbourhood use only, or factor arrives by broadcast */ };
+
+int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t variant, double sk_mean,
+                        int32_t degree, int32_t ndrift, const double* xdata, const double* z,
+                        const double* drift_data, int64_t n, int32_t flags, void* stream);
+int32_t gss_krig_destroy(gss_krig_t* h);
+
+/* number of constraints nc and system size n+nc */
+int32_t gss_krig_info(const gss_krig_t* h, int64_t* n, int32_t* nc);
+
+/* device address + size of the factor state (inverse block factor W' and dual weights) so that
+ * the host can broadcast it to peer GPUs over RCCL; after a broadcast into
+ * a handle created with GSS_KRIG_NO_FACTOR call gss_krig_adopt_factor. */
+int32_t gss_krig_factor_buffer(gss_krig_t* h, void** dev_ptr, int64_t* bytes);
+int32_t gss_krig_adopt_factor(gss_krig_t* h);
+
+/* global neighbourhood: replaces the predictprob loop krig.jl:180-183.
+ * xdom m x d point-major, drift_dom m x ndrift; outputs mean[m], var[m], status[m]. */
+int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
+                                double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
+
+/* moving neighbourhood: replaces approxsolve krig.jl:188-234 (search + fit + predictprob per point).
+ * k = maxneighbors (already clamped by searcher_ui), radius/inv_radii as gss_knn_search.
+ * idx_out (m x k int32) and count_out (m) may be NULL. */
+int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
+                             int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
+                             double* mean, double* var, uint8_t* status, int32_t* idx_out,
+                             int32_t* count_out, int32_t mem, void* stream);
+
+/* re-use a factorised handle with new data values (same locations): the conditional-FFTGS
+ * pattern fft.jl:176-188 where one kriging system serves every realisation.
+ * zbatch is nbatch x n; mean_out nbatch x m (row per batch).  No variances. */
+int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t m, const double* zbatch,
+                                      int64_t nbatch, double* mean_out, int32_t mem, void* stream);
+
+/* ---- FFTGS ------------------------------------------------------------------------------
+ * gss_fftgs_create replaces preprocess fft.jl:62-103 (unconditional part): covariance to the
+ * centre cell, F = sqrt(|fft(fftshift(C))|), F[1] = 0.  dims[0] is the fastest axis (Julia
+ * column-major), ndim in 1..3.
+ */
+int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t ndim, const int64_t* dims,
+                         const double* spacing, double mean, int32_t flags, void* stream);
+int32_t gss_fftgs_destroy(gss_fftgs_t* h);
+/* full-size spectral amplitude F (prod(dims) doubles, element order) for parity checks */
+int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* stream);
+/* device address of the half-spectrum state for RCCL broadcast */
+int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes);
+/* replaces solvesingle fft.jl:145-173 for realisations first_real .. first_real+nreals-1.
+ * noise == NULL: Philox4x32-10 uniform noise keyed by (seed, realisation) generated on device;
+ * else noise is nreals x N uniform values supplied by the caller (parity-test mode).
+ * inds (ninds int64, 0-based parent indices, may be NULL) gathers a grid view (fft.jl:152,173).
+ * out is nreals x (ninds or N). */
+int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals,
+                          const double* noise, const int64_t* inds, int64_t ninds, double* out,
+                          int32_t mem, void* stream);
+
+/* ---- LUGS -------------------------------------------------------------------------------
+ * gss_lugs_create replaces preprocess lu.jl:105-147 for one variable: covariance blocks,
+ * L11, B12 = L11 \ C12, d2, L22 = chol(C22 - B12'B12).  centroids N x d point-major;
+ * dlocs nd sorted 0-based data locations with values z1 (after initbuff, lu.jl:86,113-114).
+ */
+int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
+                        const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
+                        void* stream);
+int32_t gss_lugs_destroy(gss_lugs_t* h);
+int32_t gss_lugs_info(const gss_lugs_t* h, int64_t* ns, int64_t* nd);
+/* copy out L22 (ns x ns, column-major, lower) and d2 (ns) for parity checks; either may be NULL */
+int32_t gss_lugs_factor(gss_lugs_t* h, double* l22, double* d2, int32_t mem, void* stream);
+int32_t gss_lugs_state_buffer(gss_lugs_t* h, void** dev_ptr, int64_t* bytes);
+int32_t gss_lugs_adopt_state(gss_lugs_t* h);
+/* replaces solvesingle / lusim lu.jl:171-224: y2 = d2 + L22 * w  (w = rho*w1 + sqrt(1-rho^2)*w2
+ * when w1 != NULL), scatter to dlocs/slocs, add mean when unconditional.
+ * noise == NULL: w2 = Philox normals keyed by (seed, realisation); else nreals x ns supplied.
+ * out nreals x N; w_out (nreals x ns, may be NULL) returns the w2 used (for co-simulation). */
+int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t nreals,
+                         const double* noise, double rho, const double* w1, double* out, double* w_out,
+                         int32_t mem, void* stream);
+
+/* ---- noise (test support): the Philox streams used above, n values for one realisation ----- */
+int32_t gss_philox_uniform(uint64_t seed, int64_t real, int64_t n, double* out, int32_t mem, void* stream);
+int32_t gss_philox_normal(uint64_t seed, int64_t real, int64_t n, double* out, int32_t mem, void* stream);
+
+/* ---- dense FP64 building blocks on the MFMA path (exported for unit tests) ------------------
+ * column-major, lower triangle; potrf overwrites the lower triangle of a with L; trtri writes
+ * inv(L) (lower) to w.  Device pointers only. */
+int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream);
+int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_t ldw, void* stream);
+/* D = alpha * A * B + beta * D with arbitrary element strides (A is M x K, B is K x N) */
+int32_t gss_dev_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i,
+                     int64_t sa_k, const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D,
+                     int64_t sd_i, int64_t sd_j, int32_t lower_only, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSS_H */

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected with `-m gpu`; if someone runs the whole suite on a CPU-only box they
+    # are skipped rather than silently "passing" on some fallback (there is none).
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device: the gfx950 path has no CPU fallback")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,58 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/gss.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from gss import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gss.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint32_t\s+(gss_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gss.h but not exported"
+
+
+def test_binding_covers_header():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_buffer():
+    lib = _lib.load()
+    assert lib.gss_version() == 100
+    buf = ctypes.create_string_buffer(64)
+    assert lib.gss_last_error(buf, 64) == 0
+
+
+def test_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    lib = _lib.load()
+    assert lib.gss_init(0) == _lib.ERR_NO_DEVICE
+    assert "no CPU fallback" in _lib.last_error()
+
+
+def test_invalid_arguments_do_not_need_a_device():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    v = _lib.make_variogram("gaussian", 2)
+    # krig.jl:100-102: no non-missing sample
+    code = lib.gss_krig_create(ctypes.byref(h), ctypes.byref(v), 1, 0.0, 0, 0, ctypes.c_void_p(8), ctypes.c_void_p(8),
+                               None, 0, 0, None)
+    assert code == _lib.ERR_INVALID and "missing" in _lib.last_error()
+    bad = _lib.make_variogram("matern", 2, nu=0.7)
+    code = lib.gss_krig_create(ctypes.byref(h), ctypes.byref(bad), 1, 0.0, 0, 0, ctypes.c_void_p(8),
+                               ctypes.c_void_p(8), None, 4, 0, None)
+    assert code == _lib.ERR_UNSUPPORTED

@@ -1,0 +1,102 @@
+"""FP64 MFMA toolkit vs numpy/LAPACK (FP64).  Tolerances: GEMM 1e-12 relative to |A||B|,
+Cholesky / inverse 1e-10 relative on well-conditioned SPD matrices."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def _gemm(M, N, K, A, sa, B, sb, D, sd, alpha=1.0, beta=0.0, lower=0):
+    from gss import _lib
+    l = _lib.lib()
+    _lib.check(l.gss_dev_gemm(M, N, K, alpha, _lib.ptr(A), sa[0], sa[1], _lib.ptr(B), sb[0], sb[1], beta,
+                              _lib.ptr(D), sd[0], sd[1], lower, _lib.current_stream()))
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (128, 128, 16), (130, 67, 33), (257, 300, 129), (5, 1000, 1000)])
+def test_gemm_all_layouts_asymmetric(M, N, K):
+    import torch
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.normal(size=(M, K))
+    B = rng.normal(size=(K, N))
+    ref = A @ B
+    scale = np.abs(A) @ np.abs(B)
+    for a_cm in (False, True):
+        for b_cm in (False, True):
+            for d_cm in (False, True):
+                dA = _t(A.T if a_cm else A)          # column-major image when a_cm
+                dB = _t(B.T if b_cm else B)
+                dD = torch.zeros((N, M) if d_cm else (M, N), dtype=torch.float64, device="cuda")
+                sa = (1, M) if a_cm else (K, 1)
+                sb = (1, K) if b_cm else (N, 1)
+                sd = (1, M) if d_cm else (N, 1)
+                _gemm(M, N, K, dA, sa, dB, sb, dD, sd)
+                got = dD.cpu().numpy()
+                got = got.T if d_cm else got
+                assert np.max(np.abs(got - ref) / scale) < 1e-14 * K
+
+
+def test_gemm_identity_catches_transposed_output():
+    import torch
+    n = 64
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)     # asymmetric
+    dI, dB = _t(np.eye(n)), _t(B)
+    dD = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    _gemm(n, n, n, dI, (n, 1), dB, (n, 1), dD, (n, 1))
+    assert np.array_equal(dD.cpu().numpy(), B)
+
+
+def test_gemm_alpha_beta_and_lower_only():
+    import torch
+    rng = np.random.default_rng(5)
+    n, k = 300, 70
+    A = rng.normal(size=(n, k))
+    C0 = rng.normal(size=(n, n))
+    dA, dC = _t(A.T), _t(C0.T.copy())                          # column-major
+    _gemm(n, n, k, dA, (1, n), dA, (n, 1), dC, (1, n), alpha=-1.0, beta=1.0, lower=1)
+    got = dC.cpu().numpy().T
+    ref = C0 - A @ A.T
+    il = np.tril_indices(n)
+    assert np.allclose(got[il], ref[il], atol=1e-11)
+    # tiles strictly above the diagonal blocks are untouched
+    assert np.array_equal(got[:128, 128:], C0[:128, 128:])
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 200, 1000, 1537])
+def test_potrf_and_trtri(n):
+    import torch
+    from gss import _lib
+    l = _lib.lib()
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n + 8))
+    A = G @ G.T / n + np.eye(n)
+    lda = n + 3
+    buf = np.zeros((n, lda))
+    buf[:, :n] = A                                            # row r of buf = column r (A symmetric)
+    dA = _t(buf)
+    _lib.check(l.gss_dev_potrf(_lib.ptr(dA), n, lda, _lib.current_stream()))
+    L = np.tril(dA.cpu().numpy()[:, :n].T)
+    Lref = np.linalg.cholesky(A)
+    assert np.max(np.abs(L - Lref)) < 1e-10 * np.max(np.abs(Lref))
+    dW = torch.full((n, lda), 7.0, dtype=torch.float64, device="cuda")
+    _lib.check(l.gss_dev_trtri(_lib.ptr(dA), n, lda, _lib.ptr(dW), lda, _lib.current_stream()))
+    W = dW.cpu().numpy()[:, :n].T
+    assert np.array_equal(np.triu(W, 1), np.zeros((n, n)))
+    assert np.max(np.abs(W @ Lref - np.eye(n))) < 1e-9
+
+
+def test_potrf_reports_indefinite():
+    from gss import _lib
+    l = _lib.lib()
+    A = np.eye(100)
+    A[70, 70] = -1.0
+    dA = _t(A)
+    code = l.gss_dev_potrf(_lib.ptr(dA), 100, 100, _lib.current_stream())
+    assert code == _lib.ERR_NOT_POSDEF and "pivot at row 70" in _lib.last_error()

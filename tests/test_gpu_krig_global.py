@@ -1,0 +1,148 @@
+"""Global-neighbourhood kriging on the device vs the oracle.
+
+Tolerances: well-conditioned models (Matern / exponential / spherical) 1e-9
+relative on the mean and 1e-9 absolute (sill = 1) on the variance; Gaussian-variogram systems
+1e-6 absolute."""
+import numpy as np
+import pytest
+
+from oracle import fftgs as offt, kriging as K
+from oracle.variogram import Variogram, cov_pairwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _vg(kind, **kw):
+    import gss
+    ctor = dict(gaussian=gss.GaussianVariogram, exponential=gss.ExponentialVariogram,
+                spherical=gss.SphericalVariogram, matern=gss.MaternVariogram, cubic=gss.CubicVariogram,
+                pentaspherical=gss.PentasphericalVariogram)[kind]
+    radii = kw.pop("radii", None)
+    if radii is not None:
+        return ctor(gss.MetricBall(tuple(radii)), **kw)
+    if "nu" in kw:
+        kw["order"] = kw.pop("nu")
+    return ctor(**kw)
+
+
+CASES = [("gaussian", dict(range=12.0, nugget=0.05)), ("exponential", dict(range=20.0, sill=2.0)),
+         ("spherical", dict(range=15.0, nugget=0.1)), ("matern", dict(range=30.0, nu=0.5)),
+         ("matern", dict(range=30.0, nu=1.5)), ("matern", dict(range=30.0, nu=2.5, sill=3.0, nugget=0.5)),
+         ("cubic", dict(range=25.0)), ("pentaspherical", dict(range=25.0)),
+         ("gaussian", dict(radii=(20.0, 5.0, 10.0), nugget=0.01))]
+
+
+@pytest.mark.parametrize("kind,kw", CASES)
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_cov_pairwise_matches_oracle(kind, kw, dim):
+    from gss.engine import HipEngine
+    kw = dict(kw)
+    if "radii" in kw:
+        kw["radii"] = kw["radii"][:dim]
+        if dim == 1:
+            pytest.skip("isotropic in 1-D")
+    rng = np.random.default_rng(3)
+    a = rng.uniform(0, 50, (77, dim))
+    b = rng.uniform(0, 50, (301, dim))
+    b[:5] = a[:5]                                  # exact zero lags
+    got = HipEngine.cov_pairwise(_vg(kind, **kw), a, b)
+    ref = cov_pairwise(Variogram(kind, **kw), a, b)
+    assert np.max(np.abs(got - ref)) < 5e-15 * max(1.0, kw.get("sill", 1.0))
+    sym = HipEngine.cov_pairwise(_vg(kind, **kw), a)
+    assert np.array_equal(sym, sym.T)
+
+
+def _run(variant, kind, kw, n, m, dim, seed, **okw):
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 100, (n, dim))
+    z = rng.normal(size=n)
+    x0 = rng.uniform(0, 100, (m, dim))
+    x0[:3] = x[:3]
+    h = KrigHandle(_vg(kind, **dict(kw)), variant, x, z, mean=okw.get("mean"), degree=okw.get("degree"),
+                   drift_data=okw.get("drift_data"))
+    mu, var, st = h.predict_global(x0, okw.get("drift_dom"))
+    h.close()
+    rmu, rvar = K.exactsolve(variant, Variogram(kind, **kw), x, z, x0, mean=okw.get("mean") or 0.0,
+                             degree=okw.get("degree"), drift_data=okw.get("drift_data"),
+                             drift_dom=okw.get("drift_dom"))
+    assert not st.any()
+    return mu, var, rmu, rvar, z
+
+
+@pytest.mark.parametrize("variant,okw", [(K.SK, dict(mean=0.7)), (K.OK, {}), (K.UK, dict(degree=1)),
+                                         (K.UK, dict(degree=2))])
+@pytest.mark.parametrize("n,m,dim", [(3, 10, 2), (50, 1000, 1), (200, 777, 2), (1000, 3000, 3), (1029, 300, 3)])
+def test_global_kriging_matches_oracle(variant, okw, n, m, dim):
+    if variant == K.UK and n < 12:
+        pytest.skip("fewer samples than drift terms")
+    mu, var, rmu, rvar, z = _run(variant, "matern", dict(range=30.0, nu=1.5), n, m, dim, seed=n + dim, **okw)
+    assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu)))
+    assert np.max(np.abs(var - rvar)) < 1e-9
+    assert np.allclose(mu[:3], z[:3], atol=1e-9) and np.all(var[:3] < 1e-9)     # exact at data
+
+
+def test_external_drift_matches_oracle():
+    rng = np.random.default_rng(8)
+    n, m = 120, 500
+    dd = rng.normal(size=(n, 2))
+    d0 = rng.normal(size=(m, 2))
+    mu, var, rmu, rvar, _ = _run(K.EDK, "exponential", dict(range=25.0), n, m, 2, 5, drift_data=dd, drift_dom=d0)
+    # x0[:3] == x[:3] but drift values differ there, so no exactness check
+    assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var - rvar)) < 1e-9
+
+
+def test_gaussian_variogram_config1():
+    """BASELINE config 1: OK, 100 2-D data -> 64x64 grid, Gaussian range 20 nugget 1e-6."""
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(1)
+    x = rng.uniform(0, 64, (100, 2))
+    z = rng.normal(size=100)
+    g = offt.grid_centroids((64, 64))
+    kw = dict(range=20.0, sill=1.0, nugget=1e-6)
+    h = KrigHandle(_vg("gaussian", **kw), K.OK, x, z)
+    mu, var, st = h.predict_global(g)
+    rmu, rvar = K.exactsolve(K.OK, Variogram("gaussian", **kw), x, z, g)
+    assert np.max(np.abs(mu - rmu)) < 1e-6 and np.max(np.abs(var - rvar)) < 1e-6
+
+
+def test_device_resident_inputs_match_host_path_and_chunking(monkeypatch):
+    import torch
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 100, (300, 3))
+    z = rng.normal(size=300)
+    x0 = rng.uniform(0, 100, (5000, 3))
+    vg = _vg("matern", range=30.0, nu=1.5)
+    h = KrigHandle(vg, K.OK, x, z)
+    mu, var, _ = h.predict_global(x0)
+    tmu, tvar, tst = h.predict_global(torch.as_tensor(x0, device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(tmu.cpu().numpy(), mu) and np.array_equal(tvar.cpu().numpy(), var)
+    h.close()
+    monkeypatch.setenv("GSS_KRIG_WS_MB", "1")                 # forces many chunks
+    h2 = KrigHandle(vg, K.OK, x, z)
+    mu2, var2, _ = h2.predict_global(x0)
+    assert np.array_equal(mu2, mu) and np.array_equal(var2, var)
+
+
+def test_not_positive_definite_is_reported():
+    from gss import _lib
+    from gss.engine import KrigHandle
+    x = np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 1.0]])      # duplicate sample, no nugget
+    with pytest.raises(_lib.GSSError) as e:
+        KrigHandle(_vg("gaussian", range=5.0), K.OK, x, np.zeros(3))
+    assert e.value.code == _lib.ERR_NOT_POSDEF
+
+
+def test_reference_2d_problem_through_solve_api():
+    """test/estimation/krig.jl:22-37 through the solver front-end."""
+    import gss
+    data = gss.georef({"z": [1.0, 0.0, 1.0]}, [(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)])
+    grid = gss.CartesianGrid((100, 100), (0.5, 0.5), (1.0, 1.0))
+    problem = gss.EstimationProblem(data, grid, "z")
+    solver = gss.KrigingSolver(("z", dict(variogram=gss.GaussianVariogram(range=35.0, nugget=0.0))))
+    sol = gss.solve(problem, solver)
+    Z = gss.asarray(sol, "z")
+    assert abs(Z[24, 24] - 1.0) < 1e-3 and abs(Z[49, 74] - 0.0) < 1e-3 and abs(Z[74, 49] - 1.0) < 1e-3
+    assert sol["z_variance"].shape == (10000,) and np.all(sol["z_variance"] >= 0)
