@@ -1,0 +1,332 @@
+// FFTGS: FFT-based unconditional Gaussian simulation on Cartesian grids (Gutjahr 1997).
+// Replaces preprocess (/root/reference/src/simulation/fft.jl:62-103) and solvesingle
+// (fft.jl:145-173).  rocFFT does the transforms; everything else is fused into three kernels.
+//
+// preprocess, fft.jl:96-103:
+//     C  = sill - gamma(centre cell, every cell)             fftgs_cov_kernel          (K6)
+//     F  = sqrt(|fft(fftshift(C))|), F[1] = 0                rocFFT R2C + fftgs_amp_kernel
+//   |fft| is invariant to the circular placement of C, so the fftshift is not materialised, and C is
+//   real, so the real-to-complex transform gives the same |.| on the Hermitian half.
+// solvesingle, fft.jl:163-170:
+//     P  = F .* exp(im * angle(fft(rand)))                   noise kernel + R2C + fftgs_phase_kernel (K7)
+//     Z  = real(ifft(P)); Z *= sqrt(sill / var(Z, mean=0)); Z += mean      rocFFT C2R
+//   P is Hermitian, hence by Parseval sum(Z^2) = sum(F^2) / N for EVERY realisation: the rescale is
+//   the constant s = sqrt(sill N (N-1) / sum F^2), folded with the 1/N of the unnormalised inverse
+//   into the stored half-spectrum Fh = F s / N; the mean enters as the DC coefficient.
+// HBM traffic per realisation (FP64, N cells): noise 8N (w) + R2C + phase 8N+4N (r) 8N (w) + C2R;
+// the algorithmic floor is 32 N bytes.
+#include "gss_internal.h"
+#include "philox.h"
+
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <mutex>
+
+namespace gss {
+
+#define GSS_FFT(call)                                                              \
+  do {                                                                             \
+    rocfft_status st__ = (call);                                                   \
+    if (st__ != rocfft_status_success) {                                           \
+      ::gss::set_error("%s:%d: %s failed: rocfft status %d", __FILE__, __LINE__, #call, (int)st__); \
+      return GSS_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+struct GridSpec {
+  int64_t n1, n2, n3;  // n1 fastest
+  int64_t nh;          // n1 / 2 + 1
+  int64_t c1, c2, c3;  // 0-based centre cell (dims div 2, 1-based, fft.jl:69)
+  double s1, s2, s3;   // spacing
+};
+
+// C[e] = cov(|lag|) with lag = (cell - centre) * spacing, written as a contiguous real array
+__global__ __launch_bounds__(256) void fftgs_cov_kernel(VgDev vg, GridSpec g, double* __restrict__ C) {
+  const int64_t N = g.n1 * g.n2 * g.n3;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (int64_t)gridDim.x * 256) {
+    const int64_t i1 = e % g.n1, i2 = (e / g.n1) % g.n2, i3 = e / (g.n1 * g.n2);
+    double a[3] = {(double)(i1 - g.c1) * g.s1, (double)(i2 - g.c2) * g.s2, (double)(i3 - g.c3) * g.s3};
+    const double zero[3] = {0.0, 0.0, 0.0};
+    const double d2 = sqdist_nofma<3>(a, zero, vg.ir, vg.aniso != 0);
+    C[e] = cov_from_d2(vg, d2);
+  }
+}
+
+constexpr int RED_BLOCKS = 1024;
+
+// Fh[idx] = sqrt(|X[idx]|) (DC = 0); partial[b] = sum over this block's elements of w * F^2 where w
+// counts how many full-spectrum entries the half-spectrum entry stands for
+__global__ __launch_bounds__(256) void fftgs_amp_kernel(GridSpec g, const double2* __restrict__ X,
+                                                        double* __restrict__ Fh, double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int64_t NH = g.nh * g.n2 * g.n3;
+  double acc = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
+    const int64_t k1 = idx % g.nh;
+    const double2 x = X[idx];
+    double f = sqrt(sqrt(x.x * x.x + x.y * x.y));
+    if (idx == 0) f = 0.0;  // fft.jl:103
+    Fh[idx] = f;
+    const bool self = (k1 == 0) || (2 * k1 == g.n1);
+    acc += (self ? 1.0 : 2.0) * f * f;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// scal[0] = sum F^2, scal[1] = s / N with s = sqrt(sill N (N-1) / sum F^2)
+__global__ void fftgs_scale_kernel(const double* __restrict__ partial, int nparts, double sill, double N,
+                                   double* __restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += partial[i];
+    scal[0] = s;
+    scal[1] = sqrt(sill * N * (N - 1.0) / s) / N;
+  }
+}
+
+__global__ __launch_bounds__(256) void fftgs_apply_scale_kernel(double* __restrict__ Fh, int64_t NH,
+                                                                const double* __restrict__ scal) {
+  const double f = scal[1];
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256)
+    Fh[idx] *= f;
+}
+
+// K7: X <- Fh * X / |X| (phase of the noise spectrum, amplitude of the covariance); DC <- mean
+__global__ __launch_bounds__(256) void fftgs_phase_kernel(double2* __restrict__ X, const double* __restrict__ Fh,
+                                                          int64_t NH, double mean) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
+    const double2 x = X[idx];
+    const double f = Fh[idx];
+    const double mag2 = x.x * x.x + x.y * x.y;
+    double2 p;
+    if (mag2 > 0.0) {
+      const double inv = f / sqrt(mag2);
+      p.x = x.x * inv;
+      p.y = x.y * inv;
+    } else {  // angle(0) = 0
+      p.x = f;
+      p.y = 0.0;
+    }
+    if (idx == 0) {
+      p.x = mean;
+      p.y = 0.0;
+    }
+    X[idx] = p;
+  }
+}
+
+// full-size F from the scaled half-spectrum (parity checks): F(k) = Fh(hermitian partner) / scal[1]
+__global__ __launch_bounds__(256) void fftgs_expand_kernel(GridSpec g, const double* __restrict__ Fh,
+                                                           const double* __restrict__ scal,
+                                                           double* __restrict__ F) {
+  const int64_t N = g.n1 * g.n2 * g.n3;
+  const double inv = 1.0 / scal[1];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (int64_t)gridDim.x * 256) {
+    int64_t k1 = e % g.n1, k2 = (e / g.n1) % g.n2, k3 = e / (g.n1 * g.n2);
+    if (k1 >= g.nh) {
+      k1 = g.n1 - k1;
+      k2 = (g.n2 - k2) % g.n2;
+      k3 = (g.n3 - k3) % g.n3;
+    }
+    F[e] = Fh[k1 + g.nh * (k2 + g.n2 * k3)] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ src, const int64_t* __restrict__ inds,
+                                                     int64_t n, double* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[inds[i]];
+}
+
+static std::once_flag g_rocfft_once;
+
+}  // namespace gss
+
+using namespace gss;
+
+struct gss_fftgs {
+  VgDev vg;
+  GridSpec g;
+  int ndim = 0;
+  int64_t N = 0, NH = 0;
+  double mean = 0.0;
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  DevBuf state;  // Fh (NH doubles) followed by scal[2]
+  DevBuf U, X, work, Z;
+  double* Fh() const { return state.as<double>(); }
+  double* scal() const { return state.as<double>() + NH; }
+  ~gss_fftgs() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+    if (info) rocfft_execution_info_destroy(info);
+  }
+};
+
+static int grid_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 256 * 16 ? (b < 1 ? 1 : b) : 256 * 16);
+}
+
+static int32_t fft_exec(gss_fftgs* h, rocfft_plan plan, void* in, void* out, hipStream_t s) {
+  GSS_FFT(rocfft_execution_info_set_stream(h->info, s));
+  void* ib[1] = {in};
+  void* ob[1] = {out};
+  GSS_FFT(rocfft_execute(plan, ib, ob, h->info));
+  return GSS_OK;
+}
+
+extern "C" {
+
+int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t ndim, const int64_t* dims,
+                         const double* spacing, double mean, int32_t flags, void* stream) {
+  (void)flags;
+  GSS_REQUIRE(out != nullptr, "gss_fftgs_create: out is NULL");
+  *out = nullptr;
+  GSS_REQUIRE(ndim >= 1 && ndim <= 3 && dims != nullptr, "FFTGS needs a 1-D, 2-D or 3-D Cartesian grid");
+  gss_variogram_t v3 = *vg;
+  GSS_REQUIRE(vg->dim == ndim, "variogram dimension %d does not match the grid dimension %d", vg->dim, ndim);
+  v3.dim = 3;  // lags of absent axes are zero
+  for (int k = ndim; k < 3; ++k) v3.inv_radii[k] = 1.0;
+  gss_fftgs* h = new (std::nothrow) gss_fftgs();
+  if (!h) return GSS_ERR_ALLOC;
+  struct Guard {
+    gss_fftgs* h;
+    ~Guard() { delete h; }
+  } guard{h};
+  GSS_TRY(make_vgdev(&v3, &h->vg));
+  int64_t d[3] = {1, 1, 1};
+  double sp[3] = {1.0, 1.0, 1.0};
+  for (int k = 0; k < ndim; ++k) {
+    GSS_REQUIRE(dims[k] >= 2, "every grid axis needs at least two cells");
+    d[k] = dims[k];
+    sp[k] = spacing ? spacing[k] : 1.0;
+  }
+  h->ndim = ndim;
+  h->mean = mean;
+  h->g = GridSpec{d[0], d[1], d[2], d[0] / 2 + 1, d[0] / 2 - 1, d[1] / 2 - 1, d[2] / 2 - 1, sp[0], sp[1], sp[2]};
+  // axes beyond ndim have size 1: their centre offset must be zero
+  if (ndim < 2) h->g.c2 = 0;
+  if (ndim < 3) h->g.c3 = 0;
+  h->N = d[0] * d[1] * d[2];
+  h->NH = h->g.nh * d[1] * d[2];
+  GSS_REQUIRE(h->N >= 2, "FFTGS needs at least two cells");
+  hipStream_t s = to_stream(stream);
+
+  std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+  size_t lengths[3] = {(size_t)d[0], (size_t)d[1], (size_t)d[2]};
+  GSS_FFT(rocfft_plan_create(&h->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                             rocfft_precision_double, (size_t)ndim, lengths, 1, nullptr));
+  GSS_FFT(rocfft_plan_create(&h->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                             rocfft_precision_double, (size_t)ndim, lengths, 1, nullptr));
+  size_t w1 = 0, w2 = 0;
+  GSS_FFT(rocfft_plan_get_work_buffer_size(h->fwd, &w1));
+  GSS_FFT(rocfft_plan_get_work_buffer_size(h->inv, &w2));
+  const size_t wb = w1 > w2 ? w1 : w2;
+  GSS_FFT(rocfft_execution_info_create(&h->info));
+  if (wb > 0) {
+    GSS_TRY(h->work.alloc(wb));
+    GSS_FFT(rocfft_execution_info_set_work_buffer(h->info, h->work.p, wb));
+  }
+  GSS_TRY(h->state.alloc(sizeof(double) * (size_t)(h->NH + 2)));
+  GSS_TRY(h->U.alloc(sizeof(double) * (size_t)h->N));
+  GSS_TRY(h->X.alloc(sizeof(double) * 2 * (size_t)h->NH));
+
+  // spectrum: C -> R2C -> sqrt|.| -> Parseval scale
+  DevBuf partial;
+  GSS_TRY(partial.alloc(sizeof(double) * RED_BLOCKS));
+  hipLaunchKernelGGL(fftgs_cov_kernel, dim3(grid_blocks(h->N)), dim3(256), 0, s, h->vg, h->g, h->U.as<double>());
+  GSS_HIP(hipGetLastError());
+  GSS_TRY(fft_exec(h, h->fwd, h->U.p, h->X.p, s));
+  hipLaunchKernelGGL(fftgs_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->g, h->X.as<double2>(), h->Fh(),
+                     partial.as<double>());
+  hipLaunchKernelGGL(fftgs_scale_kernel, dim3(1), dim3(64), 0, s, partial.as<double>(), RED_BLOCKS, h->vg.sill,
+                     (double)h->N, h->scal());
+  hipLaunchKernelGGL(fftgs_apply_scale_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->Fh(), h->NH,
+                     h->scal());
+  GSS_HIP(hipGetLastError());
+  GSS_HIP(hipStreamSynchronize(s));
+  double hs[2];
+  GSS_HIP(hipMemcpy(hs, h->scal(), sizeof(hs), hipMemcpyDeviceToHost));
+  GSS_REQUIRE(hs[0] > 0.0 && std::isfinite(hs[1]), "degenerate spectrum (sum F^2 = %g)", hs[0]);
+  guard.h = nullptr;
+  *out = h;
+  return GSS_OK;
+}
+
+int32_t gss_fftgs_destroy(gss_fftgs_t* h) {
+  delete h;
+  return GSS_OK;
+}
+
+int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr && f_out != nullptr, "gss_fftgs_spectrum: NULL argument");
+  hipStream_t s = to_stream(stream);
+  Staged so;
+  GSS_TRY(so.out(f_out, sizeof(double) * (size_t)h->N, mem));
+  hipLaunchKernelGGL(fftgs_expand_kernel, dim3(grid_blocks(h->N)), dim3(256), 0, s, h->g, h->Fh(), h->scal(),
+                     so.as<double>());
+  GSS_HIP(hipGetLastError());
+  return so.back(f_out, sizeof(double) * (size_t)h->N, mem, s);
+}
+
+int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
+  *dev_ptr = h->state.p;
+  *bytes = (int64_t)(sizeof(double) * (size_t)(h->NH + 2));
+  return GSS_OK;
+}
+
+int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                          const int64_t* inds, int64_t ninds, double* out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_fftgs_realize: bad arguments");
+  if (nreals == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  const int64_t N = h->N;
+  const int64_t npts = inds ? ninds : N;
+  Staged sn, si, so;
+  GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(nreals * N), mem, s));
+  GSS_TRY(si.in(inds, sizeof(int64_t) * (size_t)(inds ? ninds : 0), mem, s));
+  GSS_TRY(so.out(out, sizeof(double) * (size_t)(nreals * npts), mem));
+  if (inds && h->Z.bytes < sizeof(double) * (size_t)N) GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N));
+
+  for (int64_t r = 0; r < nreals; ++r) {
+    double* u = h->U.as<double>();
+    if (noise) {
+      u = sn.as<double>() + r * N;  // the forward transform does not overwrite its input
+    } else {
+      ProfScope ps("fftgs_noise", s);
+      GSS_TRY(philox_uniform_dev(seed, first_real + r, N, u, N, N, s));
+    }
+    {
+      ProfScope ps("fftgs_fwd", s);
+      GSS_TRY(fft_exec(h, h->fwd, u, h->X.p, s));
+    }
+    {
+      ProfScope ps("fftgs_phase", s);
+      hipLaunchKernelGGL(fftgs_phase_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->X.as<double2>(), h->Fh(),
+                         h->NH, h->mean);
+      GSS_HIP(hipGetLastError());
+    }
+    double* z = inds ? h->Z.as<double>() : so.as<double>() + r * N;
+    {
+      ProfScope ps("fftgs_inv", s);
+      GSS_TRY(fft_exec(h, h->inv, h->X.p, z, s));
+    }
+    if (inds) {
+      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, z, si.as<int64_t>(),
+                         ninds, so.as<double>() + r * ninds);
+      GSS_HIP(hipGetLastError());
+    }
+  }
+  return so.back(out, sizeof(double) * (size_t)(nreals * npts), mem, s);
+}
+
+}  // extern "C"

@@ -11,13 +11,6 @@ int32_t gss_krig_predict_knn(gss_krig_t*, const double*, const double*, int64_t,
 }
 int32_t gss_krig_predict_global_batch(gss_krig_t*, const double*, int64_t, const double*, int64_t, double*, int32_t,
                                       void*) { GSS_STUB("gss_krig_predict_global_batch"); }
-int32_t gss_fftgs_create(gss_fftgs_t**, const gss_variogram_t*, int32_t, const int64_t*, const double*, double,
-                         int32_t, void*) { GSS_STUB("gss_fftgs_create"); }
-int32_t gss_fftgs_destroy(gss_fftgs_t*) { return GSS_OK; }
-int32_t gss_fftgs_spectrum(gss_fftgs_t*, double*, int32_t, void*) { GSS_STUB("gss_fftgs_spectrum"); }
-int32_t gss_fftgs_state_buffer(gss_fftgs_t*, void**, int64_t*) { GSS_STUB("gss_fftgs_state_buffer"); }
-int32_t gss_fftgs_realize(gss_fftgs_t*, uint64_t, int64_t, int64_t, const double*, const int64_t*, int64_t, double*,
-                          int32_t, void*) { GSS_STUB("gss_fftgs_realize"); }
 int32_t gss_lugs_create(gss_lugs_t**, const gss_variogram_t*, const double*, int64_t, const int64_t*, const double*,
                         int64_t, double, int32_t, void*) { GSS_STUB("gss_lugs_create"); }
 int32_t gss_lugs_destroy(gss_lugs_t*) { return GSS_OK; }
