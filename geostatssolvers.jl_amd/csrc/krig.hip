@@ -255,6 +255,14 @@ struct gss_krig {
   double* wd() const { return factor.as<double>() + ldw * N1pad; }
 };
 
+namespace gss {
+int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const signed char* exps, double inv_scale,
+                       double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
+                       const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
+                       const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
+                       int* count_out, hipStream_t s);
+}
+
 static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
   // graded order: total degree 0, 1, ..., `degree`; column order does not change the weights
   e.clear();
@@ -576,6 +584,38 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
   GSS_TRY(sstat.back(status, (size_t)m, mem, s));
+  return GSS_OK;
+}
+
+
+int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m, int32_t k,
+                             int32_t minneighbors, double radius, const double* inv_radii, double* mean, double* var,
+                             uint8_t* status, int32_t* idx_out, int32_t* count_out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_knn: NULL array");
+  GSS_REQUIRE(k >= 1 && k <= h->n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
+              (long long)h->n);
+  GSS_REQUIRE(h->variant != GSS_KRIG_EXTDRIFT || drift_dom != nullptr, "external drift values missing");
+  if (m == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  const int dim = h->dim;
+  Staged sx, sd, smean, svar, sstat, sidx, scnt;
+  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  if (h->variant == GSS_KRIG_EXTDRIFT) GSS_TRY(sd.in(drift_dom, sizeof(double) * m * h->ndrift, mem, s));
+  GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
+  GSS_TRY(svar.out(var, sizeof(double) * m, mem));
+  GSS_TRY(sstat.out(status, (size_t)m, mem));
+  GSS_TRY(sidx.out(idx_out, sizeof(int32_t) * (size_t)(m * k), mem));
+  GSS_TRY(scnt.out(count_out, sizeof(int32_t) * (size_t)m, mem));
+  GSS_TRY(krig_local_dev(h->vg, h->variant, h->nc, dim, &h->ds.e[0][0], h->ds.inv_scale[0], h->sk_mean,
+                         h->xdata.as<double>(), h->z.as<double>(), h->drift_data.as<double>(), h->n,
+                         sx.as<double>(), sd.as<double>(), m, k, minneighbors, radius, inv_radii, smean.as<double>(),
+                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s));
+  GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
+  GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
+  GSS_TRY(sstat.back(status, (size_t)m, mem, s));
+  GSS_TRY(sidx.back(idx_out, sizeof(int32_t) * (size_t)(m * k), mem, s));
+  GSS_TRY(scnt.back(count_out, sizeof(int32_t) * (size_t)m, mem, s));
   return GSS_OK;
 }
 

@@ -1,0 +1,320 @@
+// K5: moving-neighbourhood kriging -- one small kriging system per domain point.
+// Replaces the body of approxsolve's loop (/root/reference/src/estimation/krig.jl:205-228):
+//   :210  search!(neighbors, center, searcher)              -> K4 (knn.hip)
+//   :213  nneigh < minneighbors -> missing                  -> status GSS_PT_MISSING, NaN outputs
+//   :223  fit(estimator, view(pdata, neighbors))            -> k' x k' covariance, Cholesky in LDS
+//   :226  predictprob(krig, var, pdomain[ind])              -> mean / variance by block elimination
+//
+// One wave (a 64-thread workgroup) owns one domain point; lane j owns neighbour j.  With
+// C = L L', Y = L^-1 [c0 | F | z] (forward substitution, all right-hand sides in one sweep):
+//   q = |y_c|^2, a = y_z . y_c, S = Y_F' Y_F, r = Y_F' y_c - f0, t = Y_F' y_z
+//   sigma^2 = max(0, sill - q + r' S^-1 r),   mu = a - t' S^-1 r        (SK: mu = mean + a, nc = 0)
+// which equals solving [C F; F' 0][lambda; nu] = [c0; f0] without forming weights.
+// Universal-kriging monomials are taken about the estimation point (the polynomial space is
+// translation invariant), so f0 = (1, 0, ..., 0).
+#include "gss_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace gss {
+
+int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
+                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s);
+
+constexpr int LMAX_K = 64;
+constexpr int LMAX_NC = 10;
+constexpr int LMAX_RHS = LMAX_NC + 2;
+
+struct LocalSpec {
+  int variant;
+  int nc;
+  int dim;
+  signed char e[LMAX_NC][3];
+  double inv_scale;  // monomial scaling (1 / data extent), conditioning only
+  double sk_mean;
+};
+
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
+                                                        const double* __restrict__ z,
+                                                        const double* __restrict__ drift_data,
+                                                        const double* __restrict__ x0,
+                                                        const double* __restrict__ drift_dom, int64_t m, int k,
+                                                        int minneighbors, const int* __restrict__ idx,
+                                                        const int* __restrict__ count, double* __restrict__ mean_out,
+                                                        double* __restrict__ var_out,
+                                                        uint8_t* __restrict__ status_out) {
+  __shared__ double Lp[LMAX_K * (LMAX_K + 1) / 2];  // packed lower triangle, row major
+  __shared__ double nx[LMAX_K][3];
+  __shared__ double Ssm[LMAX_NC][LMAX_NC + 1];
+  __shared__ double rv[LMAX_NC], tv[LMAX_NC];
+  __shared__ double res[3];
+
+  const int64_t p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int cnt = count[p];
+  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
+  if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
+    if (lane == 0) {
+      mean_out[p] = NaN;
+      var_out[p] = NaN;
+      status_out[p] = GSS_PT_MISSING;
+    }
+    return;
+  }
+  const int nc = sp.nc;
+  const int nrhs = 2 + nc;
+  double c0[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
+
+  // neighbour j on lane j
+  const bool act = lane < cnt;
+  const int nj = act ? idx[p * k + lane] : 0;
+  double xj[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) {
+    xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
+    nx[lane][a] = xj[a];
+  }
+  // right-hand sides per lane: [0] = c0 column, [1] = data values, [2 + c] = drift column c
+  double b[LMAX_RHS];
+#pragma unroll
+  for (int r = 0; r < LMAX_RHS; ++r) b[r] = 0.0;
+  if (act) {
+    b[0] = cov_from_d2(vg, sqdist_nofma<DIM>(xj, c0, vg.ir, vg.aniso != 0));
+    double zz = z[nj];
+    if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
+    b[1] = zz;
+#pragma unroll
+    for (int c = 0; c < LMAX_NC; ++c) {
+      if (c < nc) {
+        double f = 1.0;
+        if (sp.variant == GSS_KRIG_UNIVERSAL) {
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) {
+            const double u = (xj[a] - c0[a]) * sp.inv_scale;
+            for (int q = 0; q < sp.e[c][a]; ++q) f *= u;
+          }
+        } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
+          f = drift_data[(int64_t)nj * nc + c];
+        }
+        b[2 + c] = f;
+      }
+    }
+  }
+  __syncthreads();
+
+  // covariance matrix, packed lower triangle, entries dealt round-robin to the lanes
+  const int nent = tri(cnt);
+  for (int e = lane; e < nent; e += 64) {
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (tri(i + 1) <= e) ++i;
+    while (tri(i) > e) --i;
+    const int c = e - tri(i);
+    double xi[DIM], xc[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      xi[a] = nx[i][a];
+      xc[a] = nx[c][a];
+    }
+    Lp[e] = cov_from_d2(vg, sqdist_nofma<DIM>(xi, xc, vg.ir, vg.aniso != 0));
+  }
+  __syncthreads();
+
+  // Cholesky, left-looking by columns: lane i owns row i
+  bool bad = false;
+  const double* rowi = Lp + tri(lane < cnt ? lane : 0);
+  for (int j = 0; j < cnt; ++j) {
+    double acc = 0.0;
+    const bool mine = lane >= j && lane < cnt;
+    if (mine) {
+      const double* rowj = Lp + tri(j);
+      acc = rowi[j];
+      for (int c = 0; c < j; ++c) acc = fma(-rowi[c], rowj[c], acc);
+    }
+    const double d = __shfl(acc, j);
+    if (!(d > 0.0)) {
+      bad = true;
+      break;
+    }
+    const double sq = sqrt(d);
+    if (mine) Lp[tri(lane) + j] = (lane == j) ? sq : acc / sq;
+    __syncthreads();
+  }
+  if (bad) {
+    if (lane == 0) {
+      mean_out[p] = NaN;
+      var_out[p] = NaN;
+      status_out[p] = GSS_PT_SINGULAR;
+    }
+    return;
+  }
+
+  // forward substitution Y = L^-1 B for all right-hand sides in one column sweep
+  for (int j = 0; j < cnt; ++j) {
+    const double ljj = Lp[tri(j) + j];
+    const double lij = (lane > j && lane < cnt) ? rowi[j] : 0.0;
+    const double inv = 1.0 / ljj;
+#pragma unroll
+    for (int r = 0; r < LMAX_RHS; ++r) {
+      if (r < nrhs) {
+        const double yj = __shfl(b[r], j) * inv;
+        if (lane == j) b[r] = yj;
+        else b[r] = fma(-lij, yj, b[r]);
+      }
+    }
+  }
+
+  const double qf = wave_sum(b[0] * b[0]);
+  const double af = wave_sum(b[1] * b[0]);
+  double rsr = 0.0, tsr = 0.0;
+  if (nc > 0) {
+#pragma unroll
+    for (int c = 0; c < LMAX_NC; ++c) {
+      if (c < nc) {
+        double f0 = 1.0;
+        if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (sp.e[c][0] + sp.e[c][1] + sp.e[c][2]) == 0 ? 1.0 : 0.0;
+        else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + c];
+        const double rc = wave_sum(b[2 + c] * b[0]) - f0;
+        const double tc = wave_sum(b[2 + c] * b[1]);
+        if (lane == 0) {
+          rv[c] = rc;
+          tv[c] = tc;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < LMAX_NC; ++c2) {
+          if (c2 <= c) {
+            const double sv = wave_sum(b[2 + c] * b[2 + c2]);
+            if (lane == 0) Ssm[c][c2] = sv;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      // Cholesky of S and the two triangular solves, serial (nc <= 10)
+      int okS = 1;
+      for (int j = 0; j < nc && okS; ++j) {
+        double d = Ssm[j][j];
+        for (int c = 0; c < j; ++c) d -= Ssm[j][c] * Ssm[j][c];
+        if (!(d > 0.0)) {
+          okS = 0;
+          break;
+        }
+        const double sq = sqrt(d);
+        Ssm[j][j] = sq;
+        for (int i = j + 1; i < nc; ++i) {
+          double v = Ssm[i][j];
+          for (int c = 0; c < j; ++c) v -= Ssm[i][c] * Ssm[j][c];
+          Ssm[i][j] = v / sq;
+        }
+      }
+      double s1 = 0.0, s2 = 0.0;
+      if (okS) {
+        for (int i = 0; i < nc; ++i) {
+          double u = rv[i], v = tv[i];
+          for (int c = 0; c < i; ++c) {
+            u -= Ssm[i][c] * rv[c];
+            v -= Ssm[i][c] * tv[c];
+          }
+          u /= Ssm[i][i];
+          v /= Ssm[i][i];
+          rv[i] = u;
+          tv[i] = v;
+          s1 += u * u;
+          s2 += u * v;
+        }
+      }
+      res[0] = s1;
+      res[1] = s2;
+      res[2] = okS ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    rsr = res[0];
+    tsr = res[1];
+    if (res[2] == 0.0) {
+      if (lane == 0) {
+        mean_out[p] = NaN;
+        var_out[p] = NaN;
+        status_out[p] = GSS_PT_SINGULAR;
+      }
+      return;
+    }
+  }
+  if (lane == 0) {
+    const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
+    const double v = vg.sill - qf + rsr;
+    mean_out[p] = mu;
+    var_out[p] = v > 0.0 ? v : 0.0;
+    status_out[p] = GSS_PT_OK;
+  }
+}
+
+
+// Host driver: chunks the domain so that the neighbour-index scratch stays small, runs K4 then K5.
+int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const signed char* exps, double inv_scale,
+                       double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
+                       const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
+                       const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
+                       int* count_out, hipStream_t s) {
+  GSS_REQUIRE(nc <= LMAX_NC, "moving-neighbourhood kriging supports at most %d drift terms (got %d)", LMAX_NC, nc);
+  GSS_REQUIRE(k >= 1 && k <= LMAX_K, "maxneighbors = %d: the moving-neighbourhood kernels hold at most %d "
+                                     "neighbours (use the global neighbourhood beyond that)", k, LMAX_K);
+  LocalSpec sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.variant = variant;
+  sp.nc = nc;
+  sp.dim = dim;
+  for (int c = 0; c < nc; ++c)
+    for (int a = 0; a < 3; ++a) sp.e[c][a] = exps ? exps[3 * c + a] : 0;
+  sp.inv_scale = inv_scale;
+  sp.sk_mean = sk_mean;
+
+  const int64_t chunk = 1 << 20;
+  DevBuf idx_s, cnt_s, st_s;
+  if (!idx_out) GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
+  if (!count_out) GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
+  if (!status) GSS_TRY(st_s.alloc((size_t)(m < chunk ? m : chunk)));
+  for (int64_t off = 0; off < m; off += chunk) {
+    const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
+    int* idx = idx_out ? idx_out + off * k : idx_s.as<int>();
+    int* cnt = count_out ? count_out + off : cnt_s.as<int>();
+    uint8_t* st = status ? status + off : st_s.as<uint8_t>();
+    {
+      ProfScope ps("knn", s);
+      GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
+    }
+    const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
+    ProfScope pl("krig_local", s);
+    switch (dim) {
+      case 1:
+        hipLaunchKernelGGL((krig_local_kernel<1>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
+                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
+        break;
+      case 2:
+        hipLaunchKernelGGL((krig_local_kernel<2>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
+                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
+        break;
+      default:
+        hipLaunchKernelGGL((krig_local_kernel<3>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
+                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
+        break;
+    }
+    GSS_HIP(hipGetLastError());
+  }
+  if (!idx_out || !count_out || !status) GSS_HIP(hipStreamSynchronize(s));  // scratch is freed on return
+  return GSS_OK;
+}
+
+}  // namespace gss

@@ -3,12 +3,6 @@
 using namespace gss;
 #define GSS_STUB(name) do { set_error(name ": not implemented in this build"); return GSS_ERR_UNSUPPORTED; } while (0)
 extern "C" {
-int32_t gss_knn_search(const double*, int64_t, int32_t, const double*, int64_t, int32_t, double, const double*,
-                       int32_t*, int32_t*, int32_t, void*) { GSS_STUB("gss_knn_search"); }
-int32_t gss_krig_predict_knn(gss_krig_t*, const double*, const double*, int64_t, int32_t, int32_t, double,
-                             const double*, double*, double*, uint8_t*, int32_t*, int32_t*, int32_t, void*) {
-  GSS_STUB("gss_krig_predict_knn");
-}
 int32_t gss_krig_predict_global_batch(gss_krig_t*, const double*, int64_t, const double*, int64_t, double*, int32_t,
                                       void*) { GSS_STUB("gss_krig_predict_global_batch"); }
 int32_t gss_lugs_create(gss_lugs_t**, const gss_variogram_t*, const double*, int64_t, const int64_t*, const double*,

@@ -1,0 +1,142 @@
+"""Moving-neighbourhood kriging (K4 + K5) vs the oracle: neighbour indices bit-exact, means and
+variances 1e-9 (well-conditioned models; Gaussian 1e-6)."""
+import numpy as np
+import pytest
+
+from oracle import fftgs as offt, kriging as K
+from oracle.variogram import Variogram
+
+pytestmark = pytest.mark.gpu
+
+
+def _vgs(kind, **kw):
+    import gss
+    ctor = dict(gaussian=gss.GaussianVariogram, exponential=gss.ExponentialVariogram,
+                spherical=gss.SphericalVariogram, matern=gss.MaternVariogram)[kind]
+    okw = dict(kw)
+    if "nu" in kw:
+        kw = dict(kw)
+        kw["order"] = kw.pop("nu")
+    return ctor(**kw), Variogram(kind, **okw)
+
+
+@pytest.mark.parametrize("n,m,dim,k", [(5, 40, 1, 3), (100, 500, 2, 8), (3000, 600, 3, 64), (2049, 300, 3, 17),
+                                       (64, 100, 2, 64), (5000, 257, 3, 64)])
+def test_knn_indices_bit_exact(n, m, dim, k):
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(n + k)
+    x = rng.uniform(0, 100, (n, dim))
+    c = rng.uniform(0, 100, (m, dim))
+    c[:3] = x[:3]
+    idx, cnt = HipEngine.knn_search(x, c, k)
+    ridx, rcnt = K.knn_search(x, c, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+
+
+def test_knn_lattice_ties_and_balls():
+    from gss.engine import HipEngine
+    g = offt.grid_centroids((12, 12))                     # lattice -> many exactly equal distances
+    c = np.array([[6.0, 6.0], [0.0, 0.0], [5.5, 5.5], [11.9, 3.2]])
+    for k in (1, 4, 9, 30):
+        idx, cnt = HipEngine.knn_search(g, c, k)
+        ridx, rcnt = K.knn_search(g, c, k)
+        assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+    idx, cnt = HipEngine.knn_search(g, c, 20, radius=1.5)
+    ridx, rcnt = K.knn_search(g, c, 20, radius=1.5)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and cnt.max() < 20
+    idx, cnt = HipEngine.knn_search(g, c, 20, radii=(3.0, 1.0))
+    ridx, rcnt = K.knn_search(g, c, 20, radii=(3.0, 1.0))
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+
+
+CASES = [(K.OK, {}, "matern", dict(range=30.0, nu=1.5)), (K.SK, dict(mean=0.4), "exponential", dict(range=25.0)),
+         (K.UK, dict(degree=1), "matern", dict(range=30.0, nu=1.5)),
+         (K.UK, dict(degree=2), "spherical", dict(range=40.0, nugget=0.05))]
+
+
+@pytest.mark.parametrize("variant,okw,kind,vkw", CASES)
+@pytest.mark.parametrize("n,m,dim,k", [(400, 300, 3, 64), (200, 250, 2, 16), (60, 100, 1, 5)])
+def test_local_kriging_matches_oracle(variant, okw, kind, vkw, n, m, dim, k):
+    from gss.engine import KrigHandle
+    if variant == K.UK and okw["degree"] == 2 and k < 12:
+        pytest.skip("fewer neighbours than drift terms")
+    gvg, ovg = _vgs(kind, **vkw)
+    rng = np.random.default_rng(n * 3 + k)
+    x = rng.uniform(0, 100, (n, dim))
+    if dim == 1:       # uniform samples on a line contain near-duplicates (cond ~ 1e12): use a jittered lattice
+        x = (np.linspace(0, 100, n) + rng.uniform(-0.3, 0.3, n))[:, None]
+    z = rng.normal(size=n) + 0.02 * x[:, 0]
+    x0 = rng.uniform(0, 100, (m, dim))
+    x0[:2] = x[:2]
+    h = KrigHandle(gvg, variant, x, z, mean=okw.get("mean"), degree=okw.get("degree"), factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, k, return_idx=True)
+    h.close()
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(variant, ovg, x, z, x0, k, mean=okw.get("mean") or 0.0,
+                                               degree=okw.get("degree"), return_idx=True)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and np.array_equal(st, rst)
+    assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu)))
+    assert np.max(np.abs(var - rvar)) < 1e-9
+    assert np.allclose(mu[:2], z[:2], atol=1e-9) or vkw.get("nugget", 0) > 0
+
+
+def test_ball_search_and_minneighbors_missing():
+    from gss.engine import KrigHandle
+    gvg, ovg = _vgs("exponential", range=20.0)
+    rng = np.random.default_rng(77)
+    x = rng.uniform(0, 50, (150, 2))
+    z = rng.normal(size=150)
+    x0 = np.vstack([rng.uniform(0, 50, (200, 2)), [[500.0, 500.0], [80.0, 80.0]]])
+    h = KrigHandle(gvg, K.OK, x, z, factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, 10, minneighbors=3, radius=6.0, return_idx=True)
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(K.OK, ovg, x, z, x0, 10, minneighbors=3, radius=6.0, return_idx=True)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and np.array_equal(st, rst)
+    assert st[-1] == 1 and st[-2] == 1 and np.isnan(mu[-1])               # krig.jl:213-214
+    ok = st == 0
+    assert ok.sum() > 50 and (~ok).sum() >= 2
+    assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-9 and np.max(np.abs(var[ok] - rvar[ok])) < 1e-9
+    h.close()
+
+
+def test_k_equals_n_reproduces_global():
+    from gss.engine import KrigHandle
+    gvg, ovg = _vgs("matern", range=30.0, nu=1.5)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 100, (48, 3))
+    z = rng.normal(size=48)
+    x0 = rng.uniform(0, 100, (300, 3))
+    hg = KrigHandle(gvg, K.OK, x, z)
+    mu_g, var_g, _ = hg.predict_global(x0)
+    hl = KrigHandle(gvg, K.OK, x, z, factor=False)
+    mu_l, var_l, st = hl.predict_knn(x0, 48)
+    assert not st.any() and np.max(np.abs(mu_g - mu_l)) < 1e-9 and np.max(np.abs(var_g - var_l)) < 1e-9
+
+
+def test_reference_nearest_and_local_cases_through_solve():
+    """test/estimation/krig.jl:39-72 through the solver front-end (atol 1e-3 as in the reference)."""
+    import gss
+    data = gss.georef({"z": [1.0, 0.0, 1.0]}, [(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)])
+    grid = gss.CartesianGrid((100, 100), (0.5, 0.5), (1.0, 1.0))
+    vg = gss.GaussianVariogram(range=35.0, nugget=0.0)
+    for params in (dict(variogram=vg, maxneighbors=3),
+                   dict(variogram=vg, maxneighbors=3, neighborhood=gss.MetricBall(100.0))):
+        sol = gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", params)))
+        Z = gss.asarray(sol, "z")
+        assert abs(Z[24, 24] - 1.0) < 1e-3 and abs(Z[49, 74] - 0.0) < 1e-3 and abs(Z[74, 49] - 1.0) < 1e-3
+    with pytest.warns(UserWarning, match="Invalid maximum number of neighbors. Adjusting to 3..."):
+        sol = gss.solve(gss.EstimationProblem(data, grid, "z"),
+                        gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=7))))
+    assert np.all(np.isfinite(sol["z"]))
+
+
+def test_config5_shape_small():
+    """BASELINE config 5 at reduced m: UK degree 1, 5 000 3-D data, k = 64, Matern-3/2."""
+    from gss.engine import KrigHandle
+    gvg, ovg = _vgs("matern", range=30.0, nu=1.5)
+    x = np.random.default_rng(6).uniform(0, 100, (5000, 3))
+    z = 1.0 + 0.03 * x[:, 0] - 0.02 * x[:, 1] + 0.01 * x[:, 2] + np.random.default_rng(60).normal(size=5000)
+    x0 = np.random.default_rng(7).uniform(0, 100, (400, 3))
+    h = KrigHandle(gvg, K.UK, x, z, degree=1, factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, 64, return_idx=True)
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(K.UK, ovg, x, z, x0, 64, degree=1, return_idx=True)
+    assert np.array_equal(idx, ridx) and not st.any()
+    assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var - rvar)) < 1e-9
