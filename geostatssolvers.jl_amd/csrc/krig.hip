@@ -225,6 +225,18 @@ __global__ void flip_tail_kernel(double* u, int64_t from, int64_t to) {
   if (i < to) u[i] = -u[i];
 }
 
+// rows [from, to) of a column-major matrix with `ncols` columns change sign
+__global__ void flip_rows_kernel(double* u, int64_t ld, int64_t from, int64_t to, int64_t ncols) {
+  const int64_t i = from + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t c = blockIdx.y;
+  if (i < to && c < ncols) u[i + c * ld] = -u[i + c * ld];
+}
+
+__global__ void add_scalar_kernel(double* x, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] += v;
+}
+
 __global__ void sub_scalar_kernel(double* z, int64_t n, double mu) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) z[i] -= mu;
@@ -616,6 +628,100 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
   GSS_TRY(sstat.back(status, (size_t)m, mem, s));
   GSS_TRY(sidx.back(idx_out, sizeof(int32_t) * (size_t)(m * k), mem, s));
   GSS_TRY(scnt.back(count_out, sizeof(int32_t) * (size_t)m, mem, s));
+  return GSS_OK;
+}
+
+
+// One factorised system, many data vectors: the conditional-FFTGS pattern (fft.jl:176-188) where every
+// realisation is kriged from the same locations.  mean_b(p) = wd_b . rhs(p) with WD = K^-1 [Z; 0]:
+// one GEMM for the dual weights and one GEMM per chunk of domain points.
+int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t m, const double* zbatch,
+                                      int64_t nbatch, double* mean_out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_REQUIRE(h->factored, "handle has no factor");
+  GSS_REQUIRE(m >= 0 && nbatch >= 0, "negative sizes");
+  GSS_REQUIRE(h->variant != GSS_KRIG_EXTDRIFT, "batched prediction is not available with external drifts");
+  if (m == 0 || nbatch == 0) return GSS_OK;
+  GSS_REQUIRE(xdom && zbatch && mean_out, "gss_krig_predict_global_batch: NULL array");
+  hipStream_t s = to_stream(stream);
+  const int dim = h->dim;
+  const int64_t n = h->n, N1 = h->N1, ldw = h->ldw;
+  Staged sx, sz, so;
+  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  GSS_TRY(sz.in(zbatch, sizeof(double) * nbatch * n, mem, s));
+  GSS_TRY(so.out(mean_out, sizeof(double) * (size_t)(nbatch * m), mem));
+
+  DevBuf Zm, U, WD;
+  GSS_TRY(Zm.alloc(sizeof(double) * (size_t)(ldw * nbatch)));
+  GSS_TRY(U.alloc(sizeof(double) * (size_t)(ldw * nbatch)));
+  GSS_TRY(WD.alloc(sizeof(double) * (size_t)(ldw * nbatch)));
+  GSS_HIP(hipMemsetAsync(Zm.p, 0, Zm.bytes, s));
+  GSS_HIP(hipMemsetAsync(WD.p, 0, WD.bytes, s));
+  GSS_HIP(hipMemcpy2DAsync(Zm.p, sizeof(double) * ldw, sz.p, sizeof(double) * n, sizeof(double) * n, nbatch,
+                           hipMemcpyDeviceToDevice, s));
+  if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
+    // only the first n rows of each column hold data; the padding rows are multiplied by zero columns of W'
+    hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)((ldw * nbatch + 255) / 256)), dim3(256), 0, s,
+                       Zm.as<double>(), ldw * nbatch, -h->sk_mean);
+  }
+  // U = W' Zm ; flip constraint rows ; WD = W'' U
+  GSS_TRY(gemm_f64(N1, nbatch, n, 1.0, h->Wp(), 1, ldw, Zm.as<double>(), 1, ldw, 0.0, U.as<double>(), 1, ldw,
+                   false, s));
+  if (h->nc > 0) {
+    hipLaunchKernelGGL(flip_rows_kernel, dim3(1, (unsigned)nbatch), dim3(256), 0, s, U.as<double>(), ldw, n, N1,
+                       nbatch);
+  }
+  GSS_TRY(gemm_f64(N1, nbatch, N1, 1.0, h->Wp(), ldw, 1, U.as<double>(), 1, ldw, 0.0, WD.as<double>(), 1, ldw,
+                   false, s));
+  GSS_HIP(hipGetLastError());
+
+  size_t ws = (size_t)1536 << 20;
+  int64_t cap = (int64_t)(ws / (sizeof(double) * (size_t)h->N1pad)) / 256 * 256;
+  if (cap < 256) cap = 256;
+  const int64_t mc = round_up(m, 256) < cap ? round_up(m, 256) : cap;
+  if (h->mc < mc) {
+    GSS_HIP(hipStreamSynchronize(s));
+    GSS_TRY(h->R.alloc(sizeof(double) * (size_t)(h->N1pad * mc)));
+    GSS_TRY(h->mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
+    h->mc = mc;
+  }
+  const int64_t ldr = h->mc;
+  const int seg_len = (int)((n + NSEG - 1) / NSEG);
+  for (int64_t off = 0; off < m; off += mc) {
+    const int64_t mv = (m - off) < mc ? (m - off) : mc;
+    const int64_t cols = round_up(mv, 256);
+    const double* x0 = sx.as<double>() + off * dim;
+    dim3 g1((unsigned)(cols / 256), NSEG);
+    switch (dim) {
+      case 1:
+        hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
+                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+      case 2:
+        hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
+                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+      default:
+        hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
+                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+        break;
+    }
+    GSS_HIP(hipGetLastError());
+    const int nrows = (int)(h->N1pad - n);
+    if (nrows > 0)
+      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, h->R.as<double>() + n * ldr, ldr, nrows, h->wd() + n,
+                                h->mean_part.as<double>() + (int64_t)NSEG * ldr, s));
+    // out(b, off + p) = sum_k WD(k, b) R(k, p)
+    GSS_TRY(gemm_f64(nbatch, mv, N1, 1.0, WD.as<double>(), ldw, 1, h->R.as<double>(), ldr, 1, 0.0,
+                     so.as<double>() + off, m, 1, false, s));
+  }
+  if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
+    hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)((nbatch * m + 255) / 256)), dim3(256), 0, s,
+                       so.as<double>(), nbatch * m, h->sk_mean);
+  }
+  GSS_HIP(hipGetLastError());
+  GSS_TRY(so.back(mean_out, sizeof(double) * (size_t)(nbatch * m), mem, s));
+  GSS_HIP(hipStreamSynchronize(s));  // Zm / U / WD are freed on return
   return GSS_OK;
 }
 

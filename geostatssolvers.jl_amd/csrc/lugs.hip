@@ -1,0 +1,268 @@
+// LUGS: LU (Cholesky) Gaussian simulation (Alabert 1987).
+// Replaces preprocess (/root/reference/src/simulation/lu.jl:105-147) and lusim (lu.jl:198-224) for one
+// variable; the host front-end keeps the reference's loop over co-variables and the rho mixing
+// (lu.jl:171-196) and passes w1 back in for the second variable.
+//
+//   lu.jl:124      C22 = sill - pairwise(g, Ds)                   cov_pairwise (K1)
+//   lu.jl:128      L22 = cholesky(C22).L          (unconditional)  potrf_f64 (FP64 MFMA GEMM recursion)
+//   lu.jl:131-132  C11, C12
+//   lu.jl:134      L11 = cholesky(C11).L
+//   lu.jl:135      B12 = L11 \ C12     -> stored transposed: A21 = C21 * inv(L11)'   (trsm_right_lt_f64)
+//   lu.jl:136-138  d2  = A21 * (L11 \ z1)
+//   lu.jl:139      L22 = cholesky(C22 - A21 * B12).L               (lower-tile SYRK + potrf)
+//   lu.jl:209-213  y2  = d2 + L22 * w          for all realisations at once: one GEMM L22 * W
+//   lu.jl:217-221  scatter to dlocs / slocs, add the mean when unconditional
+// State kept in HBM: L22 (ns x ns, column-major, strict upper triangle zeroed) followed by d2 (ns).
+#include "gss_internal.h"
+#include "philox.h"
+
+#include <cmath>
+#include <vector>
+
+namespace gss {
+
+__global__ __launch_bounds__(256) void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // row
+  const int64_t j = blockIdx.y;                               // column
+  if (i < n && i < j) A[i + j * ld] = 0.0;
+}
+
+// W(k, r) = rho * w1(k, r) + sqrt(1 - rho^2) * w2(k, r)
+__global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ w1, const double* __restrict__ w2,
+                                                  double rho, double c, int64_t n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rho * w1[i] + c * w2[i];
+}
+
+__global__ __launch_bounds__(256) void philox_normal_batch_kernel(uint64_t seed, int64_t first_real, int64_t ns,
+                                                                  double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (e < ns) out[r * ns + e] = philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)e);
+}
+
+// out[r * N + slocs[i]] = d2[i] + Y2[i + r * ns] (+ mean);  out[r * N + dlocs[j]] = z1[j]
+__global__ __launch_bounds__(256) void lugs_scatter_kernel(const double* __restrict__ Y2,
+                                                           const double* __restrict__ d2,
+                                                           const int64_t* __restrict__ slocs, int64_t ns,
+                                                           const double* __restrict__ z1,
+                                                           const int64_t* __restrict__ dlocs, int64_t nd, double add,
+                                                           int64_t N, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (e < ns) out[r * N + slocs[e]] = d2[e] + Y2[e + r * ns] + add;
+  else if (e < ns + nd) out[r * N + dlocs[e - ns]] = z1[e - ns];
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+struct gss_lugs {
+  VgDev vg;
+  int dim = 0;
+  int64_t N = 0, nd = 0, ns = 0;
+  double mean = 0.0;
+  DevBuf state;  // L22 (ns*ns) + d2 (ns)
+  DevBuf slocs, dlocs, z1;
+  bool ready = false;
+  double* L22() const { return state.as<double>(); }
+  double* d2() const { return state.as<double>() + ns * ns; }
+};
+
+static int32_t check_info(DevBuf& info, const char* what) {
+  int h = 0;
+  GSS_HIP(hipMemcpy(&h, info.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (h != 0) {
+    set_error("%s is not positive definite (pivot %d); add a nugget or remove duplicate locations", what, h - 1);
+    return GSS_ERR_NOT_POSDEF;
+  }
+  return GSS_OK;
+}
+
+extern "C" {
+
+int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
+                        const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
+                        void* stream) {
+  GSS_REQUIRE(out != nullptr, "gss_lugs_create: out is NULL");
+  *out = nullptr;
+  GSS_REQUIRE(centroids != nullptr && N >= 1 && nd >= 0 && nd <= N, "gss_lugs_create: bad sizes");
+  GSS_REQUIRE(nd == 0 || (dlocs != nullptr && z1 != nullptr), "gss_lugs_create: NULL conditioning data");
+  gss_lugs* h = new (std::nothrow) gss_lugs();
+  if (!h) return GSS_ERR_ALLOC;
+  struct Guard {
+    gss_lugs* h;
+    ~Guard() { delete h; }
+  } guard{h};
+  GSS_TRY(make_vgdev(vg, &h->vg));
+  const int dim = h->dim = h->vg.dim;
+  h->N = N;
+  h->nd = nd;
+  h->ns = N - nd;
+  h->mean = mean;
+  const int64_t ns = h->ns;
+  hipStream_t s = to_stream(stream);
+
+  // slocs = complement of dlocs (lu.jl:117), coordinates gathered on the host (O(N) bookkeeping)
+  std::vector<char> isdata((size_t)N, 0);
+  for (int64_t j = 0; j < nd; ++j) {
+    GSS_REQUIRE(dlocs[j] >= 0 && dlocs[j] < N && !isdata[(size_t)dlocs[j]], "dlocs must be distinct and inside 0..N-1");
+    GSS_REQUIRE(j == 0 || dlocs[j] > dlocs[j - 1], "dlocs must be sorted (findall(mask), lu.jl:113)");
+    isdata[(size_t)dlocs[j]] = 1;
+  }
+  std::vector<int64_t> sl;
+  sl.reserve((size_t)ns);
+  for (int64_t l = 0; l < N; ++l)
+    if (!isdata[(size_t)l]) sl.push_back(l);
+  std::vector<double> xs((size_t)(ns * dim)), xd((size_t)(nd * dim));
+  for (int64_t i = 0; i < ns; ++i)
+    for (int a = 0; a < dim; ++a) xs[(size_t)(i * dim + a)] = centroids[sl[(size_t)i] * dim + a];
+  for (int64_t j = 0; j < nd; ++j)
+    for (int a = 0; a < dim; ++a) xd[(size_t)(j * dim + a)] = centroids[dlocs[j] * dim + a];
+
+  DevBuf dxs, dxd, info;
+  GSS_TRY(dxs.alloc(sizeof(double) * xs.size()));
+  GSS_TRY(dxd.alloc(sizeof(double) * xd.size()));
+  GSS_TRY(info.alloc(sizeof(int)));
+  GSS_TRY(h->slocs.alloc(sizeof(int64_t) * (size_t)ns));
+  GSS_TRY(h->dlocs.alloc(sizeof(int64_t) * (size_t)nd));
+  GSS_TRY(h->z1.alloc(sizeof(double) * (size_t)nd));
+  GSS_TRY(h->state.alloc(sizeof(double) * (size_t)(ns * ns + ns)));
+  if (ns) GSS_HIP(hipMemcpyAsync(dxs.p, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice, s));
+  if (ns) GSS_HIP(hipMemcpyAsync(h->slocs.p, sl.data(), sizeof(int64_t) * (size_t)ns, hipMemcpyHostToDevice, s));
+  if (nd) {
+    GSS_HIP(hipMemcpyAsync(dxd.p, xd.data(), sizeof(double) * xd.size(), hipMemcpyHostToDevice, s));
+    GSS_HIP(hipMemcpyAsync(h->dlocs.p, dlocs, sizeof(int64_t) * (size_t)nd, hipMemcpyHostToDevice, s));
+    GSS_HIP(hipMemcpyAsync(h->z1.p, z1, sizeof(double) * (size_t)nd, hipMemcpyHostToDevice, s));
+  }
+  GSS_HIP(hipMemsetAsync(h->d2(), 0, sizeof(double) * (size_t)ns, s));
+
+  if (ns > 0) {
+    double* C22 = h->L22();
+    GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
+    if (nd > 0) {
+      DevBuf C11, A21, w, scratch;
+      GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
+      GSS_TRY(A21.alloc(sizeof(double) * (size_t)(ns * nd)));
+      GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));
+      GSS_TRY(scratch.alloc(sizeof(double) * 64 * 64));
+      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxd.as<double>(), nd, C11.as<double>(), nd, s));  // :131
+      // row-major nd x ns == column-major ns x nd: A21 <- C21                                             // :132
+      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, A21.as<double>(), ns, s));
+      GSS_TRY(potrf_f64(C11.as<double>(), nd, nd, info.as<int>(), s));                                      // :134
+      GSS_TRY(check_info(info, "data covariance C11"));
+      GSS_TRY(trsm_right_lt_f64(A21.as<double>(), ns, nd, ns, C11.as<double>(), nd, scratch.as<double>(), s));  // :135
+      // w' = z1' * inv(L11)'  i.e. w = L11 \ z1                                                           // :138
+      GSS_HIP(hipMemcpyAsync(w.p, h->z1.p, sizeof(double) * (size_t)nd, hipMemcpyDeviceToDevice, s));
+      GSS_TRY(trsm_right_lt_f64(w.as<double>(), 1, nd, 1, C11.as<double>(), nd, scratch.as<double>(), s));
+      GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), s));                   // :138
+      // C22 -= A21 * A21'  (lower tiles)                                                                  // :139
+      GSS_TRY(gemm_f64(ns, ns, nd, -1.0, A21.as<double>(), 1, ns, A21.as<double>(), ns, 1, 1.0, C22, 1, ns, true, s));
+      GSS_HIP(hipStreamSynchronize(s));
+    }
+    GSS_TRY(potrf_f64(C22, ns, ns, info.as<int>(), s));                                                     // :128/:139
+    GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22"));
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)ns), dim3(256), 0, s, C22, ns,
+                       ns);
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_HIP(hipStreamSynchronize(s));
+  h->ready = true;
+  (void)flags;
+  guard.h = nullptr;
+  *out = h;
+  return GSS_OK;
+}
+
+int32_t gss_lugs_destroy(gss_lugs_t* h) {
+  delete h;
+  return GSS_OK;
+}
+
+int32_t gss_lugs_info(const gss_lugs_t* h, int64_t* ns, int64_t* nd) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  if (ns) *ns = h->ns;
+  if (nd) *nd = h->nd;
+  return GSS_OK;
+}
+
+int32_t gss_lugs_factor(gss_lugs_t* h, double* l22, double* d2, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  hipStream_t s = to_stream(stream);
+  const hipMemcpyKind kind = mem == GSS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (l22) GSS_HIP(hipMemcpyAsync(l22, h->L22(), sizeof(double) * (size_t)(h->ns * h->ns), kind, s));
+  if (d2) GSS_HIP(hipMemcpyAsync(d2, h->d2(), sizeof(double) * (size_t)h->ns, kind, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+int32_t gss_lugs_state_buffer(gss_lugs_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
+  *dev_ptr = h->state.p;
+  *bytes = (int64_t)(sizeof(double) * (size_t)(h->ns * h->ns + h->ns));
+  return GSS_OK;
+}
+
+int32_t gss_lugs_adopt_state(gss_lugs_t* h) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  h->ready = true;
+  return GSS_OK;
+}
+
+int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                         double rho, const double* w1, double* out, double* w_out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_lugs_realize: bad arguments");
+  GSS_REQUIRE(h->ready, "handle has no factor");
+  GSS_REQUIRE(w1 == nullptr || (rho >= -1.0 && rho <= 1.0), "correlation %g outside [-1, 1]", rho);
+  if (nreals == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  const int64_t ns = h->ns, nd = h->nd, N = h->N, R = nreals;
+  Staged sn, sw1, so, swo;
+  GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(R * ns), mem, s));
+  GSS_TRY(sw1.in(w1, sizeof(double) * (size_t)(R * ns), mem, s));
+  GSS_TRY(so.out(out, sizeof(double) * (size_t)(R * N), mem));
+  GSS_TRY(swo.out(w_out, sizeof(double) * (size_t)(R * ns), mem));
+  DevBuf w2buf, wmix, Y2;
+  const double* w2 = sn.as<double>();
+  if (!noise) {                                                                                 // lu.jl:209
+    double* dst = swo.p ? swo.as<double>() : nullptr;
+    if (!dst) {
+      GSS_TRY(w2buf.alloc(sizeof(double) * (size_t)(R * ns)));
+      dst = w2buf.as<double>();
+    }
+    if (ns) {
+      hipLaunchKernelGGL(philox_normal_batch_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)R), dim3(256), 0, s,
+                         seed, first_real, ns, dst);
+      GSS_HIP(hipGetLastError());
+    }
+    w2 = dst;
+  } else if (swo.p) {
+    GSS_HIP(hipMemcpyAsync(swo.p, w2, sizeof(double) * (size_t)(R * ns), hipMemcpyDeviceToDevice, s));
+  }
+  const double* weff = w2;
+  if (w1 && ns) {                                                                               // lu.jl:213
+    GSS_TRY(wmix.alloc(sizeof(double) * (size_t)(R * ns)));
+    hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((R * ns + 255) / 256)), dim3(256), 0, s, sw1.as<double>(), w2, rho,
+                       std::sqrt(1.0 - rho * rho), R * ns, wmix.as<double>());
+    GSS_HIP(hipGetLastError());
+    weff = wmix.as<double>();
+  }
+  GSS_TRY(Y2.alloc(sizeof(double) * (size_t)(R * ns)));
+  if (ns) {
+    ProfScope ps("lugs_gemm", s);
+    // Y2 (ns x R, column-major) = L22 * W                                                      // lu.jl:211
+    GSS_TRY(gemm_f64(ns, R, ns, 1.0, h->L22(), 1, ns, weff, 1, ns, 0.0, Y2.as<double>(), 1, ns, false, s));
+  }
+  const double add = nd == 0 ? h->mean : 0.0;                                                   // lu.jl:221
+  hipLaunchKernelGGL(lugs_scatter_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)R), dim3(256), 0, s,
+                     Y2.as<double>(), h->d2(), h->slocs.as<int64_t>(), ns, h->z1.as<double>(),
+                     h->dlocs.as<int64_t>(), nd, add, N, so.as<double>());
+  GSS_HIP(hipGetLastError());
+  GSS_TRY(so.back(out, sizeof(double) * (size_t)(R * N), mem, s));
+  GSS_TRY(swo.back(w_out, sizeof(double) * (size_t)(R * ns), mem, s));
+  GSS_HIP(hipStreamSynchronize(s));  // scratch buffers are freed on return
+  return GSS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""LUGS on the device vs the oracle (lu.jl:76-224 restated with LAPACK).
+
+Tolerances: factors L22 / d2 and realisations from supplied normals 1e-9 absolute (sill 1,
+spherical / exponential models, cond(C) <~ 1e4); Gaussian-variogram cases are property-checked only."""
+import numpy as np
+import pytest
+
+from oracle import fftgs as offt, lugs as O, philox
+from oracle.variogram import Variogram, cov_pairwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(kind, **kw):
+    import gss
+    ctor = dict(gaussian=gss.GaussianVariogram, exponential=gss.ExponentialVariogram,
+                spherical=gss.SphericalVariogram)[kind]
+    radii = kw.pop("radii", None)
+    return ctor(gss.MetricBall(tuple(radii)), **kw) if radii is not None else ctor(**kw)
+
+
+@pytest.mark.parametrize("dims,ndata", [((100,), 5), ((100,), 0), ((30, 20), 40), ((12, 10, 8), 100), ((70, 70), 0)])
+def test_factor_and_realisations_match_oracle(dims, ndata):
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids(dims)
+    N = cent.shape[0]
+    rng = np.random.default_rng(N + ndata)
+    kw = dict(range=0.2 * max(dims) + 3.0, nugget=0.02)
+    dlocs = np.sort(rng.choice(N, ndata, replace=False)) if ndata else np.empty(0, dtype=np.int64)
+    z1 = rng.normal(size=ndata)
+    h = LUGSHandle(_mk("spherical", **kw), cent, dlocs, z1, mean=0.75)
+    ovg = Variogram("spherical", **kw)
+    p = O.preprocess(ovg, cent, cent[dlocs] if ndata else None, z1 if ndata else None, mean=0.75)
+    assert np.array_equal(p.dlocs, dlocs) and h.ns == p.slocs.size
+    L22, d2 = h.factor()
+    assert np.array_equal(np.triu(L22, 1), np.zeros_like(L22))
+    assert np.max(np.abs(L22 - p.L22)) < 1e-9 and np.max(np.abs(d2 - p.d2)) < 1e-9
+    w = rng.normal(size=(3, h.ns))
+    y, wout = h.realize(0, 0, 3, noise=w)
+    assert np.array_equal(wout, w)
+    for r in range(3):
+        ref, _ = O.lusim(p, w[r])
+        assert np.max(np.abs(y[r] - ref)) < 1e-9
+        assert np.array_equal(y[r][dlocs], z1)                       # lu.jl:217
+    # device Philox normals: same draws as the oracle up to libm rounding
+    y2, w2 = h.realize(123, 5, 2)
+    ry, rw = O.realize(p, 123, 5, 2)
+    assert np.max(np.abs(w2 - rw)) < 1e-12 and np.max(np.abs(y2 - ry)) < 1e-9
+    h.close()
+
+
+def test_cosimulation_matches_oracle():
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids((500,))                                # test/simulation/lu.jl:33-45
+    h1 = LUGSHandle(_mk("spherical", range=10.0), cent, [], [], 0.0)
+    h2 = LUGSHandle(_mk("exponential", range=10.0), cent, [], [], 0.0)
+    p1 = O.preprocess(Variogram("spherical", range=10.0), cent)
+    p2 = O.preprocess(Variogram("exponential", range=10.0), cent)
+    y1, w1 = h1.realize(7, 0, 4)
+    y2, w2 = h2.realize(8, 0, 4, rho=0.95, w1=w1)
+    ry1, rw1 = O.realize(p1, 7, 0, 4)
+    ry2, rw2 = O.realize(p2, 8, 0, 4, rho=0.95, w1=rw1)
+    assert np.max(np.abs(y1 - ry1)) < 1e-9 and np.max(np.abs(y2 - ry2)) < 1e-9
+    assert np.max(np.abs(w2 - rw2)) < 1e-12                            # w_out is the raw second draw (lu.jl:223)
+
+
+def test_statistics_and_device_outputs():
+    import torch
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids((16, 16))
+    vg = Variogram("exponential", range=6.0, sill=2.0)
+    h = LUGSHandle(_mk("exponential", range=6.0, sill=2.0), cent, [], [], mean=3.0)
+    y, _ = h.realize(11, 0, 20000, device=True)
+    torch.cuda.synchronize()
+    C = cov_pairwise(vg, cent)
+    emp = torch.cov(y.T).cpu().numpy()
+    assert np.max(np.abs(emp - C)) < 0.08 and abs(float(y.mean()) - 3.0) < 0.02
+    L22, _ = h.factor()
+    assert np.max(np.abs(L22 @ L22.T - C)) < 1e-10
+
+
+def test_reference_cases_through_solve_api():
+    import gss
+    S = gss.georef({"z": [0.0, 1.0, 0.0, 1.0, 0.0]}, np.array([[0.0], [25.0], [50.0], [75.0], [100.0]]))
+    D = gss.CartesianGrid(100)
+    # conditional (test/simulation/lu.jl:8-16)
+    sol = gss.solve(gss.SimulationProblem(S, D, "z", 2),
+                    gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))), rng=123))
+    assert len(sol) == 2 and sol[0].z.shape == (100,)
+    cent = D.centroids()
+    near = [int(np.argmin(np.abs(cent[:, 0] - c))) for c in (0.0, 25.0, 50.0, 75.0, 100.0)]
+    assert np.allclose(sol[1].z[near], [0.0, 1.0, 0.0, 1.0, 0.0])
+    # unconditional (lu.jl:18-27)
+    sol = gss.solve(gss.SimulationProblem(D, ("z", float), 2),
+                    gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))), rng=123))
+    assert np.all(np.isfinite(sol["z"][0]))
+    # co-simulation (lu.jl:29-45)
+    D5 = gss.CartesianGrid(500)
+    solver = gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))),
+                      ("y", dict(variogram=gss.GaussianVariogram(range=10.0, nugget=1e-4))),
+                      (("z", "y"), dict(correlation=0.95)), rng=123)
+    sol = gss.solve(gss.SimulationProblem(D5, (("z", float), ("y", float)), 1), solver)
+    assert sol[0].z.shape == (500,) and sol[0].y.shape == (500,)
+    # anisotropy (lu.jl:56-64), with a nugget so the Gaussian model is numerically positive definite
+    ball = gss.MetricBall((20.0, 5.0))
+    sol = gss.solve(gss.SimulationProblem(gss.CartesianGrid(40, 40), ("z", float), 3),
+                    gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(ball, nugget=1e-3))), rng=123))
+    assert len(sol["z"]) == 3 and np.all(np.isfinite(sol["z"][2]))
+    # custom factorization (lu.jl:66-76): `lu` is documented as unsupported on the device
+    with pytest.raises(NotImplementedError):
+        gss.solve(gss.SimulationProblem(S, D, "z", 1),
+                  gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), factorization="lu")), rng=1))
+    with pytest.warns(UserWarning, match="mean can only be specified in unconditional simulation"):
+        gss.solve(gss.SimulationProblem(S, D, "z", 1),
+                  gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), mean=1.0)), rng=1))
+
+
+def test_gaussian_without_nugget_reports_not_posdef_or_runs():
+    """test/simulation/lu.jl:47-54 runs a 100x100 Gaussian model with no nugget (10^4 x 10^4 Cholesky of a
+    numerically singular matrix); on the device this either factors or fails loudly, never silently."""
+    import gss
+    from gss import _lib
+    try:
+        sol = gss.solve(gss.SimulationProblem(gss.CartesianGrid(30, 30), ("z", float), 1),
+                        gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(range=10.0))), rng=123))
+        assert np.all(np.isfinite(sol["z"][0]))
+    except _lib.GSSError as e:
+        assert e.code == _lib.ERR_NOT_POSDEF
+
+
+def test_2d_100x100_runs_with_properties():
+    """The reference's largest LUGS case size (N = 10^4): L22 L22' == C checked through random probes."""
+    import torch
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids((100, 100))
+    vg = Variogram("spherical", range=10.0)
+    h = LUGSHandle(_mk("spherical", range=10.0), cent, [], [], 0.0)
+    L22, d2 = h.factor()
+    rows = np.random.default_rng(0).integers(0, h.ns, 6)
+    for i in rows:
+        assert np.max(np.abs(L22[i] @ L22.T - cov_pairwise(vg, cent[i:i + 1], cent)[0])) < 1e-10
+    assert not d2.any()
+    y, _ = h.realize(3, 0, 3)
+    assert y.shape == (3, 10000) and np.all(np.isfinite(y)) and abs(y.var() - 1.0) < 0.3   # 3 correlated fields: loose sanity bound
+    h.close()
+
+
+def test_batched_global_prediction_matches_loop():
+    from gss.engine import KrigHandle
+    import gss
+    from oracle import kriging as K
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 100, (150, 2))
+    x0 = rng.uniform(0, 100, (700, 2))
+    zb = rng.normal(size=(5, 150))
+    for variant, mean in ((K.SK, 0.3), (K.OK, None)):
+        h = KrigHandle(gss.ExponentialVariogram(range=25.0), variant, x, zb[0], mean=mean)
+        out = h.predict_global_batch(x0, zb)
+        h.close()
+        for b in range(5):
+            ref, _ = K.exactsolve(variant, Variogram("exponential", range=25.0), x, zb[b], x0, mean=mean or 0.0)
+            assert np.max(np.abs(out[b] - ref)) < 1e-9
