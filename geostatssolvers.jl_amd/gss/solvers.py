@@ -249,12 +249,23 @@ class FFTGS(_Solver):
                 np.empty((0, pdom.nelements()))
             if q["krig"] is not None and hi > lo:                                     # fft.jl:176-192
                 cent = pdom.centroids()
-                out = np.empty_like(zu)
-                for r in range(zu.shape[0]):
-                    kdat = georef({var: zu[r, q["dinds"]]}, cent[q["dinds"]])
-                    zbar_u = _solve_local(q["krig"], kdat, PointSet(cent), var)[var]
-                    out[r] = q["zbar"] + (zu[r] - zbar_u)
-                zu = out
+                dinds = q["dinds"]
+                kp = q["krig"].params(var)
+                if kp["maxneighbors"] is None:
+                    # one kriging system (same locations) serves every realisation: factor once, batch the data
+                    h = self.engine.Krig(q["vg"], SK, cent[dinds], zu[0, dinds], mean=q["mean"])
+                    try:
+                        zbar_u = h.predict_global_batch(cent, np.ascontiguousarray(zu[:, dinds]))
+                    finally:
+                        h.close()
+                    zu = q["zbar"][None, :] + (zu - zbar_u)                           # fft.jl:191
+                else:
+                    out = np.empty_like(zu)
+                    for r in range(zu.shape[0]):
+                        kdat = georef({var: zu[r, dinds]}, cent[dinds])
+                        zbar_u = _solve_local(q["krig"], kdat, PointSet(cent), var)[var]
+                        out[r] = q["zbar"] + (zu[r] - zbar_u)
+                    zu = out
             q["handle"].close()
             if gather and ws > 1:
                 zu = parallel.all_gather_concat(zu, problem.nreals)

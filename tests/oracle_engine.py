@@ -1,0 +1,86 @@
+"""Stand-in engine for CPU-only tests of the HOST logic (parameter handling, sharding, collectives).
+
+It has the interface of gss.engine.HipEngine but computes with the oracle.  It lives under tests/ on
+purpose: the product never imports it, and GPU parity tests never use it."""
+import numpy as np
+
+from oracle import fftgs as OF, kriging as OK_, lugs as OL, philox
+from oracle.variogram import Variogram, cov_pairwise
+
+
+def _ovg(vg):
+    return Variogram(vg.kind, sill=vg.sill, nugget=vg.nugget, range=vg.range, nu=vg.nu, radii=vg.radii)
+
+
+class _Krig:
+    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True):
+        self.vg, self.variant = _ovg(vg), variant
+        self.x = np.atleast_2d(np.asarray(xdata, dtype=np.float64))
+        self.z = np.asarray(z, dtype=np.float64)
+        self.mean, self.degree, self.drift_data = mean or 0.0, degree, drift_data
+
+    def close(self):
+        pass
+
+    def predict_global(self, xdom, drift_dom=None):
+        mu, var = OK_.exactsolve(self.variant, self.vg, self.x, self.z, xdom, mean=self.mean, degree=self.degree,
+                                 drift_data=self.drift_data, drift_dom=drift_dom)
+        return mu, var, np.zeros(len(mu), dtype=np.uint8)
+
+    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False):
+        return OK_.approxsolve(self.variant, self.vg, self.x, self.z, xdom, k, minneighbors, mean=self.mean,
+                               degree=self.degree, drift_data=self.drift_data, drift_dom=drift_dom, radius=radius,
+                               radii=radii, return_idx=return_idx)
+
+    def predict_global_batch(self, xdom, zbatch):
+        return np.stack([OK_.exactsolve(self.variant, self.vg, self.x, zb, xdom, mean=self.mean)[0] for zb in zbatch])
+
+
+class _FFTGS:
+    def __init__(self, vg, dims, spacing=None, mean=0.0):
+        self.pre = OF.preprocess(_ovg(vg), dims, spacing=spacing, mean=mean)
+        self.N = int(np.prod(dims))
+
+    def close(self):
+        pass
+
+    def spectrum(self):
+        return self.pre.F.ravel()
+
+    def realize(self, seed, first_real, nreals, noise=None, inds=None, out=None, device=False):
+        if noise is not None:
+            return np.stack([OF.solvesingle(self.pre, noise[r], inds) for r in range(nreals)])
+        return OF.realize(self.pre, seed, first_real, nreals, inds) if nreals else np.empty((0, self.N))
+
+
+class _LUGS:
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0):
+        c = np.asarray(centroids, dtype=np.float64)
+        dl = np.asarray(dlocs, dtype=np.int64)
+        self.p = OL.preprocess(_ovg(vg), c, c[dl] if dl.size else None, np.asarray(z1) if dl.size else None, mean=mean)
+        self.N, self.ns = c.shape[0], self.p.slocs.size
+
+    def close(self):
+        pass
+
+    def realize(self, seed, first_real, nreals, noise=None, rho=None, w1=None, device=False):
+        ys, ws = [], []
+        for r in range(nreals):
+            w2 = noise[r] if noise is not None else philox.normal(seed, first_real + r, self.ns)
+            y, _ = OL.lusim(self.p, w2, rho, None if w1 is None else w1[r])
+            ys.append(y)
+            ws.append(w2)
+        return (np.stack(ys), np.stack(ws)) if nreals else (np.empty((0, self.N)), np.empty((0, self.ns)))
+
+
+class OracleEngine:
+    name = "oracle-stand-in"
+    Krig, FFTGS, LUGS = _Krig, _FFTGS, _LUGS
+
+    @staticmethod
+    def cov_pairwise(vg, a, b=None):
+        return cov_pairwise(_ovg(vg), a, b)
+
+    @staticmethod
+    def knn_search(xdata, centers, k, radius=None, radii=None):
+        return OK_.knn_search(xdata, centers, k, radius, radii)

@@ -147,3 +147,25 @@ def test_large_grid_properties():
     ratio = A[sel] / F[sel]
     assert float((ratio.max() - ratio.min()) / ratio.mean()) < 1e-8
     h.close()
+
+
+@pytest.mark.parametrize("maxneighbors", [None, 2])
+def test_conditional_simulation_matches_oracle(maxneighbors):
+    """test/simulation/fft.jl:24-32 (conditional, 3 data) at the oracle's tolerance for a spherical model;
+    the conditioning path is fft.jl:105-135 + 176-192 (simple kriging with the solver's mean)."""
+    import gss
+    coords = np.array([(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)]) * 0.4
+    vals = [1.0, -1.0, 1.0]
+    grid = gss.CartesianGrid(40, 40)
+    problem = gss.SimulationProblem(gss.georef({"z": vals}, coords), grid, ("z", float), 4)
+    params = dict(variogram=gss.SphericalVariogram(range=12.0), mean=0.2)
+    if maxneighbors:
+        params["maxneighbors"] = maxneighbors
+    sol = gss.solve(problem, gss.FFTGS(("z", params), rng=2022))
+    pre = O.preprocess(Variogram("spherical", range=12.0), (40, 40), mean=0.2, data_coords=coords, data_vals=vals,
+                       maxneighbors=maxneighbors)
+    for r in range(4):
+        ref = O.solvesingle(pre, philox.uniform(2022, r, 1600))
+        assert np.max(np.abs(sol[r].z - ref)) < 1e-8
+    # data are honoured at the data cells up to the centroid offset (fft.jl:112 vs :180-184)
+    assert np.max(np.abs(sol[0].z[pre.dinds] - np.array(vals))) < 0.35

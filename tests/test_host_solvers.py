@@ -1,0 +1,134 @@
+"""Host-side logic of the solver front-ends (no GPU): parameter surface, model / searcher choice,
+missing values, error and warning behaviour of the reference (krig.jl:76-164, ui.jl, fft.jl:62-143,
+lu.jl:76-169).  Arithmetic is supplied by the oracle stand-in engine in tests/oracle_engine.py."""
+import warnings
+
+import numpy as np
+import pytest
+
+import gss
+from gss.engine import EDK, OK, SK, UK
+from oracle_engine import OracleEngine
+
+
+def test_exports_mirror_the_reference_module():        # GeoStatsSolvers.jl:46-69 (hot-path subset)
+    for name in ("KrigingSolver", "FFTGS", "LUGS", "solve", "EstimationProblem", "SimulationProblem"):
+        assert hasattr(gss, name)
+
+
+def test_ui_dispatch_rules():                           # test/ui.jl:6-37
+    dom = gss.PointSet(np.random.default_rng(0).uniform(size=(3, 2)))
+    assert gss.searcher_ui(dom, 2, "euclidean", None) == ("KNearestSearch", 2)
+    assert gss.searcher_ui(dom, 2, None, gss.MetricBall(1.0)) == ("KBallSearch", 2)
+    assert gss.searcher_ui(dom, None, "euclidean", None) == ("KNearestSearch", 3)
+    with pytest.warns(UserWarning, match=r"Invalid maximum number of neighbors. Adjusting to 3\.\.\."):
+        assert gss.searcher_ui(dom, 4, "euclidean", None) == ("KNearestSearch", 3)
+    g = gss.CartesianGrid(10, 10)
+    v = gss.GaussianVariogram()
+    assert gss.kriging_ui(g, v, None, None, None) == OK
+    assert gss.kriging_ui(g, v, 0.0, None, None) == SK
+    assert gss.kriging_ui(g, v, None, 2, None) == UK
+    assert gss.kriging_ui(g, v, None, None, [lambda x: 1]) == EDK
+
+
+def test_solver_parameter_surface():
+    s = gss.KrigingSolver(("a", dict(mean=1.0)), b=dict(degree=1, variogram=gss.SphericalVariogram(range=20.0)))
+    assert s.params("a")["mean"] == 1.0 and s.params("a")["variogram"].kind == "gaussian"     # krig.jl:65 default
+    assert s.params("b")["degree"] == 1 and s.params("c")["minneighbors"] == 1
+    with pytest.raises(ValueError):
+        gss.KrigingSolver(("a", dict(nope=1)))
+    l = gss.LUGS(("z", {}), ("y", {}), (("z", "y"), dict(correlation=0.7)))
+    p = gss.SimulationProblem(gss.CartesianGrid(10), (("z", float), ("y", float), ("w", float)), 1)
+    assert l.covariables(p) == [("z", "y"), ("w",)]
+    assert gss.FFTGS().params("z")["mean"] == 0.0                                              # fft.jl:53
+
+
+def test_variogram_constructors():
+    v = gss.GaussianVariogram(gss.MetricBall((20.0, 5.0)))
+    assert v.radii == (20.0, 5.0) and v.range == 1.0
+    assert gss.SphericalVariogram(gss.MetricBall(7.0)).range == 7.0
+    assert gss.MaternVariogram(range=3.0, order=1.5).nu == 1.5
+
+
+def test_kriging_missing_values_and_errors():
+    data = gss.georef({"z": [1.0, None, 0.0, np.nan, 1.0]}, [(25.0, 25.0), (1.0, 1.0), (50.0, 75.0), (2.0, 2.0), (75.0, 50.0)])
+    grid = gss.CartesianGrid((20, 20), (0.0, 0.0), (5.0, 5.0))
+    solver = gss.KrigingSolver(("z", dict(variogram=gss.GaussianVariogram(range=35.0))), engine=OracleEngine)
+    pre = solver.preprocess(gss.EstimationProblem(data, grid, "z"))
+    assert pre["z"]["x"].shape == (3, 2) and pre["z"]["z"].tolist() == [1.0, 0.0, 1.0]          # krig.jl:97-107
+    sol = gss.solve(gss.EstimationProblem(data, grid, "z"), solver)
+    assert set(sol.names()) == {"z", "z_variance"} and sol["z"].shape == (400,)                # krig.jl:160-163
+    allmiss = gss.georef({"z": [np.nan, np.nan]}, [(0.0, 0.0), (1.0, 1.0)])
+    with pytest.raises(AssertionError, match="all samples of z are missing, aborting..."):    # krig.jl:100-102
+        gss.solve(gss.EstimationProblem(allmiss, grid, "z"), solver)
+
+
+def test_kriging_variants_through_solve_match_direct_oracle():
+    from oracle import kriging as K
+    from oracle.variogram import Variogram
+    rng = np.random.default_rng(1)
+    xy = rng.uniform(0, 50, (30, 2))
+    z = rng.normal(size=30)
+    data = gss.georef({"z": z}, xy)
+    dom = gss.PointSet(rng.uniform(0, 50, (40, 2)))
+    vg = gss.ExponentialVariogram(range=20.0)
+    ovg = Variogram("exponential", range=20.0)
+    for params, ref in [(dict(), K.exactsolve(K.OK, ovg, xy, z, dom.coords)),
+                        (dict(mean=0.5), K.exactsolve(K.SK, ovg, xy, z, dom.coords, mean=0.5)),
+                        (dict(degree=1), K.exactsolve(K.UK, ovg, xy, z, dom.coords, degree=1)),
+                        (dict(mean=0.5, degree=1), K.exactsolve(K.UK, ovg, xy, z, dom.coords, degree=1))]:
+        sol = gss.solve(gss.EstimationProblem(data, dom, "z"),
+                        gss.KrigingSolver(("z", dict(variogram=vg, **params)), engine=OracleEngine))
+        assert np.allclose(sol["z"], ref[0]) and np.allclose(sol["z_variance"], ref[1])
+    # moving neighbourhood with too few neighbours -> missing (NaN)                              krig.jl:213-214
+    sol = gss.solve(gss.EstimationProblem(data, gss.PointSet([[500.0, 500.0]]), "z"),
+                    gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=5, minneighbors=2,
+                                                 neighborhood=gss.MetricBall(3.0))), engine=OracleEngine))
+    assert np.isnan(sol["z"][0]) and np.isnan(sol["z_variance"][0])
+    # external drift functions are evaluated on the host and shipped as values
+    drifts = [lambda p: 1.0, lambda p: p[0]]
+    sol = gss.solve(gss.EstimationProblem(data, dom, "z"),
+                    gss.KrigingSolver(("z", dict(variogram=vg, drifts=drifts)), engine=OracleEngine))
+    ref = K.exactsolve(K.UK, ovg, xy, z, dom.coords, degree=None, drift_data=None) if False else None
+    fd = np.stack([[f(c) for f in drifts] for c in xy])
+    f0 = np.stack([[f(c) for f in drifts] for c in dom.coords])
+    mu, var = K.exactsolve(K.EDK, ovg, xy, z, dom.coords, drift_data=fd, drift_dom=f0)
+    assert np.allclose(sol["z"], mu) and np.allclose(sol["z_variance"], var)
+
+
+def test_unsupported_options_fail_loudly():
+    data = gss.georef({"z": [1.0, 0.0]}, [(0.0, 0.0), (1.0, 1.0)])
+    grid = gss.CartesianGrid(4, 4)
+    for bad in (dict(distance="chebyshev"), dict(path="multigrid")):
+        with pytest.raises(NotImplementedError):
+            gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", bad), engine=OracleEngine))
+    with pytest.raises(ValueError, match="Cartesian grids"):                                    # fft.jl:40-42
+        gss.solve(gss.SimulationProblem(gss.PointSet(np.zeros((4, 2))), ("z", float), 1), gss.FFTGS(engine=OracleEngine))
+
+
+def test_fftgs_and_lugs_through_solve_with_stand_in():
+    grid = gss.CartesianGrid(20, 16)
+    vgrid = gss.view(grid, range(0, 100))
+    sol = gss.solve(gss.SimulationProblem(vgrid, ("z", float), 3),
+                    gss.FFTGS(("z", dict(variogram=gss.ExponentialVariogram(range=5.0))), rng=5, engine=OracleEngine))
+    assert gss.domain(sol) == vgrid and len(sol[0].z) == 100 and len(sol["z"]) == 3           # fft.jl tests :21-22
+    S = gss.georef({"z": [0.0, 1.0, 0.0]}, np.array([[0.0], [10.0], [20.0]]))
+    sol = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(30), "z", 2),
+                    gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=3, engine=OracleEngine))
+    assert len(sol) == 2 and sol[0].z.shape == (30,)
+    with pytest.raises(NotImplementedError, match="factorization=lu"):
+        gss.solve(gss.SimulationProblem(gss.CartesianGrid(10), ("z", float), 1),
+                  gss.LUGS(("z", dict(factorization="lu")), engine=OracleEngine))
+    with pytest.raises(AssertionError):                                                        # lu.jl:96
+        l3 = gss.LUGS((("a", "b", "c"), {}), engine=OracleEngine)
+        gss.solve(gss.SimulationProblem(gss.CartesianGrid(5), (("a", float), ("b", float), ("c", float)), 1), l3)
+
+
+def test_product_engine_refuses_to_run_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    from gss import _lib
+    data = gss.georef({"z": [1.0, 0.0]}, [(0.0, 0.0), (1.0, 1.0)])
+    with pytest.raises(_lib.GSSError, match="no CPU fallback"):
+        gss.solve(gss.EstimationProblem(data, gss.CartesianGrid(4, 4), "z"), gss.KrigingSolver())
