@@ -116,114 +116,160 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
 }
 
 // ---------------------------------------------------------------------------------------------
-// GEMV (column-major A): one wave per output element group; deterministic reduction order
+// GEMV (column-major A): 2-D grid of partial sums, then a fixed-order reduction (deterministic)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemv_n_kernel(int64_t m, int64_t n, const double* __restrict__ A,
-                                                     int64_t lda, const double* __restrict__ x,
-                                                     double* __restrict__ y) {
-  // y[i] = sum_j A[i + j*lda] x[j]; thread per row (coalesced over i)
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+constexpr int GEMV_CHUNK = 64;    // columns per partial (non-transposed)
+constexpr int GEMV_TCHUNK = 256;  // rows per partial (transposed)
+
+__global__ __launch_bounds__(64) void gemv_n_partial_kernel(int64_t m, int64_t n, const double* __restrict__ A,
+                                                            int64_t lda, const double* __restrict__ x,
+                                                            double* __restrict__ partial) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.y * GEMV_CHUNK;
+  const int64_t j1 = j0 + GEMV_CHUNK < n ? j0 + GEMV_CHUNK : n;
   if (i >= m) return;
   double acc = 0.0;
-  for (int64_t j = 0; j < n; ++j) acc = fma(A[i + j * lda], x[j], acc);
+  for (int64_t j = j0; j < j1; ++j) acc = fma(A[i + j * lda], x[j], acc);
+  partial[(int64_t)blockIdx.y * m + i] = acc;
+}
+
+__global__ __launch_bounds__(64) void gemv_t_partial_kernel(int64_t m, int64_t n, const double* __restrict__ A,
+                                                            int64_t lda, const double* __restrict__ x,
+                                                            double* __restrict__ partial) {
+  const int64_t j = blockIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.y * GEMV_TCHUNK;
+  const int64_t i1 = i0 + GEMV_TCHUNK < m ? i0 + GEMV_TCHUNK : m;
+  const int lane = threadIdx.x;
+  double acc = 0.0;
+  for (int64_t i = i0 + lane; i < i1; i += 64) acc = fma(A[i + j * lda], x[i], acc);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) partial[(int64_t)blockIdx.y * n + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void gemv_reduce_kernel(const double* __restrict__ partial, int nparts, int64_t len,
+                                                          double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  double acc = 0.0;
+  for (int p = 0; p < nparts; ++p) acc += partial[(int64_t)p * len + i];
   y[i] = acc;
 }
 
-__global__ __launch_bounds__(64) void gemv_t_kernel(int64_t m, int64_t n, const double* __restrict__ A,
-                                                    int64_t lda, const double* __restrict__ x,
-                                                    double* __restrict__ y) {
-  // y[j] = sum_i A[i + j*lda] x[i]; one wave per column, lanes stride over i, butterfly reduce
-  const int64_t j = blockIdx.x;
-  const int lane = threadIdx.x;
-  double acc = 0.0;
-  for (int64_t i = lane; i < m; i += 64) acc = fma(A[i + j * lda], x[i], acc);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) y[j] = acc;
+int64_t gemv_work_doubles(bool trans, int64_t m, int64_t n) {
+  return trans ? ((m + GEMV_TCHUNK - 1) / GEMV_TCHUNK) * n : ((n + GEMV_CHUNK - 1) / GEMV_CHUNK) * m;
 }
 
 int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda, const double* x, double* y,
-                 hipStream_t s) {
+                 double* work, hipStream_t s) {
+  if (m <= 0 || n <= 0) return GSS_OK;
   if (!trans) {
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, n, A, lda, x, y);
+    const int np = (int)((n + GEMV_CHUNK - 1) / GEMV_CHUNK);
+    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)np), dim3(64), 0, s, m, n, A,
+                       lda, x, work);
+    hipLaunchKernelGGL(gemv_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, work, np, m, y);
   } else {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)n), dim3(64), 0, s, m, n, A, lda, x, y);
+    const int np = (int)((m + GEMV_TCHUNK - 1) / GEMV_TCHUNK);
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)n, (unsigned)np), dim3(64), 0, s, m, n, A, lda, x, work);
+    hipLaunchKernelGGL(gemv_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, work, np, n, y);
   }
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// leaves: Cholesky and triangular inverse of one block (n <= 64) in LDS
+// leaves: Cholesky and triangular inverse of one diagonal block (n <= 64), one wave, out of LDS
 // ---------------------------------------------------------------------------------------------
 constexpr int LEAF = 64;
 constexpr int LEAF_LD = LEAF + 1;
 
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(double* __restrict__ A, int n, int64_t lda,
-                                                         int row_offset, int* __restrict__ info) {
+// Lower-triangular inverse in LDS: X[c * LEAF_LD + i] = W(i, c); lane c owns column c.  S holds L row-major.
+__device__ __forceinline__ void leaf_invert(const double* S, double* X, int n, int lane) {
+  for (int i = lane; i < LEAF * LEAF_LD; i += 64) X[i] = 0.0;
+  __syncthreads();
+  double* x = X + lane * LEAF_LD;
+  for (int i = 0; i < n; ++i) {
+    // columns k < c hold zeros, so the sum may start at 0 for every lane (uniform trip count)
+    double acc = 0.0;
+    const double* row = S + i * LEAF_LD;
+    for (int k = 0; k < i; ++k) acc = fma(row[k], x[k], acc);
+    const double d = row[i];
+    if (lane < n) {
+      if (i == lane) x[i] = 1.0 / d;
+      else if (i > lane) x[i] = -acc / d;
+    }
+  }
+  __syncthreads();
+}
+
+// In-place Cholesky of the lower triangle of A (n <= 64) and, when dinv != nullptr, inv(L) into dinv
+// (64 x 64 column-major, ld = 64, zero padded).  Left-looking by columns: lane i owns row i.
+__global__ __launch_bounds__(64) void potrf_inv_leaf_kernel(double* __restrict__ A, int n, int64_t lda,
+                                                            int row_offset, int* __restrict__ info,
+                                                            double* __restrict__ dinv) {
   __shared__ double S[LEAF * LEAF_LD];  // S[i * LEAF_LD + j] = A(i, j)
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int idx = tid; idx < n * n; idx += 256) {
+  __shared__ double X[LEAF * LEAF_LD];
+  const int lane = threadIdx.x;
+  for (int idx = lane; idx < n * n; idx += 64) {
     const int i = idx % n, j = idx / n;
     S[i * LEAF_LD + j] = (j <= i) ? A[i + (int64_t)j * lda] : 0.0;
   }
   __syncthreads();
+  const double* rowi = S + (lane < n ? lane : 0) * LEAF_LD;
   for (int j = 0; j < n; ++j) {
-    if (tid == 0) {
-      const double d = S[j * LEAF_LD + j];
-      if (!(d > 0.0)) {
-        bad = 1;
-        if (*info == 0) *info = row_offset + j + 1;
-        S[j * LEAF_LD + j] = 1.0;
-      } else {
-        S[j * LEAF_LD + j] = sqrt(d);
-      }
+    const bool mine = lane >= j && lane < n;
+    double acc = 0.0;
+    if (mine) {
+      const double* rowj = S + j * LEAF_LD;
+      acc = rowi[j];
+      for (int c = 0; c < j; ++c) acc = fma(-rowi[c], rowj[c], acc);
     }
-    __syncthreads();
-    const double inv = 1.0 / S[j * LEAF_LD + j];
-    for (int i = j + 1 + tid; i < n; i += 256) S[i * LEAF_LD + j] *= inv;
-    __syncthreads();
-    const int rem = n - j - 1;
-    for (int idx = tid; idx < rem * rem; idx += 256) {
-      const int ii = j + 1 + idx / rem;
-      const int kk = j + 1 + idx % rem;
-      if (kk <= ii) S[ii * LEAF_LD + kk] -= S[ii * LEAF_LD + j] * S[kk * LEAF_LD + j];
+    double d = __shfl(acc, j);
+    if (!(d > 0.0)) {
+      if (lane == 0 && *info == 0) *info = row_offset + j + 1;
+      d = 1.0;
     }
+    const double sq = sqrt(d);
+    if (mine) S[lane * LEAF_LD + j] = (lane == j) ? sq : acc / sq;
     __syncthreads();
   }
-  for (int idx = tid; idx < n * n; idx += 256) {
+  for (int idx = lane; idx < n * n; idx += 64) {
     const int i = idx % n, j = idx / n;
     if (j <= i) A[i + (int64_t)j * lda] = S[i * LEAF_LD + j];
   }
+  if (dinv) {
+    leaf_invert(S, X, n, lane);
+    for (int idx = lane; idx < LEAF * LEAF; idx += 64) {
+      const int i = idx % LEAF, j = idx / LEAF;
+      dinv[idx] = (i < n && j <= i) ? X[j * LEAF_LD + i] : 0.0;
+    }
+  }
 }
 
-// W = inv(L) for one lower-triangular block; each of the first n threads owns one column of W.
+// W = inv(L) for one lower-triangular block (used when no cached inverse exists)
 __global__ __launch_bounds__(64) void trtri_leaf_kernel(const double* __restrict__ L, int n, int64_t ldl,
                                                         double* __restrict__ W, int64_t ldw) {
   __shared__ double S[LEAF * LEAF_LD];
-  __shared__ double X[LEAF * LEAF_LD];  // X[c * LEAF_LD + i] = W(i, c)
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < n * n; idx += 64) {
+  __shared__ double X[LEAF * LEAF_LD];
+  const int lane = threadIdx.x;
+  for (int idx = lane; idx < n * n; idx += 64) {
     const int i = idx % n, j = idx / n;
     S[i * LEAF_LD + j] = (j <= i) ? L[i + (int64_t)j * ldl] : 0.0;
   }
   __syncthreads();
-  if (tid < n) {
-    const int c = tid;
-    double* x = X + c * LEAF_LD;
-    x[c] = 1.0 / S[c * LEAF_LD + c];
-    for (int i = c + 1; i < n; ++i) {
-      double acc = 0.0;
-      for (int k = c; k < i; ++k) acc = fma(S[i * LEAF_LD + k], x[k], acc);
-      x[i] = -acc / S[i * LEAF_LD + i];
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < n * n; idx += 64) {
+  leaf_invert(S, X, n, lane);
+  for (int idx = lane; idx < n * n; idx += 64) {
     const int i = idx % n, j = idx / n;
     W[i + (int64_t)j * ldw] = (j <= i) ? X[j * LEAF_LD + i] : 0.0;
+  }
+}
+
+// W block <- cached inverse block (ld = 64)
+__global__ __launch_bounds__(256) void copy_leaf_kernel(const double* __restrict__ dinv, int n, double* __restrict__ W,
+                                                        int64_t ldw) {
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx % n, j = idx / n;
+    W[i + (int64_t)j * ldw] = dinv[i + j * LEAF];
   }
 }
 
@@ -235,10 +281,12 @@ static int64_t split_point(int64_t n) {
   return h;
 }
 
-int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, hipStream_t s) {
+int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, const double* dinv,
+                  hipStream_t s) {
   if (n <= 0) return GSS_OK;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(64), 0, s, L, (int)n, ldl, W, ldw);
+    if (dinv) hipLaunchKernelGGL(copy_leaf_kernel, dim3(1), dim3(256), 0, s, dinv, (int)n, W, ldw);
+    else hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(64), 0, s, L, (int)n, ldl, W, ldw);
     GSS_HIP(hipGetLastError());
     return GSS_OK;
   }
@@ -247,8 +295,9 @@ int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ld
   const double* L22 = L + n1 + n1 * ldl;
   double* W21 = W + n1;
   double* W22 = W + n1 + n1 * ldw;
-  GSS_TRY(trtri_f64(L, n1, ldl, W, ldw, T, s));
-  GSS_TRY(trtri_f64(L22, n2, ldl, W22, ldw, T, s));
+  const double* dinv2 = dinv ? dinv + (n1 / LEAF) * LEAF * LEAF : nullptr;
+  GSS_TRY(trtri_f64(L, n1, ldl, W, ldw, T, dinv, s));
+  GSS_TRY(trtri_f64(L22, n2, ldl, W22, ldw, T, dinv2, s));
   // T (n2 x n1, row-major) = L21 * W11
   GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, ldl, W, 1, ldw, 0.0, T, n1, 1, false, s));
   // W21 = -W22 * T
@@ -256,55 +305,60 @@ int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ld
   return GSS_OK;
 }
 
+// dinv != nullptr: cached inverses of L's diagonal leaf blocks (block b = rows 64 b ..), else computed in scratch
 int32_t trsm_right_lt_f64(double* X, int64_t m, int64_t n, int64_t ldx, const double* L, int64_t ldl,
-                          double* scratch, hipStream_t s) {
+                          double* scratch, const double* dinv, hipStream_t s) {
   if (m <= 0 || n <= 0) return GSS_OK;
   if (n <= LEAF) {
-    // X <- X * inv(L)'  with inv(L) formed in scratch (n x n, ld = LEAF)
-    hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(64), 0, s, L, (int)n, ldl, scratch, (int64_t)LEAF);
-    GSS_HIP(hipGetLastError());
+    const double* inv = dinv;
+    if (!inv) {
+      hipLaunchKernelGGL(trtri_leaf_kernel, dim3(1), dim3(64), 0, s, L, (int)n, ldl, scratch, (int64_t)LEAF);
+      GSS_HIP(hipGetLastError());
+      inv = scratch;
+    }
     // D(i,j) = sum_k X(i,k) Winv(j,k): one column block (n <= BN), so each workgroup reads all of its
     // rows of X before writing them back
-    return gemm_f64(m, n, n, 1.0, X, 1, ldx, scratch, LEAF, 1, 0.0, X, 1, ldx, false, s);
+    return gemm_f64(m, n, n, 1.0, X, 1, ldx, inv, LEAF, 1, 0.0, X, 1, ldx, false, s);
   }
   const int64_t n1 = split_point(n), n2 = n - n1;
   double* X1 = X;
   double* X2 = X + n1 * ldx;
   const double* L21 = L + n1;
   const double* L22 = L + n1 + n1 * ldl;
-  GSS_TRY(trsm_right_lt_f64(X1, m, n1, ldx, L, ldl, scratch, s));
+  const double* dinv2 = dinv ? dinv + (n1 / LEAF) * LEAF * LEAF : nullptr;
+  GSS_TRY(trsm_right_lt_f64(X1, m, n1, ldx, L, ldl, scratch, dinv, s));
   // X2 -= X1 * L21'
   GSS_TRY(gemm_f64(m, n2, n1, -1.0, X1, 1, ldx, L21, ldl, 1, 1.0, X2, 1, ldx, false, s));
-  GSS_TRY(trsm_right_lt_f64(X2, m, n2, ldx, L22, ldl, scratch, s));
+  GSS_TRY(trsm_right_lt_f64(X2, m, n2, ldx, L22, ldl, scratch, dinv2, s));
   return GSS_OK;
 }
 
-static int32_t potrf_rec(double* A, int64_t n, int64_t lda, int64_t row_offset, int* d_info, double* scratch,
+static int32_t potrf_rec(double* A, int64_t n, int64_t lda, int64_t row_offset, int* d_info, double* dinv,
                          hipStream_t s) {
   if (n <= 0) return GSS_OK;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), 0, s, A, (int)n, lda, (int)row_offset, d_info);
+    hipLaunchKernelGGL(potrf_inv_leaf_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, dinv);
     GSS_HIP(hipGetLastError());
     return GSS_OK;
   }
   const int64_t n1 = split_point(n), n2 = n - n1;
   double* A21 = A + n1;
   double* A22 = A + n1 + n1 * lda;
-  GSS_TRY(potrf_rec(A, n1, lda, row_offset, d_info, scratch, s));
-  GSS_TRY(trsm_right_lt_f64(A21, n2, n1, lda, A, lda, scratch, s));
+  GSS_TRY(potrf_rec(A, n1, lda, row_offset, d_info, dinv, s));
+  GSS_TRY(trsm_right_lt_f64(A21, n2, n1, lda, A, lda, nullptr, dinv, s));
   // A22 -= A21 * A21'   (lower tiles)
   GSS_TRY(gemm_f64(n2, n2, n1, -1.0, A21, 1, lda, A21, lda, 1, 1.0, A22, 1, lda, true, s));
-  GSS_TRY(potrf_rec(A22, n2, lda, row_offset + n1, d_info, scratch, s));
+  GSS_TRY(potrf_rec(A22, n2, lda, row_offset + n1, d_info, dinv + (n1 / LEAF) * LEAF * LEAF, s));
   return GSS_OK;
 }
 
-int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, hipStream_t s) {
-  DevBuf scratch;
-  GSS_TRY(scratch.alloc(sizeof(double) * LEAF * LEAF));
+int64_t potrf_dinv_doubles(int64_t n) { return ((n + LEAF - 1) / LEAF) * LEAF * LEAF; }
+
+// dinv: caller workspace of potrf_dinv_doubles(n) doubles receiving the inverses of the diagonal leaf blocks
+// (they are needed by the panel solves anyway); asynchronous on s, *d_info is zeroed first.
+int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s) {
   GSS_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
-  GSS_TRY(potrf_rec(A, n, lda, 0, d_info, scratch.as<double>(), s));
-  GSS_HIP(hipStreamSynchronize(s));  // scratch is freed on return
-  return GSS_OK;
+  return potrf_rec(A, n, lda, 0, d_info, dinv, s);
 }
 
 }  // namespace gss
@@ -316,11 +370,13 @@ extern "C" {
 int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream) {
   GSS_REQUIRE(a != nullptr && n >= 0 && lda >= n, "gss_dev_potrf: bad arguments");
   hipStream_t s = to_stream(stream);
-  DevBuf info;
+  DevBuf info, dinv;
   GSS_TRY(info.alloc(sizeof(int)));
-  GSS_TRY(potrf_f64(a, n, lda, info.as<int>(), s));
+  GSS_TRY(dinv.alloc(sizeof(double) * (size_t)potrf_dinv_doubles(n)));
+  GSS_TRY(potrf_f64(a, n, lda, info.as<int>(), dinv.as<double>(), s));
   int h = 0;
-  GSS_HIP(hipMemcpy(&h, info.p, sizeof(int), hipMemcpyDeviceToHost));
+  GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
   if (h != 0) {
     set_error("Cholesky failed: non-positive pivot at row %d", h - 1);
     return GSS_ERR_NOT_POSDEF;
@@ -335,7 +391,7 @@ int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_
   const int64_t h = n / 2 + LEAF;
   GSS_TRY(T.alloc(sizeof(double) * (size_t)(h * h)));
   GSS_HIP(hipMemset2DAsync(w, sizeof(double) * ldw, 0, sizeof(double) * n, n, s));
-  GSS_TRY(trtri_f64(l, n, ldl, w, ldw, T.as<double>(), s));
+  GSS_TRY(trtri_f64(l, n, ldl, w, ldw, T.as<double>(), nullptr, s));
   GSS_HIP(hipStreamSynchronize(s));
   return GSS_OK;
 }

@@ -177,17 +177,22 @@ __device__ __forceinline__ double cov_from_d2(const VgDev& v, double d2) {
 int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
                  const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
                  int64_t sd_j, bool lower_only, hipStream_t s);
-// y = op(A) x for column-major A (m x n, lda); trans: y = A' x.  Optional sign flip of rows >= flip_from.
+// y = op(A) x for column-major A (m x n, lda); trans: y = A' x.  work: gemv_work_doubles(trans, m, n) doubles.
+int64_t gemv_work_doubles(bool trans, int64_t m, int64_t n);
 int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda, const double* x, double* y,
-                 hipStream_t s);
-// in-place Cholesky of the lower triangle (column-major); *d_info (device int) set to 1+row on failure
-int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, hipStream_t s);
+                 double* work, hipStream_t s);
+// in-place Cholesky of the lower triangle (column-major); *d_info (device int) set to 1+row on failure.
+// dinv: workspace of potrf_dinv_doubles(n) doubles that receives inv() of every 64 x 64 diagonal leaf block.
+// Asynchronous on s.
+int64_t potrf_dinv_doubles(int64_t n);
+int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s);
 // W = inv(L), lower, column-major; W's strict upper triangle must be zero on entry; T is scratch of
-// at least (n/2+64)^2 doubles
-int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, hipStream_t s);
-// X <- X * inv(L)' (X is m x n column-major); scratch >= 64*64 doubles
+// at least (n/2+64)^2 doubles; dinv (nullable) = cached leaf inverses from potrf_f64
+int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, const double* dinv,
+                  hipStream_t s);
+// X <- X * inv(L)' (X is m x n column-major); scratch >= 64*64 doubles (unused when dinv is given)
 int32_t trsm_right_lt_f64(double* X, int64_t m, int64_t n, int64_t ldx, const double* L, int64_t ldl,
-                          double* scratch, hipStream_t s);
+                          double* scratch, const double* dinv, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // covariance assembly (cov_kernels.hip)

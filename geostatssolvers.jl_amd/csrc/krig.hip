@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* _
 // contributes.  Global -> register -> LDS staging is double buffered: one barrier per BK stage.
 constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 
+template <bool B4>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
     int64_t ldr, const double* __restrict__ mean_part, int nparts, double sill, double mean0, int64_t m_valid,
@@ -133,7 +134,15 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const int ntile = kend / BK;
 
     d4 acc[4][4];
-    zero_acc(acc);
+    double acc4[16][4];
+    if (B4) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc4[u][v] = 0.0;
+    } else {
+      zero_acc(acc);
+    }
 
     d2v ra[4], rb[4];
     const double* wp = W + (int64_t)kq * ldw + i0 + i2;
@@ -163,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
           rb[r] = *reinterpret_cast<const d2v*>(rq + (int64_t)(4 * r) * ldr);
         }
       }
-      mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+      if (B4) mma_stage_b4(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc4, wm, wn, lane);
+      else mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
       if (more) {
         double* an = As + (cur ^ 1) * TILE_LDS;
         double* bn = Bs + (cur ^ 1) * TILE_LDS;
@@ -180,15 +190,25 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       double s = 0.0;
+      if (B4) {
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i0 + wm * 64 + tm * 16 + lk + 4 * r;
-          const double v = acc[tm][tn][r];
+        for (int u = 0; u < 16; ++u) {
+          const int row = i0 + wm * 64 + 4 * u + lk;
+          const double v = acc4[u][tn];
           const double vv = v * v;
           s += (row < n) ? vv : -vv;
         }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i0 + wm * 64 + tm * 16 + lk + 4 * r;
+            const double v = acc[tm][tn][r];
+            const double vv = v * v;
+            s += (row < n) ? vv : -vv;
+          }
+      }
       qacc[tn] += s;
     }
   }
@@ -260,9 +280,6 @@ struct gss_krig {
   DevBuf xdata, z, drift_data;
   DevBuf factor;  // W' (ldw x N1pad, column-major) followed by wd (N1pad)
   bool factored = false;
-  // prediction workspace
-  DevBuf R, mean_part;
-  int64_t mc = 0, ldr = 0;
   double* Wp() const { return factor.as<double>(); }
   double* wd() const { return factor.as<double>() + ldw * N1pad; }
 };
@@ -298,6 +315,49 @@ static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
   }
 }
 
+// Points per chunk of the RHS workspace R (N1pad x mc doubles).  A K3 launch runs mc / 128 workgroups on 512
+// resident slots (2 per CU), so small chunks lose up to one slot-round to the tail: the budget defaults to
+// min(16 GiB, half of the free HBM) -- 10^6 points at n = 1000 are one launch -- and, when the domain must be
+// split, chunks are multiples of 512 * 128 points.  GSS_KRIG_WS_MB overrides the budget.
+static int64_t krig_chunk_points(int64_t N1pad, int64_t m) {
+  size_t ws = (size_t)16 << 30;
+  size_t freeb = 0, totalb = 0;
+  if (hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb / 2 < ws) ws = freeb / 2;
+  if (const char* e = std::getenv("GSS_KRIG_WS_MB")) {
+    const long v = std::atol(e);
+    if (v > 0) ws = (size_t)v << 20;
+  }
+  int64_t cap = (int64_t)(ws / (sizeof(double) * (size_t)N1pad));
+  const int64_t round = 512 * 128;
+  cap = cap >= round ? cap / round * round : cap / 256 * 256;
+  if (cap < 256) cap = 256;
+  return round_up(m, 256) < cap ? round_up(m, 256) : cap;
+}
+
+// Prediction workspace (RHS tiles + mean partials), shared by all handles of the process and grown on
+// demand: handles are short-lived (one per solve) while the workspace is GiB-sized, and one process
+// drives one GPU with non-thread-safe handles, so a process-wide cache is safe.
+struct KrigWorkspace {
+  DevBuf R, mean_part;
+  int64_t doubles = 0, mc = 0;
+};
+static KrigWorkspace g_ws;
+
+static int32_t krig_workspace(int64_t N1pad, int64_t mc, hipStream_t s, double** R, double** mean_part) {
+  if (g_ws.doubles < N1pad * mc || g_ws.mc < mc) {
+    GSS_HIP(hipStreamSynchronize(s));
+    g_ws.R.release();
+    g_ws.mean_part.release();
+    GSS_TRY(g_ws.R.alloc(sizeof(double) * (size_t)(N1pad * mc)));
+    GSS_TRY(g_ws.mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
+    g_ws.doubles = N1pad * mc;
+    g_ws.mc = mc;
+  }
+  *R = g_ws.R.as<double>();
+  *mean_part = g_ws.mean_part.as<double>();
+  return GSS_OK;
+}
+
 static int32_t launch_drift_rows(const gss_krig* h, const double* x, const double* drift_vals, int64_t npts,
                                  int64_t ncols_pad, double* out, int64_t ld, int nrows, const double* wd,
                                  double* mean_part, hipStream_t s) {
@@ -320,79 +380,112 @@ static int32_t launch_drift_rows(const gss_krig* h, const double* x, const doubl
   return GSS_OK;
 }
 
+// small dense helpers for the constraint block (nc <= 64): one thread per output element
+__global__ void small_gram_kernel(const double* __restrict__ Bm, int nc, int64_t n, double* __restrict__ S, int lds) {
+  // S(c, c2) = Bm[c] . Bm[c2], one wave per entry of the lower triangle
+  const int c = blockIdx.x, c2 = blockIdx.y;
+  if (c2 > c) return;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 64) acc = fma(Bm[(int64_t)c * n + i], Bm[(int64_t)c2 * n + i], acc);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) {
+    S[c + c2 * lds] = acc;
+    S[c2 + c * lds] = acc;
+  }
+}
+
+// Wp[(n + i) + j * ldw] = -sum_c WS(i, c) T[c * n + j]   (WS = inv(L_S), lower, ld = ldws)
+__global__ void constraint_rows_kernel(const double* __restrict__ WS, int64_t ldws, const double* __restrict__ T,
+                                       int nc, int64_t n, double* __restrict__ Wp_rows, int64_t ldw) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  for (int i = 0; i < nc; ++i) {
+    double acc = 0.0;
+    for (int c = 0; c <= i; ++c) acc = fma(WS[i + c * ldws], T[(int64_t)c * n + j], acc);
+    Wp_rows[i + j * ldw] = -acc;
+  }
+}
+
+// Factorisation of the kriging system on the device (GeoStatsModels.fit, krig.jl:176).  One workspace
+// allocation, no host synchronisation until the final status read.
 static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
   const int64_t n = h->n, N1 = h->N1, N1pad = h->N1pad, ldw = h->ldw;
   const int nc = h->nc;
-  // M: working matrix (column-major, ld = ldw) whose top-left n x n receives C then L
-  DevBuf M, T, info, scratch;
-  GSS_TRY(M.alloc(sizeof(double) * (size_t)(ldw * N1pad)));
-  GSS_HIP(hipMemsetAsync(M.p, 0, M.bytes, s));
-  GSS_HIP(hipMemsetAsync(h->factor.p, 0, h->factor.bytes, s));
-  GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M.as<double>(), ldw, s));
-  GSS_TRY(info.alloc(sizeof(int)));
-  GSS_TRY(potrf_f64(M.as<double>(), n, ldw, info.as<int>(), s));
-  int hinfo = 0;
-  GSS_HIP(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (hinfo != 0) {
-    set_error("kriging covariance matrix is not positive definite (pivot %d of %lld); add a nugget or remove "
-              "duplicate samples", hinfo - 1, (long long)n);
-    return GSS_ERR_NOT_POSDEF;
-  }
   const int64_t hh = n / 2 + 64;
-  GSS_TRY(T.alloc(sizeof(double) * (size_t)(hh * hh > (int64_t)MAX_NC * n ? hh * hh : (int64_t)MAX_NC * n)));
+  const int64_t szM = ldw * N1pad;
+  const int64_t szT = hh * hh > (int64_t)MAX_NC * n ? hh * hh : (int64_t)MAX_NC * n;
+  const int64_t szDinv = potrf_dinv_doubles(n) + 64 * 64;
+  const int64_t szFd = (int64_t)MAX_NC * n, szBm = (int64_t)MAX_NC * n;
+  const int64_t szS = 2 * MAX_NC * MAX_NC + 64 * 64;
+  int64_t szGemv = gemv_work_doubles(false, ldw, ldw);
+  if (gemv_work_doubles(true, ldw, ldw) > szGemv) szGemv = gemv_work_doubles(true, ldw, ldw);
+  const int64_t szVec = 2 * ldw;
+  DevBuf ws;
+  GSS_TRY(ws.alloc(sizeof(double) * (size_t)(szM + szT + szDinv + szFd + szBm + szS + szGemv + szVec) + 64));
+  double* M = ws.as<double>();
+  double* T = M + szM;
+  double* Dinv = T + szT;
+  double* Fd = Dinv + szDinv;
+  double* Bm = Fd + szFd;
+  double* S = Bm + szBm;            // S (MAX_NC^2), then its leaf inverse scratch (64 x 64)
+  double* SDinv = S + MAX_NC * MAX_NC;
+  double* gwork = S + szS;
+  double* zz = gwork + szGemv;
+  double* u = zz + ldw;
+  int* info = reinterpret_cast<int*>(u + ldw);
+  int* info2 = info + 1;
+
+  GSS_HIP(hipMemsetAsync(M, 0, sizeof(double) * (size_t)szM, s));
+  GSS_HIP(hipMemsetAsync(h->factor.p, 0, h->factor.bytes, s));
+  GSS_HIP(hipMemsetAsync(info2, 0, sizeof(int), s));
+  GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M, ldw, s));
+  GSS_TRY(potrf_f64(M, n, ldw, info, Dinv, s));
   double* Wp = h->Wp();
-  GSS_TRY(trtri_f64(M.as<double>(), n, ldw, Wp, ldw, T.as<double>(), s));
+  GSS_TRY(trtri_f64(M, n, ldw, Wp, ldw, T, Dinv, s));
 
   if (nc > 0) {
-    DevBuf Fd, Bm, S, WS;
-    GSS_TRY(Fd.alloc(sizeof(double) * (size_t)(n * nc)));
-    GSS_TRY(Bm.alloc(sizeof(double) * (size_t)(n * nc)));
-    GSS_TRY(S.alloc(sizeof(double) * MAX_NC * MAX_NC));
-    GSS_TRY(WS.alloc(sizeof(double) * MAX_NC * MAX_NC));
-    GSS_HIP(hipMemsetAsync(S.p, 0, S.bytes, s));
-    GSS_HIP(hipMemsetAsync(WS.p, 0, WS.bytes, s));
+    GSS_HIP(hipMemsetAsync(S, 0, sizeof(double) * (size_t)szS, s));
     // Fd (n x nc, column-major): drift functions at the data locations
-    GSS_TRY(launch_drift_rows(h, h->xdata.as<double>(), h->drift_data.as<double>(), n, n, Fd.as<double>(), n, nc,
-                              nullptr, nullptr, s));
-    // Bm (nc x n row-major) = F' W'   i.e. Bm(c,i) = sum_k F(k,c) W(i,k)
-    GSS_TRY(gemm_f64(nc, n, n, 1.0, Fd.as<double>(), n, 1, Wp, ldw, 1, 0.0, Bm.as<double>(), n, 1, false, s));
-    // S (nc x nc, column-major ld = MAX_NC) = Bm Bm'
-    GSS_TRY(gemm_f64(nc, nc, n, 1.0, Bm.as<double>(), n, 1, Bm.as<double>(), 1, n, 0.0, S.as<double>(), 1, MAX_NC,
-                     false, s));
-    GSS_TRY(potrf_f64(S.as<double>(), nc, MAX_NC, info.as<int>(), s));
-    GSS_HIP(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (hinfo != 0) {
-      set_error("drift functions are linearly dependent on the sample locations (constraint %d)", hinfo - 1);
-      return GSS_ERR_NOT_POSDEF;
-    }
+    GSS_TRY(launch_drift_rows(h, h->xdata.as<double>(), h->drift_data.as<double>(), n, n, Fd, n, nc, nullptr,
+                              nullptr, s));
+    // Bm[c] = W F[:, c]   (row c of B = (L^-1 F)')
+    for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(false, n, n, Wp, ldw, Fd + (int64_t)c * n, Bm + (int64_t)c * n, gwork, s));
+    hipLaunchKernelGGL(small_gram_kernel, dim3(nc, nc), dim3(64), 0, s, Bm, nc, n, S, MAX_NC);
+    GSS_HIP(hipGetLastError());
+    GSS_TRY(potrf_f64(S, nc, MAX_NC, info2, SDinv, s));
     // W'[n:, n:] = inv(L_S)
-    GSS_TRY(trtri_f64(S.as<double>(), nc, MAX_NC, Wp + n + n * ldw, ldw, T.as<double>(), s));
-    // T (nc x n row-major) = Bm * W        T(c,j) = sum_k Bm(c,k) W(k,j)
-    GSS_TRY(gemm_f64(nc, n, n, 1.0, Bm.as<double>(), n, 1, Wp, 1, ldw, 0.0, T.as<double>(), n, 1, false, s));
+    GSS_TRY(trtri_f64(S, nc, MAX_NC, Wp + n + n * ldw, ldw, T, SDinv, s));
+    // T[c] = W' Bm[c]  (row c of B W)
+    for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(true, n, n, Wp, ldw, Bm + (int64_t)c * n, T + (int64_t)c * n, gwork, s));
     // W'[n:, 0:n] = -inv(L_S) * T
-    GSS_TRY(gemm_f64(nc, n, nc, -1.0, Wp + n + n * ldw, 1, ldw, T.as<double>(), n, 1, 0.0, Wp + n, 1, ldw, false,
-                     s));
-    GSS_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(constraint_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, SDinv, (int64_t)64, T,
+                       nc, n, Wp + n, ldw);
+    GSS_HIP(hipGetLastError());
   }
 
   // dual weights wd = W'' D W' [z - mean; 0]
-  DevBuf zz, u;
-  GSS_TRY(zz.alloc(sizeof(double) * (size_t)ldw));
-  GSS_TRY(u.alloc(sizeof(double) * (size_t)ldw));
-  GSS_HIP(hipMemsetAsync(zz.p, 0, zz.bytes, s));
-  GSS_HIP(hipMemcpyAsync(zz.p, h->z.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  GSS_HIP(hipMemsetAsync(zz, 0, sizeof(double) * (size_t)(2 * ldw), s));
+  GSS_HIP(hipMemcpyAsync(zz, h->z.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
   if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
-    hipLaunchKernelGGL(sub_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zz.as<double>(), n,
-                       h->sk_mean);
+    hipLaunchKernelGGL(sub_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zz, n, h->sk_mean);
   }
-  GSS_TRY(gemv_f64(false, N1, N1, Wp, ldw, zz.as<double>(), u.as<double>(), s));
-  if (nc > 0) {
-    hipLaunchKernelGGL(flip_tail_kernel, dim3(1), dim3(256), 0, s, u.as<double>(), n, N1);
-  }
-  GSS_TRY(gemv_f64(true, N1, N1, Wp, ldw, u.as<double>(), h->wd(), s));
+  GSS_TRY(gemv_f64(false, N1, N1, Wp, ldw, zz, u, gwork, s));
+  if (nc > 0) hipLaunchKernelGGL(flip_tail_kernel, dim3(1), dim3(256), 0, s, u, n, N1);
+  GSS_TRY(gemv_f64(true, N1, N1, Wp, ldw, u, h->wd(), gwork, s));
   GSS_HIP(hipGetLastError());
+  int hinfo[2] = {0, 0};
+  GSS_HIP(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
-  (void)N1pad;
+  if (hinfo[0] != 0) {
+    set_error("kriging covariance matrix is not positive definite (pivot %d of %lld); add a nugget or remove "
+              "duplicate samples", hinfo[0] - 1, (long long)n);
+    return GSS_ERR_NOT_POSDEF;
+  }
+  if (hinfo[1] != 0) {
+    set_error("drift functions are linearly dependent on the sample locations (constraint %d)", hinfo[1] - 1);
+    return GSS_ERR_NOT_POSDEF;
+  }
   h->factored = true;
   return GSS_OK;
 }
@@ -523,28 +616,20 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   const int dim = h->dim;
 
   static bool attr_set = false;
+  static int variant = 0;  // 0: v_mfma_f64_16x16x4 (default), 1: v_mfma_f64_4x4x4_4b (GSS_K3_VARIANT=1); same rate in situ
   if (!attr_set) {
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel),
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
+    if (const char* e = std::getenv("GSS_K3_VARIANT")) variant = std::atoi(e);
     attr_set = true;
   }
 
-  // chunk size from the workspace budget (default 1.5 GiB of RHS tiles; GSS_KRIG_WS_MB overrides)
-  size_t ws = (size_t)1536 << 20;
-  if (const char* e = std::getenv("GSS_KRIG_WS_MB")) {
-    const long v = std::atol(e);
-    if (v > 0) ws = (size_t)v << 20;
-  }
-  int64_t cap = (int64_t)(ws / (sizeof(double) * (size_t)h->N1pad)) / 256 * 256;
-  if (cap < 256) cap = 256;
-  const int64_t mc = round_up(m, 256) < cap ? round_up(m, 256) : cap;
-  if (h->mc < mc) {
-    GSS_HIP(hipStreamSynchronize(s));
-    GSS_TRY(h->R.alloc(sizeof(double) * (size_t)(h->N1pad * mc)));
-    GSS_TRY(h->mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
-    h->mc = mc;
-  }
-  const int64_t ldr = h->mc;
+  const int64_t mc = krig_chunk_points(h->N1pad, m);
+  double *Rws = nullptr, *mpart = nullptr;
+  GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
+  const int64_t ldr = mc;
   const int seg_len = (int)((h->n + NSEG - 1) / NSEG);
 
   Staged sx, sd, smean, svar, sstat;
@@ -565,32 +650,39 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
       switch (dim) {
       case 1:
         hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           mv, h->wd(), Rws, ldr, mpart, seg_len);
         break;
       case 2:
         hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           mv, h->wd(), Rws, ldr, mpart, seg_len);
         break;
       default:
         hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           mv, h->wd(), Rws, ldr, mpart, seg_len);
         break;
     }
     GSS_HIP(hipGetLastError());
     // drift rows n..N1-1 and zero rows up to N1pad, plus their share of the mean
     if (nrows > 0) {
       const double* dv = h->variant == GSS_KRIG_EXTDRIFT ? sd.as<double>() + off * h->ndrift : nullptr;
-      GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, h->R.as<double>() + h->n * ldr, ldr, nrows, h->wd() + h->n,
-                                h->mean_part.as<double>() + (int64_t)NSEG * ldr, s));
+      GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, Rws + h->n * ldr, ldr, nrows, h->wd() + h->n,
+                                mpart + (int64_t)NSEG * ldr, s));
     }
     }
     const int nparts = nrows > 0 ? NSEG + 1 : NSEG;
     ProfScope pq("krig_quadform", s);
-    hipLaunchKernelGGL(krig_quadform_kernel, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
-                       h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, h->R.as<double>(), ldr,
-                       h->mean_part.as<double>(), nparts, h->vg.sill,
-                       h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
-                       svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
+    if (variant == 1)
+      hipLaunchKernelGGL(krig_quadform_kernel<true>, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
+                         h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr,
+                         mpart, nparts, h->vg.sill,
+                         h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
+                         svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
+    else
+      hipLaunchKernelGGL(krig_quadform_kernel<false>, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
+                         h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr,
+                         mpart, nparts, h->vg.sill,
+                         h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
+                         svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
     GSS_HIP(hipGetLastError());
   }
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
@@ -675,17 +767,10 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
                    false, s));
   GSS_HIP(hipGetLastError());
 
-  size_t ws = (size_t)1536 << 20;
-  int64_t cap = (int64_t)(ws / (sizeof(double) * (size_t)h->N1pad)) / 256 * 256;
-  if (cap < 256) cap = 256;
-  const int64_t mc = round_up(m, 256) < cap ? round_up(m, 256) : cap;
-  if (h->mc < mc) {
-    GSS_HIP(hipStreamSynchronize(s));
-    GSS_TRY(h->R.alloc(sizeof(double) * (size_t)(h->N1pad * mc)));
-    GSS_TRY(h->mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
-    h->mc = mc;
-  }
-  const int64_t ldr = h->mc;
+  const int64_t mc = krig_chunk_points(h->N1pad, m);
+  double *Rws = nullptr, *mpart = nullptr;
+  GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
+  const int64_t ldr = mc;
   const int seg_len = (int)((n + NSEG - 1) / NSEG);
   for (int64_t off = 0; off < m; off += mc) {
     const int64_t mv = (m - off) < mc ? (m - off) : mc;
@@ -695,24 +780,24 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
     switch (dim) {
       case 1:
         hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           h->wd(), Rws, ldr, mpart, seg_len);
         break;
       case 2:
         hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           h->wd(), Rws, ldr, mpart, seg_len);
         break;
       default:
         hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), h->R.as<double>(), ldr, h->mean_part.as<double>(), seg_len);
+                           h->wd(), Rws, ldr, mpart, seg_len);
         break;
     }
     GSS_HIP(hipGetLastError());
     const int nrows = (int)(h->N1pad - n);
     if (nrows > 0)
-      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, h->R.as<double>() + n * ldr, ldr, nrows, h->wd() + n,
-                                h->mean_part.as<double>() + (int64_t)NSEG * ldr, s));
+      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, Rws + n * ldr, ldr, nrows, h->wd() + n,
+                                mpart + (int64_t)NSEG * ldr, s));
     // out(b, off + p) = sum_k WD(k, b) R(k, p)
-    GSS_TRY(gemm_f64(nbatch, mv, N1, 1.0, WD.as<double>(), ldw, 1, h->R.as<double>(), ldr, 1, 0.0,
+    GSS_TRY(gemm_f64(nbatch, mv, N1, 1.0, WD.as<double>(), ldw, 1, Rws, ldr, 1, 0.0,
                      so.as<double>() + off, m, 1, false, s));
   }
   if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {

@@ -70,9 +70,10 @@ struct gss_lugs {
   double* d2() const { return state.as<double>() + ns * ns; }
 };
 
-static int32_t check_info(DevBuf& info, const char* what) {
+static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   int h = 0;
-  GSS_HIP(hipMemcpy(&h, info.p, sizeof(int), hipMemcpyDeviceToHost));
+  GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
   if (h != 0) {
     set_error("%s is not positive definite (pivot %d); add a nugget or remove duplicate locations", what, h - 1);
     return GSS_ERR_NOT_POSDEF;
@@ -142,27 +143,30 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
     double* C22 = h->L22();
     GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
     if (nd > 0) {
-      DevBuf C11, A21, w, scratch;
+      DevBuf C11, A21, w, dinv, gwork;
       GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
       GSS_TRY(A21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));
-      GSS_TRY(scratch.alloc(sizeof(double) * 64 * 64));
+      GSS_TRY(dinv.alloc(sizeof(double) * (size_t)potrf_dinv_doubles(nd)));
+      GSS_TRY(gwork.alloc(sizeof(double) * (size_t)gemv_work_doubles(false, ns, nd)));
       GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxd.as<double>(), nd, C11.as<double>(), nd, s));  // :131
       // row-major nd x ns == column-major ns x nd: A21 <- C21                                             // :132
       GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, A21.as<double>(), ns, s));
-      GSS_TRY(potrf_f64(C11.as<double>(), nd, nd, info.as<int>(), s));                                      // :134
-      GSS_TRY(check_info(info, "data covariance C11"));
-      GSS_TRY(trsm_right_lt_f64(A21.as<double>(), ns, nd, ns, C11.as<double>(), nd, scratch.as<double>(), s));  // :135
+      GSS_TRY(potrf_f64(C11.as<double>(), nd, nd, info.as<int>(), dinv.as<double>(), s));                  // :134
+      GSS_TRY(check_info(info, "data covariance C11", s));
+      GSS_TRY(trsm_right_lt_f64(A21.as<double>(), ns, nd, ns, C11.as<double>(), nd, nullptr, dinv.as<double>(), s));  // :135
       // w' = z1' * inv(L11)'  i.e. w = L11 \ z1                                                           // :138
       GSS_HIP(hipMemcpyAsync(w.p, h->z1.p, sizeof(double) * (size_t)nd, hipMemcpyDeviceToDevice, s));
-      GSS_TRY(trsm_right_lt_f64(w.as<double>(), 1, nd, 1, C11.as<double>(), nd, scratch.as<double>(), s));
-      GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), s));                   // :138
+      GSS_TRY(trsm_right_lt_f64(w.as<double>(), 1, nd, 1, C11.as<double>(), nd, nullptr, dinv.as<double>(), s));
+      GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), gwork.as<double>(), s));  // :138
       // C22 -= A21 * A21'  (lower tiles)                                                                  // :139
       GSS_TRY(gemm_f64(ns, ns, nd, -1.0, A21.as<double>(), 1, ns, A21.as<double>(), ns, 1, 1.0, C22, 1, ns, true, s));
       GSS_HIP(hipStreamSynchronize(s));
     }
-    GSS_TRY(potrf_f64(C22, ns, ns, info.as<int>(), s));                                                     // :128/:139
-    GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22"));
+    DevBuf dinv22;
+    GSS_TRY(dinv22.alloc(sizeof(double) * (size_t)potrf_dinv_doubles(ns)));
+    GSS_TRY(potrf_f64(C22, ns, ns, info.as<int>(), dinv22.as<double>(), s));                                // :128/:139
+    GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22", s));
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)ns), dim3(256), 0, s, C22, ns,
                        ns);
     GSS_HIP(hipGetLastError());

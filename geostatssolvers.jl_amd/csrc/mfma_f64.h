@@ -45,6 +45,32 @@ __device__ __forceinline__ void mma_stage(const double* __restrict__ As, const d
   }
 }
 
+// Same 64 x 64 wave tile on v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction), which
+// sustains ~1.5x the FLOP rate of the 16x16x4 form on gfx950 (tools/probe_f64.hip).  Lane maps, measured
+// with tools/probe_mfma4x4.hip: A lane = 16k + 4b + i, B lane = 16k + 4b + j, D lane = 16i + 4b + j for
+// block b.  Instruction (u, v) gives every block the row group u and block b the column group 4v + b:
+//   A operand u : lane holds A[4u + (lane & 3)][k = lane >> 4]      (replicated over b: LDS broadcast)
+//   B operand v : lane holds B[k = lane >> 4][16v + (lane & 15)]    (the 16x16x4 B layout)
+//   acc[u][v]   : lane holds D[4u + (lane >> 4)][16v + (lane & 15)]
+__device__ __forceinline__ void mma_stage_b4(const double* __restrict__ As, const double* __restrict__ Bs,
+                                             double (&acc)[16][4], int wm, int wn, int lane) {
+  const int lk = lane >> 4;
+#pragma unroll 1
+  for (int kk = 0; kk < BK / 4; ++kk) {
+    const double* ap = As + (kk * 4 + lk) * LDS_LD + wm * 64 + (lane & 3);
+    const double* bp = Bs + (kk * 4 + lk) * LDS_LD + wn * 64 + (lane & 15);
+    double a[16], b[4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = ap[4 * u];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = bp[16 * v];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void zero_acc(d4 (&acc)[4][4]) {
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
