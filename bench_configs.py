@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Measures the remaining BASELINE.json configs on ONE MI355X (per-GPU share of each config) and prints one JSON
+line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
+(configs[1]); this script feeds DESIGN.md section 5 and profiles/.
+
+    python bench_configs.py [--configs 2,3,4] [--quick]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP64_PEAK = 78.6
+HBM_PEAK = 8000.0
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def cfg2_fftgs(a, gss, _lib):
+    """configs[2]: FFTGS 512^3, exponential range 50, 256 realisations over 8 GPUs -> 32 per GPU."""
+    from gss.engine import FFTGSHandle
+    e = 256 if a.quick else 512
+    R = 8 if a.quick else 32
+    N = e ** 3
+    t0 = time.perf_counter()
+    f = FFTGSHandle(gss.ExponentialVariogram(range=50.0 * e / 512), (e, e, e))
+    sync()
+    t_pre = time.perf_counter() - t0
+    out = torch.empty((1, N), dtype=torch.float64, device="cuda")
+    f.realize(4, 0, 1, out=out)
+    sync()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for r in range(R):
+        f.realize(4, r, 1, out=out)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv")}
+    var = float((out[0] * out[0]).sum().item() / (N - 1))
+    # CPU baseline: oracle solvesingle (two C2C FFTs + temporaries like fft.jl:163-170) on a 256^3 grid
+    from oracle import fftgs as O, philox
+    from oracle.variogram import Variogram
+    ce = 128 if a.quick else 256
+    pre = O.preprocess(Variogram("exponential", range=50.0 * ce / 512), (ce, ce, ce))
+    u = philox.uniform(4, 0, ce ** 3)
+    t1 = time.perf_counter()
+    O.solvesingle(pre, u)
+    cdt = time.perf_counter() - t1
+    return {"config": "configs[2] FFTGS %d^3 exponential, %d realisations on this GPU" % (e, R),
+            "metric": "realisations/s", "value": round(R / dt, 2), "preprocess_s": round(t_pre, 3),
+            "roofline": {"bound": "hbm", "achieved": round(32.0 * N * R / dt / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": round(32.0 * N * R / dt / 1e9 / HBM_PEAK, 4)},
+            "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items()}, "sample_variance": var,
+            "cpu_baseline": {"value": round(1.0 / cdt * (ce / e) ** 3, 4), "unit": "realisations/s", "cores": 1,
+                             "kind": "port", "sample": "oracle.fftgs.solvesingle (numpy pocketfft C2C as fft.jl:163-166) on "
+                             "%d^3 in %.1f s, scaled by cell count to %d^3" % (ce, cdt, e)}}
+
+
+def cfg3_lugs(a, gss, _lib):
+    """configs[3]: LUGS, 128x128 grid, 4 096 conditioning cells, spherical range 20, 100 realisations."""
+    from gss.engine import LUGSHandle
+    from oracle import fftgs as O
+    g = 64 if a.quick else 128
+    nd = g * g // 4
+    cent = O.grid_centroids((g, g))
+    N = g * g
+    dlocs = np.sort(np.random.default_rng(5).permutation(N)[:nd])
+    z1 = np.random.default_rng(50).normal(size=nd)
+    vg = gss.SphericalVariogram(range=20.0)
+    t0 = time.perf_counter()
+    h = LUGSHandle(vg, cent, dlocs, z1)
+    sync()
+    t_pre = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h2 = LUGSHandle(vg, cent, dlocs, z1)
+    sync()
+    t_pre2 = time.perf_counter() - t0
+    ns = N - nd
+    flops = nd ** 3 / 3 + nd * nd * ns + nd * ns * ns + ns ** 3 / 3
+    R = 100
+    h.realize(5, 0, R, device=True)
+    sync()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    y, _ = h.realize(5, 0, R, device=True)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    gm = _lib.profile_read("lugs_gemm")
+    ok = bool(torch.equal(y[:, torch.as_tensor(dlocs, device="cuda")][0], torch.as_tensor(z1, device="cuda")))
+    # CPU baseline: oracle preprocess (LAPACK, threaded) at the same size
+    from oracle import lugs as OL
+    from oracle.variogram import Variogram
+    t1 = time.perf_counter()
+    OL.preprocess(Variogram("spherical", range=20.0), cent, cent[dlocs], z1)
+    cdt = time.perf_counter() - t1
+    return {"config": "configs[3] LUGS %dx%d grid, %d conditioning cells, ns=%d, spherical range 20, %d realisations" % (g, g, nd, ns, R),
+            "metric": "preprocess seconds / realisations per s", "preprocess_s": round(min(t_pre, t_pre2), 4),
+            "value": round(R / dt, 1), "unit": "realisations/s",
+            "roofline": {"bound": "mfma", "stage": "preprocess (potrf+trsm+syrk+potrf)", "achieved": round(flops / min(t_pre, t_pre2) / 1e12, 3),
+                         "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": round(flops / min(t_pre, t_pre2) / 1e12 / FP64_PEAK, 4)},
+            "realize_gemm_ms": round(gm[0] / max(gm[1], 1), 3), "hard_data_honoured": ok,
+            "cpu_baseline": {"value": round(cdt, 3), "unit": "preprocess seconds", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "oracle.lugs.preprocess (numpy/scipy LAPACK, threaded BLAS) same size"}}
+
+
+def cfg4_local(a, gss, _lib):
+    """configs[4]: UK degree 1, 5 000 3-D data, k = 64, Matern-3/2; 10^7 points over 8 GPUs -> 1.25e6 per GPU."""
+    from gss.engine import KrigHandle, UK
+    n = 5000
+    m = 100_000 if a.quick else 1_250_000
+    x = np.random.default_rng(6).uniform(0, 100, (n, 3))
+    z = 1.0 + 0.03 * x[:, 0] - 0.02 * x[:, 1] + 0.01 * x[:, 2] + np.random.default_rng(60).normal(size=n)
+    x0 = np.random.default_rng(7).uniform(0, 100, (m, 3))
+    x0d = torch.as_tensor(x0, device="cuda")
+    h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), UK, x, z, degree=1, factor=False)
+    h.predict_knn(x0d[:50000], 64)
+    sync()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    mu, var, st = h.predict_knn(x0d, 64)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    knn = _lib.profile_read("knn")
+    loc = _lib.profile_read("krig_local")
+    flop_pt = 68 ** 3 / 3 + 2 * 68 ** 2 + 8 * n
+    from oracle import kriging as K
+    from oracle.variogram import Variogram
+    ns = 300
+    t1 = time.perf_counter()
+    rmu, rvar, _ = K.approxsolve(K.UK, Variogram("matern", range=30.0, nu=1.5), x, z, x0[:ns], 64, degree=1)
+    cdt = time.perf_counter() - t1
+    err = float(np.max(np.abs(mu[:ns].cpu().numpy() - rmu)))
+    return {"config": "configs[4] UK degree 1, 5000 3-D data, k=64, Matern-3/2, %d points on this GPU" % m,
+            "metric": "kriged points/s", "value": round(m / dt, 1), "unit": "points/s",
+            "roofline": {"bound": "fp64-valu", "achieved": round(flop_pt * m / dt / 1e12, 3), "peak": FP64_PEAK, "unit": "TFLOP/s",
+                         "frac": round(flop_pt * m / dt / 1e12 / FP64_PEAK, 4)},
+            "kernel_ms": {"knn": round(knn[0], 2), "krig_local": round(loc[0], 2)}, "missing": int(st.sum().item()),
+            "parity_max_abs_err_first_%d" % ns: err,
+            "cpu_baseline": {"value": round(ns / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                             "sample": "oracle.kriging.approxsolve (search + fit + predict per point as krig.jl:205-228), %d points in %.1f s" % (ns, cdt)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="2,3,4")
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    torch.cuda.set_device(0)
+    import gss
+    from gss import _lib
+    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local}
+    for c in a.configs.split(","):
+        print(json.dumps(fns[c](a, gss, _lib)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -26,10 +26,15 @@ struct GemmArgs {
   int lower_only;
 };
 
+constexpr size_t GEMM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
+
+// Register-staged, LDS double-buffered pipeline (one barrier per BK stage), bounds-checked scalar loads that
+// are coalesced along whichever index is contiguous.
 template <bool A_ICONTIG, bool B_JCONTIG>
-__global__ __launch_bounds__(256) void gemm_f64_generic_kernel(GemmArgs g) {
-  __shared__ double As[TILE_LDS];
-  __shared__ double Bs[TILE_LDS];
+__global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                 // [2][TILE_LDS]
+  double* Bs = smem + 2 * TILE_LDS;  // [2][TILE_LDS]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -38,42 +43,59 @@ __global__ __launch_bounds__(256) void gemm_f64_generic_kernel(GemmArgs g) {
   const int64_t j0 = (int64_t)blockIdx.x * BN;
   if (g.lower_only && j0 > i0 + BM - 1) return;
 
+  // staging map of this thread: 8 elements of each operand tile per stage
+  int ai[8], ak[8], bj[8], bk[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (A_ICONTIG) {
+      ai[r] = tid & 127;
+      ak[r] = (tid >> 7) + 2 * r;
+    } else {
+      ak[r] = tid & 15;
+      ai[r] = (tid >> 4) + 16 * r;
+    }
+    if (B_JCONTIG) {
+      bj[r] = tid & 127;
+      bk[r] = (tid >> 7) + 2 * r;
+    } else {
+      bk[r] = tid & 15;
+      bj[r] = (tid >> 4) + 16 * r;
+    }
+  }
+  double ra[8], rb[8];
+  auto load_stage = [&](int64_t k0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t gi = i0 + ai[r], gka = k0 + ak[r];
+      ra[r] = (gi < g.M && gka < g.K) ? g.A[gi * g.sa_i + gka * g.sa_k] : 0.0;
+      const int64_t gj = j0 + bj[r], gkb = k0 + bk[r];
+      rb[r] = (gj < g.N && gkb < g.K) ? g.B[gkb * g.sb_k + gj * g.sb_j] : 0.0;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    double* a = As + buf * TILE_LDS;
+    double* b = Bs + buf * TILE_LDS;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      a[ak[r] * LDS_LD + ai[r]] = ra[r];
+      b[bk[r] * LDS_LD + bj[r]] = rb[r];
+    }
+  };
+
   d4 acc[4][4];
   zero_acc(acc);
-
-  for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int i, k;
-      if (A_ICONTIG) {
-        i = tid & 127;
-        k = (tid >> 7) + 2 * r;
-      } else {
-        k = tid & 15;
-        i = (tid >> 4) + 16 * r;
-      }
-      const int64_t gi = i0 + i, gk = k0 + k;
-      double v = 0.0;
-      if (gi < g.M && gk < g.K) v = g.A[gi * g.sa_i + gk * g.sa_k];
-      As[k * LDS_LD + i] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int j, k;
-      if (B_JCONTIG) {
-        j = tid & 127;
-        k = (tid >> 7) + 2 * r;
-      } else {
-        k = tid & 15;
-        j = (tid >> 4) + 16 * r;
-      }
-      const int64_t gj = j0 + j, gk = k0 + k;
-      double v = 0.0;
-      if (gj < g.N && gk < g.K) v = g.B[gk * g.sb_k + gj * g.sb_j];
-      Bs[k * LDS_LD + j] = v;
-    }
-    __syncthreads();
-    mma_stage(As, Bs, acc, wm, wn, lane);
+  const int64_t ntile = (g.K + BK - 1) / BK;
+  if (ntile > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int64_t t = 0; t < ntile; ++t) {
+    const int cur = (int)(t & 1);
+    const bool more = (t + 1) < ntile;
+    if (more) load_stage((t + 1) * BK);
+    mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+    if (more) store_stage(cur ^ 1);
     __syncthreads();
   }
 
@@ -95,6 +117,19 @@ __global__ __launch_bounds__(256) void gemm_f64_generic_kernel(GemmArgs g) {
       }
 }
 
+template <bool AI, bool BJ>
+static int32_t gemm_launch(const GemmArgs& g, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_generic_kernel<AI, BJ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_generic_kernel<AI, BJ>), grid, dim3(256), GEMM_LDS_BYTES, s, g);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
 int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
                  const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
                  int64_t sd_j, bool lower_only, hipStream_t s) {
@@ -103,16 +138,10 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM));
   const bool ai = (sa_i == 1) || (sa_k != 1);
   const bool bj = (sb_j == 1) || (sb_k != 1);
-  if (ai && bj)
-    hipLaunchKernelGGL((gemm_f64_generic_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (ai && !bj)
-    hipLaunchKernelGGL((gemm_f64_generic_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (!ai && bj)
-    hipLaunchKernelGGL((gemm_f64_generic_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_f64_generic_kernel<false, false>), grid, dim3(256), 0, s, g);
-  GSS_HIP(hipGetLastError());
-  return GSS_OK;
+  if (ai && bj) return gemm_launch<true, true>(g, grid, s);
+  if (ai && !bj) return gemm_launch<true, false>(g, grid, s);
+  if (!ai && bj) return gemm_launch<false, true>(g, grid, s);
+  return gemm_launch<false, false>(g, grid, s);
 }
 
 // ---------------------------------------------------------------------------------------------
