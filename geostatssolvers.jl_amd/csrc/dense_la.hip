@@ -231,48 +231,61 @@ __device__ __forceinline__ void leaf_invert(const double* S, double* X, int n, i
   __syncthreads();
 }
 
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // In-place Cholesky of the lower triangle of A (n <= 64) and, when dinv != nullptr, inv(L) into dinv
-// (64 x 64 column-major, ld = 64, zero padded).  Left-looking by columns: lane i owns row i.
+// (64 x 64 column-major, ld = 64, zero padded).  One wave, everything in registers: lane i owns row i of the
+// block (64 doubles), other rows' entries arrive by v_readlane broadcasts, the loops are fully unrolled so all
+// register indices are static.  A block with n < 64 is embedded in diag(A, I), whose factor and inverse are
+// diag(L, I) and diag(inv(L), I).
 __global__ __launch_bounds__(64) void potrf_inv_leaf_kernel(double* __restrict__ A, int n, int64_t lda,
                                                             int row_offset, int* __restrict__ info,
                                                             double* __restrict__ dinv) {
-  __shared__ double S[LEAF * LEAF_LD];  // S[i * LEAF_LD + j] = A(i, j)
-  __shared__ double X[LEAF * LEAF_LD];
   const int lane = threadIdx.x;
-  for (int idx = lane; idx < n * n; idx += 64) {
-    const int i = idx % n, j = idx / n;
-    S[i * LEAF_LD + j] = (j <= i) ? A[i + (int64_t)j * lda] : 0.0;
+  double row[LEAF];
+#pragma unroll
+  for (int c = 0; c < LEAF; ++c) {
+    double v = (c == lane) ? 1.0 : 0.0;
+    if (lane < n && c <= lane) v = A[lane + (int64_t)c * lda];
+    row[c] = v;
   }
-  __syncthreads();
-  const double* rowi = S + (lane < n ? lane : 0) * LEAF_LD;
-  for (int j = 0; j < n; ++j) {
-    const bool mine = lane >= j && lane < n;
-    double acc = 0.0;
-    if (mine) {
-      const double* rowj = S + j * LEAF_LD;
-      acc = rowi[j];
-      for (int c = 0; c < j; ++c) acc = fma(-rowi[c], rowj[c], acc);
-    }
-    double d = __shfl(acc, j);
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < LEAF; ++j) {
+    double acc = row[j];
+#pragma unroll
+    for (int c = 0; c < j; ++c) acc = fma(-row[c], bcast_lane(row[c], j), acc);
+    double d = bcast_lane(acc, j);
     if (!(d > 0.0)) {
-      if (lane == 0 && *info == 0) *info = row_offset + j + 1;
+      if (bad == 0) bad = row_offset + j + 1;
       d = 1.0;
     }
     const double sq = sqrt(d);
-    if (mine) S[lane * LEAF_LD + j] = (lane == j) ? sq : acc / sq;
-    __syncthreads();
+    row[j] = (lane == j) ? sq : acc / sq;  // lanes < j hold don't-care values in the upper triangle
+    __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later columns from being hoisted (SGPR pressure)
   }
-  for (int idx = lane; idx < n * n; idx += 64) {
-    const int i = idx % n, j = idx / n;
-    if (j <= i) A[i + (int64_t)j * lda] = S[i * LEAF_LD + j];
+  if (bad != 0 && lane == 0 && *info == 0) *info = bad;
+#pragma unroll
+  for (int c = 0; c < LEAF; ++c)
+    if (lane < n && c <= lane) A[lane + (int64_t)c * lda] = row[c];
+  if (!dinv) return;
+  // inverse: lane c owns column c of W = inv(L); x[i] = W(i, c)
+  double x[LEAF];
+#pragma unroll
+  for (int i = 0; i < LEAF; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc = fma(bcast_lane(row[k], i), x[k], acc);  // x[k] = 0 for k < lane
+    const double dii = bcast_lane(row[i], i);
+    x[i] = (i == lane) ? 1.0 / dii : (i > lane ? -acc / dii : 0.0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (dinv) {
-    leaf_invert(S, X, n, lane);
-    for (int idx = lane; idx < LEAF * LEAF; idx += 64) {
-      const int i = idx % LEAF, j = idx / LEAF;
-      dinv[idx] = (i < n && j <= i) ? X[j * LEAF_LD + i] : 0.0;
-    }
-  }
+#pragma unroll
+  for (int i = 0; i < LEAF; ++i) dinv[i + lane * LEAF] = (i < n && lane < n) ? x[i] : 0.0;
 }
 
 // W = inv(L) for one lower-triangular block (used when no cached inverse exists)

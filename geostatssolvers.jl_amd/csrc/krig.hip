@@ -105,11 +105,17 @@ __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* _
 // contributes.  Global -> register -> LDS staging is double buffered: one barrier per BK stage.
 constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 
-template <bool B4>
+// SPLIT: one workgroup per (strip, row block I) instead of one per strip.  Block ids are mapped so that the
+// row blocks of a strip run on ONE XCD at about the same time (ids b and b + 8 share an XCD): the strip's R
+// tile is then fetched from HBM once and re-read from that XCD's L2 / the Infinity Cache by the other row
+// blocks, instead of 4.6 times from HBM.  Partial column sums go to qpart[I][p]; krig_finish_kernel adds them
+// in fixed order.  Heavy row blocks (large I) are issued first.
+template <bool B4, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
     int64_t ldr, const double* __restrict__ mean_part, int nparts, double sill, double mean0, int64_t m_valid,
-    double* __restrict__ mean_out, double* __restrict__ var_out, uint8_t* __restrict__ status_out) {
+    double* __restrict__ mean_out, double* __restrict__ var_out, uint8_t* __restrict__ status_out,
+    double* __restrict__ qpart, int nstrips) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                 // [2][TILE_LDS]
   double* Bs = smem + 2 * TILE_LDS;  // [2][TILE_LDS]
@@ -119,16 +125,26 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int64_t p0 = (int64_t)blockIdx.x * BN;
+  const int nI = (N1 + BM - 1) / BM;
+  int64_t strip = blockIdx.x;
+  int Ibeg = 0, Iend = nI;
+  if (SPLIT) {
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    strip = (int64_t)(slot / nI) * 8 + xcd;
+    if (strip >= nstrips) return;
+    Ibeg = nI - 1 - (slot % nI);
+    Iend = Ibeg + 1;
+  }
+  const int64_t p0 = strip * BN;
 
   // staging map: thread moves 2 consecutive doubles of rows kq, kq+4, kq+8, kq+12 of each operand
   const int i2 = (tid & 63) * 2;
   const int kq = tid >> 6;
 
   double qacc[4] = {0.0, 0.0, 0.0, 0.0};
-  const int nI = (N1 + BM - 1) / BM;
 
-  for (int I = 0; I < nI; ++I) {
+  for (int I = Ibeg; I < Iend; ++I) {
     const int i0 = I * BM;
     const int kend = (i0 + BM < N1pad) ? i0 + BM : N1pad;
     const int ntile = kend / BK;
@@ -226,6 +242,10 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     for (int tn = 0; tn < 4; ++tn) red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
   }
   __syncthreads();
+  if (SPLIT) {
+    if (tid < BN) qpart[(int64_t)Ibeg * ldr + p0 + tid] = red[tid] + red[BN + tid];
+    return;
+  }
   if (tid < BN) {
     const int64_t p = p0 + tid;
     if (p < m_valid) {
@@ -238,6 +258,24 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
       if (status_out) status_out[p] = GSS_PT_OK;
     }
   }
+}
+
+// mean / variance from the per-row-block partial sums of the SPLIT quadratic form (fixed summation order)
+__global__ __launch_bounds__(256) void krig_finish_kernel(const double* __restrict__ qpart, int nI,
+                                                          const double* __restrict__ mean_part, int nparts,
+                                                          int64_t ldr, double sill, double mean0, int64_t m_valid,
+                                                          double* __restrict__ mean_out, double* __restrict__ var_out,
+                                                          uint8_t* __restrict__ status_out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= m_valid) return;
+  double q = 0.0;
+  for (int I = 0; I < nI; ++I) q += qpart[(int64_t)I * ldr + p];
+  double mu = mean0;
+  for (int s = 0; s < nparts; ++s) mu += mean_part[(int64_t)s * ldr + p];
+  const double v = sill - q;
+  mean_out[p] = mu;
+  var_out[p] = v > 0.0 ? v : 0.0;
+  if (status_out) status_out[p] = GSS_PT_OK;
 }
 
 __global__ void flip_tail_kernel(double* u, int64_t from, int64_t to) {
@@ -339,19 +377,21 @@ static int64_t krig_chunk_points(int64_t N1pad, int64_t m) {
 // drives one GPU with non-thread-safe handles, so a process-wide cache is safe.
 struct KrigWorkspace {
   DevBuf R, mean_part;
-  int64_t doubles = 0, mc = 0;
+  int64_t doubles = 0, mc = 0, nI = 0;
 };
 static KrigWorkspace g_ws;
 
 static int32_t krig_workspace(int64_t N1pad, int64_t mc, hipStream_t s, double** R, double** mean_part) {
-  if (g_ws.doubles < N1pad * mc || g_ws.mc < mc) {
+  const int64_t nI = (N1pad + BM - 1) / BM + 1;
+  if (g_ws.doubles < N1pad * mc || g_ws.mc < mc || g_ws.nI < nI) {
     GSS_HIP(hipStreamSynchronize(s));
     g_ws.R.release();
     g_ws.mean_part.release();
     GSS_TRY(g_ws.R.alloc(sizeof(double) * (size_t)(N1pad * mc)));
-    GSS_TRY(g_ws.mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1) * mc)));
+    GSS_TRY(g_ws.mean_part.alloc(sizeof(double) * (size_t)((NSEG + 1 + nI) * mc)));  // + qpart[nI][mc]
     g_ws.doubles = N1pad * mc;
     g_ws.mc = mc;
+    g_ws.nI = nI;
   }
   *R = g_ws.R.as<double>();
   *mean_part = g_ws.mean_part.as<double>();
@@ -616,13 +656,19 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   const int dim = h->dim;
 
   static bool attr_set = false;
+  static int split = 0;    // 0: one workgroup per strip (default); 1: per (strip, row block), XCD-aware ids -- measured 24 % slower
   static int variant = 0;  // 0: v_mfma_f64_16x16x4 (default), 1: v_mfma_f64_4x4x4_4b (GSS_K3_VARIANT=1); same rate in situ
   if (!attr_set) {
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false>),
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true>),
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
     if (const char* e = std::getenv("GSS_K3_VARIANT")) variant = std::atoi(e);
+    if (const char* e = std::getenv("GSS_K3_SPLIT")) split = std::atoi(e);
     attr_set = true;
   }
 
@@ -671,18 +717,32 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
     }
     const int nparts = nrows > 0 ? NSEG + 1 : NSEG;
     ProfScope pq("krig_quadform", s);
-    if (variant == 1)
-      hipLaunchKernelGGL(krig_quadform_kernel<true>, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
-                         h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr,
-                         mpart, nparts, h->vg.sill,
-                         h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
-                         svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
-    else
-      hipLaunchKernelGGL(krig_quadform_kernel<false>, dim3((unsigned)(cols / BN)), dim3(256), QUADFORM_LDS_BYTES, s,
-                         h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr,
-                         mpart, nparts, h->vg.sill,
-                         h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0, mv, smean.as<double>() + off,
-                         svar.as<double>() + off, status ? sstat.as<uint8_t>() + off : nullptr);
+    {
+      const int nstrips = (int)(cols / BN);
+      const int nI = (int)((h->N1 + BM - 1) / BM);
+      double* qpart = mpart + (int64_t)(NSEG + 1) * ldr;
+      const double mean0 = h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0;
+      uint8_t* stp = status ? sstat.as<uint8_t>() + off : nullptr;
+#define GSS_K3_ARGS h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, mpart, nparts, h->vg.sill, mean0, mv, \
+                    smean.as<double>() + off, svar.as<double>() + off, stp, qpart, nstrips
+      if (split) {
+        const unsigned grid = (unsigned)(8 * ((nstrips + 7) / 8) * nI);
+        if (variant == 1)
+          hipLaunchKernelGGL((krig_quadform_kernel<true, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s, GSS_K3_ARGS);
+        else
+          hipLaunchKernelGGL((krig_quadform_kernel<false, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s, GSS_K3_ARGS);
+        hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv + 255) / 256)), dim3(256), 0, s, qpart, nI, mpart, nparts,
+                           ldr, h->vg.sill, mean0, mv, smean.as<double>() + off, svar.as<double>() + off, stp);
+      } else {
+        if (variant == 1)
+          hipLaunchKernelGGL((krig_quadform_kernel<true, false>), dim3((unsigned)nstrips), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS);
+        else
+          hipLaunchKernelGGL((krig_quadform_kernel<false, false>), dim3((unsigned)nstrips), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS);
+      }
+#undef GSS_K3_ARGS
+    }
     GSS_HIP(hipGetLastError());
   }
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
