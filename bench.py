@@ -145,7 +145,10 @@ def main():
         rmu, rvar = K.exactsolve(K.OK, ovg, x, z, x0[sel])
         err = max(float(np.max(np.abs(mu[sel].cpu().numpy() - rmu))), float(np.max(np.abs(var[sel].cpu().numpy() - rvar))))
         line["parity_max_abs_err_64pts"] = err
-        assert err < 1e-8 and int(st.sum().item()) == 0, f"parity check failed: {err}"
+        if not os.environ.get("GSS_BENCH_EXPERIMENT"):   # set only for deliberately-wrong timing experiments
+            assert err < 1e-8 and int(st.sum().item()) == 0, f"parity check failed: {err}"
+        else:
+            line["EXPERIMENT_RESULTS_INVALID"] = True
 
         if world == 1 and not a.no_cpu_baseline:
             from oracle import cbind

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace gss {
@@ -110,12 +111,12 @@ constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 // tile is then fetched from HBM once and re-read from that XCD's L2 / the Infinity Cache by the other row
 // blocks, instead of 4.6 times from HBM.  Partial column sums go to qpart[I][p]; krig_finish_kernel adds them
 // in fixed order.  Heavy row blocks (large I) are issued first.
-template <bool B4, bool SPLIT>
+template <bool W14, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
     int64_t ldr, const double* __restrict__ mean_part, int nparts, double sill, double mean0, int64_t m_valid,
     double* __restrict__ mean_out, double* __restrict__ var_out, uint8_t* __restrict__ status_out,
-    double* __restrict__ qpart, int nstrips) {
+    double* __restrict__ qpart, int strip0, int nstrips) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                 // [2][TILE_LDS]
   double* Bs = smem + 2 * TILE_LDS;  // [2][TILE_LDS]
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
   const int nI = (N1 + BM - 1) / BM;
-  int64_t strip = blockIdx.x;
+  int64_t strip = blockIdx.x;  // strips strip0 .. strip0 + nstrips - 1 belong to this launch
   int Ibeg = 0, Iend = nI;
   if (SPLIT) {
     const int xcd = blockIdx.x & 7;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     Ibeg = nI - 1 - (slot % nI);
     Iend = Ibeg + 1;
   }
-  const int64_t p0 = strip * BN;
+  const int64_t p0 = (strip0 + strip) * BN;
 
   // staging map: thread moves 2 consecutive doubles of rows kq, kq+4, kq+8, kq+12 of each operand
   const int i2 = (tid & 63) * 2;
@@ -150,12 +151,10 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const int ntile = kend / BK;
 
     d4 acc[4][4];
-    double acc4[16][4];
-    if (B4) {
+    d4 accw[8][2];
+    if (W14) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc4[u][v] = 0.0;
+      for (int tm = 0; tm < 8; ++tm) accw[tm][0] = accw[tm][1] = d4{0.0, 0.0, 0.0, 0.0};
     } else {
       zero_acc(acc);
     }
@@ -176,7 +175,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     }
     __syncthreads();
 
-    for (int t = 0; t < ntile; ++t) {
+    auto stage = [&](int t, auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
       const int cur = t & 1;
       const bool more = (t + 1) < ntile;
       if (more) {
@@ -188,8 +188,12 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
           rb[r] = *reinterpret_cast<const d2v*>(rq + (int64_t)(4 * r) * ldr);
         }
       }
-      if (B4) mma_stage_b4(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc4, wm, wn, lane);
-      else mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+      if (W14) {
+        // stages inside the diagonal block (k > i0) only touch row tiles tm >= (k - i0) / 16
+        mma_stage_w14<GUARD>(As + cur * TILE_LDS, Bs + cur * TILE_LDS, accw, wave, lane, (t * BK - i0) >> 4);
+      } else {
+        mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+      }
       if (more) {
         double* an = As + (cur ^ 1) * TILE_LDS;
         double* bn = Bs + (cur ^ 1) * TILE_LDS;
@@ -200,21 +204,35 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
         }
       }
       __syncthreads();
+    };
+    if (W14) {
+      const int tdiag = (i0 / BK + 1) < ntile ? (i0 / BK + 1) : ntile;
+      for (int t = 0; t < tdiag; ++t) stage(t, std::false_type{});
+      for (int t = tdiag; t < ntile; ++t) stage(t, std::true_type{});
+    } else {
+      for (int t = 0; t < ntile; ++t) stage(t, std::false_type{});
     }
 
     // signed squares: rows < n count +, constraint rows n..N1-1 count -, padding rows are zero
+    if (W14) {
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      double s = 0.0;
-      if (B4) {
+      for (int tn = 0; tn < 2; ++tn) {
+        double s = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int row = i0 + wm * 64 + 4 * u + lk;
-          const double v = acc4[u][tn];
-          const double vv = v * v;
-          s += (row < n) ? vv : -vv;
-        }
-      } else {
+        for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i0 + tm * 16 + lk + 4 * r;
+            const double v = accw[tm][tn][r];
+            const double vv = v * v;
+            s += (row < n) ? vv : -vv;
+          }
+        qacc[tn] += s;
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        double s = 0.0;
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -224,12 +242,12 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
             const double vv = v * v;
             s += (row < n) ? vv : -vv;
           }
+        qacc[tn] += s;
       }
-      qacc[tn] += s;
     }
   }
 
-  // reduce over the 4 lane groups (rows) of the wave, then over the two wave rows of the workgroup
+  // reduce over the 4 lane groups (rows) of the wave, then (2 x 2 layout) over the two wave rows
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     qacc[tn] += __shfl_xor(qacc[tn], 16);
@@ -238,8 +256,15 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   __syncthreads();
   double* red = smem;  // [2][BN]
   if (lk == 0) {
+    if (W14) {
+      red[wave * 32 + lr] = qacc[0];
+      red[wave * 32 + 16 + lr] = qacc[1];
+      red[BN + wave * 32 + lr] = 0.0;
+      red[BN + wave * 32 + 16 + lr] = 0.0;
+    } else {
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
+      for (int tn = 0; tn < 4; ++tn) red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
+    }
   }
   __syncthreads();
   if (SPLIT) {
@@ -657,7 +682,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
 
   static bool attr_set = false;
   static int split = 0;    // 0: one workgroup per strip (default); 1: per (strip, row block), XCD-aware ids -- measured 24 % slower
-  static int variant = 0;  // 0: v_mfma_f64_16x16x4 (default), 1: v_mfma_f64_4x4x4_4b (GSS_K3_VARIANT=1); same rate in situ
+  static int variant = 1;  // 1: 1 x 4 waves with zero-tile skipping in the diagonal block (default); 0: 2 x 2 waves
   if (!attr_set) {
     GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
@@ -723,23 +748,33 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
       double* qpart = mpart + (int64_t)(NSEG + 1) * ldr;
       const double mean0 = h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0;
       uint8_t* stp = status ? sstat.as<uint8_t>() + off : nullptr;
-#define GSS_K3_ARGS h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, mpart, nparts, h->vg.sill, mean0, mv, \
-                    smean.as<double>() + off, svar.as<double>() + off, stp, qpart, nstrips
-      if (split) {
-        const unsigned grid = (unsigned)(8 * ((nstrips + 7) / 8) * nI);
+#define GSS_K3_ARGS(S0, NS) h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, mpart, nparts, h->vg.sill, \
+                            mean0, mv, smean.as<double>() + off, svar.as<double>() + off, stp, qpart, (S0), (NS)
+      // Whole rounds of 512 resident workgroups (2 per CU) run one workgroup per strip; the remainder strips
+      // would occupy a full extra round, so they run as (strip, row block) units, which pack ~3x tighter.
+      const int nmain = split ? 0 : (nstrips / 512) * 512;
+      const int nrem = nstrips - nmain;
+      if (nmain > 0) {
         if (variant == 1)
-          hipLaunchKernelGGL((krig_quadform_kernel<true, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s, GSS_K3_ARGS);
+          hipLaunchKernelGGL((krig_quadform_kernel<true, false>), dim3((unsigned)nmain), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS(0, nmain));
         else
-          hipLaunchKernelGGL((krig_quadform_kernel<false, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s, GSS_K3_ARGS);
-        hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv + 255) / 256)), dim3(256), 0, s, qpart, nI, mpart, nparts,
-                           ldr, h->vg.sill, mean0, mv, smean.as<double>() + off, svar.as<double>() + off, stp);
-      } else {
+          hipLaunchKernelGGL((krig_quadform_kernel<false, false>), dim3((unsigned)nmain), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS(0, nmain));
+      }
+      if (nrem > 0) {
+        const unsigned grid = (unsigned)(8 * ((nrem + 7) / 8) * nI);
         if (variant == 1)
-          hipLaunchKernelGGL((krig_quadform_kernel<true, false>), dim3((unsigned)nstrips), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS);
+          hipLaunchKernelGGL((krig_quadform_kernel<true, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS(nmain, nrem));
         else
-          hipLaunchKernelGGL((krig_quadform_kernel<false, false>), dim3((unsigned)nstrips), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS);
+          hipLaunchKernelGGL((krig_quadform_kernel<false, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s,
+                             GSS_K3_ARGS(nmain, nrem));
+        const int64_t pbeg = (int64_t)nmain * BN;
+        if (mv > pbeg)
+          hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv - pbeg + 255) / 256)), dim3(256), 0, s, qpart + pbeg,
+                             nI, mpart + pbeg, nparts, ldr, h->vg.sill, mean0, mv - pbeg, smean.as<double>() + off + pbeg,
+                             svar.as<double>() + off + pbeg, stp ? stp + pbeg : nullptr);
       }
 #undef GSS_K3_ARGS
     }

@@ -45,29 +45,33 @@ __device__ __forceinline__ void mma_stage(const double* __restrict__ As, const d
   }
 }
 
-// Same 64 x 64 wave tile on v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction), which
-// sustains ~1.5x the FLOP rate of the 16x16x4 form on gfx950 (tools/probe_f64.hip).  Lane maps, measured
-// with tools/probe_mfma4x4.hip: A lane = 16k + 4b + i, B lane = 16k + 4b + j, D lane = 16i + 4b + j for
-// block b.  Instruction (u, v) gives every block the row group u and block b the column group 4v + b:
-//   A operand u : lane holds A[4u + (lane & 3)][k = lane >> 4]      (replicated over b: LDS broadcast)
-//   B operand v : lane holds B[k = lane >> 4][16v + (lane & 15)]    (the 16x16x4 B layout)
-//   acc[u][v]   : lane holds D[4u + (lane >> 4)][16v + (lane & 15)]
-__device__ __forceinline__ void mma_stage_b4(const double* __restrict__ As, const double* __restrict__ Bs,
-                                             double (&acc)[16][4], int wm, int wn, int lane) {
+// 1 x 4 wave arrangement for triangular operands: every wave owns all 128 rows of the workgroup tile and 32 of
+// its columns (8 x 2 MFMA tiles, still 128 accumulator VGPRs).  All waves then see the same rows, so the zero
+// 16-row tiles of a lower-triangular A can be skipped uniformly: in the stage that covers k = i0 + 16 s .. + 15
+// of the diagonal block only row tiles tm >= s are non-zero (tm_min = s; 0 for ordinary stages).
+// Measured alternative, kept out of the build: the 4-block form v_mfma_f64_4x4x4_4b_f64 (lane maps
+// A = 16k + 4b + i, B = 16k + 4b + j, D = 16i + 4b + j, tools/probe_mfma4x4.hip) runs this kernel at the same
+// rate as the 16x16x4 form although it is 1.5x faster in a register-only loop (tools/probe_f64.hip).
+template <bool GUARD>
+__device__ __forceinline__ void mma_stage_w14(const double* __restrict__ As, const double* __restrict__ Bs,
+                                              d4 (&acc)[8][2], int wave, int lane, int tm_min) {
+  const int lr = lane & 15;
   const int lk = lane >> 4;
-#pragma unroll 1
+#pragma unroll
   for (int kk = 0; kk < BK / 4; ++kk) {
-    const double* ap = As + (kk * 4 + lk) * LDS_LD + wm * 64 + (lane & 3);
-    const double* bp = Bs + (kk * 4 + lk) * LDS_LD + wn * 64 + (lane & 15);
-    double a[16], b[4];
+    const double* ap = As + (kk * 4 + lk) * LDS_LD + lr;
+    const double* bp = Bs + (kk * 4 + lk) * LDS_LD + wave * 32 + lr;
+    const double b0 = bp[0], b1 = bp[16];
+    double a[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a[u] = ap[4 * u];
+    for (int tm = 0; tm < 8; ++tm) a[tm] = ap[tm * 16];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = bp[16 * v];
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+    for (int tm = 0; tm < 8; ++tm) {
+      if (!GUARD || tm >= tm_min) {
+        acc[tm][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b0, acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b1, acc[tm][1], 0, 0, 0);
+      }
+    }
   }
 }
 
