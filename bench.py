@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--npoints", type=int, default=1_000_000, help="domain points per GPU per step")
     ap.add_argument("--factor-broadcast", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=12000, help="points of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=30000, help="points of the CPU baseline sample")
     ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the extra leg)")
     ap.add_argument("--fftgs-reals", type=int, default=8)
     return ap.parse_args()
@@ -126,6 +126,16 @@ def main():
                              "achieved": round(8.0 * n * m * a.steps / (r_ms * 1e-3) / 1e9, 1) if r_n else 0.0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(r_ms / max(r_n, 1), 4),
                              "launches": r_n}}
+
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the value is
+    # the one measured for this exact configuration with tools/pmc_krig.sh + tools/pmc_traffic.py (separate --pmc
+    # passes, gfx950 FETCH_SIZE correction) and committed under profiles/.
+    tfile = os.path.join(ROOT, "profiles", "r01_krig_cfg2_pmc_traffic.json")
+    if n == 1000 and m == 1_000_000 and os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        roofline["traffic"] = tj["hbm_bytes_per_step"] / max(q_n / a.steps, 1)
+        roofline["traffic_unit"] = "B per launch (rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE, profiles/r01_krig_cfg2_pmc_traffic.json)"
+        roofline["algorithmic_bytes"] = 8.0 * N1 * m / max(q_n / a.steps, 1)   # R read once: 8 (n+nc) B per point
 
     line = {"metric": "kriged domain points/sec (OK, 1000 3-D data, Matern-3/2, global neighbourhood)",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
