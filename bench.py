@@ -200,14 +200,15 @@ def fftgs_leg(a, gss, _lib):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
-    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv")}
+    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", "fftgs_p1", "fftgs_p2", "fftgs_p3", "fftgs_p4",
+                                               "fftgs_p5")}
     zc = out[0]
     res = {"metric": "FFTGS %d^3 realisations/sec" % e, "value": round(a.fftgs_reals / dt, 2), "unit": "realisations/s",
            "ms_per_realisation": round(dt / a.fftgs_reals * 1e3, 3),
            "roofline": {"bound": "hbm", "achieved": round(32.0 * N * a.fftgs_reals / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(32.0 * N * a.fftgs_reals / dt / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": None},
-           "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items()},
+           "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items() if v[1]},
            "sample_variance": float((zc * zc).sum().item() / (N - 1))}
     f.close()
     return res

@@ -47,7 +47,8 @@ def cfg2_fftgs(a, gss, _lib):
     sync()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
-    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv")}
+    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", "fftgs_p1", "fftgs_p2", "fftgs_p3", "fftgs_p4",
+                                               "fftgs_p5")}
     var = float((out[0] * out[0]).sum().item() / (N - 1))
     # CPU baseline: oracle solvesingle (two C2C FFTs + temporaries like fft.jl:163-170) on a 256^3 grid
     from oracle import fftgs as O, philox
@@ -62,7 +63,7 @@ def cfg2_fftgs(a, gss, _lib):
             "metric": "realisations/s", "value": round(R / dt, 2), "preprocess_s": round(t_pre, 3),
             "roofline": {"bound": "hbm", "achieved": round(32.0 * N * R / dt / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(32.0 * N * R / dt / 1e9 / HBM_PEAK, 4)},
-            "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items()}, "sample_variance": var,
+            "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items() if v[1]}, "sample_variance": var,
             "cpu_baseline": {"value": round(1.0 / cdt * (ce / e) ** 3, 4), "unit": "realisations/s", "cores": 1,
                              "kind": "port", "sample": "oracle.fftgs.solvesingle (numpy pocketfft C2C as fft.jl:163-166) on "
                              "%d^3 in %.1f s, scaled by cell count to %d^3" % (ce, cdt, e)}}

@@ -16,12 +16,16 @@
 // HBM traffic per realisation (FP64, N cells): noise 8N (w) + R2C + phase 8N+4N (r) 8N (w) + C2R;
 // the algorithmic floor is 32 N bytes.
 #include "gss_internal.h"
+#include "fftgs_fused.h"
 #include "philox.h"
 
 #include <rocfft/rocfft.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace gss {
 
@@ -161,6 +165,10 @@ struct gss_fftgs {
   rocfft_execution_info info = nullptr;
   DevBuf state;  // Fh (NH doubles) followed by scal[2]
   DevBuf U, X, work, Z;
+  // fused pipeline (power-of-two 3-D grids)
+  bool fused = false;
+  FusedGrid fg;
+  DevBuf tw1, tw2, tw3, Fh_tiled;
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
   ~gss_fftgs() {
@@ -180,6 +188,109 @@ static int32_t fft_exec(gss_fftgs* h, rocfft_plan plan, void* in, void* out, hip
   void* ib[1] = {in};
   void* ob[1] = {out};
   GSS_FFT(rocfft_execute(plan, ib, ob, h->info));
+  return GSS_OK;
+}
+
+static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+static int ilog2(int64_t v) {
+  int l = 0;
+  while ((1LL << l) < v) ++l;
+  return l;
+}
+
+static int32_t upload_twiddles(DevBuf& buf, int L, hipStream_t s) {
+  std::vector<double> t((size_t)L);  // L/2 complex: exp(-2 pi i k / L)
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int k = 0; k < L / 2; ++k) {
+    const long double a = two_pi * (long double)k / (long double)L;
+    t[(size_t)(2 * k)] = (double)cosl(a);
+    t[(size_t)(2 * k + 1)] = (double)(-sinl(a));
+  }
+  GSS_TRY(buf.alloc(sizeof(double) * (size_t)L));
+  GSS_HIP(hipMemcpyAsync(buf.p, t.data(), sizeof(double) * (size_t)L, hipMemcpyHostToDevice, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+static size_t ff_axis_lds(int L) { return sizeof(double2) * (size_t)(L / 2 + FF_TX * lds_line_pitch(L)); }
+static size_t ff_xfwd_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * lds_line_pitch(M)); }
+static size_t ff_xinv_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * (M + 1) + FF_ROWS * lds_line_pitch(M)); }
+
+// The fused five-pass pipeline serves 3-D grids whose sizes are powers of two (32..1024 along x, 16..1024 along
+// y and z); everything else, and GSS_FFTGS_PATH=rocfft, stays on the rocFFT pipeline.
+static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
+  const char* e = std::getenv("GSS_FFTGS_PATH");
+  if (e && std::strcmp(e, "rocfft") == 0) return GSS_OK;
+  const GridSpec& g = h->g;
+  if (h->ndim != 3 || !pow2(g.n1) || !pow2(g.n2) || !pow2(g.n3)) return GSS_OK;
+  if (g.n1 < 32 || g.n1 > 1024 || g.n2 < 16 || g.n2 > 1024 || g.n3 < 16 || g.n3 > 1024) return GSS_OK;
+  FusedGrid f;
+  f.n1 = (int)g.n1; f.n2 = (int)g.n2; f.n3 = (int)g.n3;
+  f.l1 = ilog2(g.n1); f.l2 = ilog2(g.n2); f.l3 = ilog2(g.n3);
+  f.nh = (int)g.nh;
+  f.nhp = (f.nh + FF_TX - 1) / FF_TX * FF_TX;
+  f.ntx = f.nhp / FF_TX;
+  h->fg = f;
+  GSS_TRY(upload_twiddles(h->tw1, f.n1, s));
+  GSS_TRY(upload_twiddles(h->tw2, f.n2, s));
+  GSS_TRY(upload_twiddles(h->tw3, f.n3, s));
+  const int64_t nt = (int64_t)f.n2 * f.ntx * f.n3 * FF_TX;
+  GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)nt));
+  hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+  GSS_HIP(hipGetLastError());
+  const int M = f.n1 / 2;
+  const int lmax = f.n2 > f.n3 ? f.n2 : f.n3;
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ff_xfwd_lds(M)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ff_xinv_lds(M)));
+  // the half-spectrum buffer of the fused path has the padded row pitch; padding columns stay zero
+  GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)f.nhp * f.n2 * f.n3));
+  GSS_HIP(hipMemsetAsync(h->X.p, 0, h->X.bytes, s));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ff_axis_lds(lmax)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ff_axis_lds(lmax)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ff_axis_lds(lmax)));
+  GSS_HIP(hipStreamSynchronize(s));
+  h->fused = true;
+  return GSS_OK;
+}
+
+// one realisation through the fused pipeline; `noise` (N uniforms) may be NULL; z receives N doubles
+static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z,
+                               hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  const int M = f.n1 / 2;
+  const int64_t nrows = (int64_t)f.n2 * f.n3;
+  const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
+  double2* X = h->X.as<double2>();
+  {
+    ProfScope ps("fftgs_p1", s);
+    hipLaunchKernelGGL(ff_x_fwd_kernel, dim3(gx), dim3(FF_THREADS), ff_xfwd_lds(M), s, f,
+                       h->tw1.as<double2>(), seed, (uint32_t)real, noise, X);
+  }
+  {
+    ProfScope ps("fftgs_p2", s);
+    hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
+                       h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, X, nullptr, 0.0);
+  }
+  {
+    ProfScope ps("fftgs_p3", s);
+    hipLaunchKernelGGL(ff_axis_kernel<2>, dim3((unsigned)(f.n2 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n3), s, f, f.l3,
+                       h->tw3.as<double2>(), (int64_t)f.nhp, (int64_t)f.n2 * f.nhp, X, h->Fh_tiled.as<double>(), h->mean);
+  }
+  {
+    ProfScope ps("fftgs_p4", s);
+    hipLaunchKernelGGL(ff_axis_kernel<1>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
+                       h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, X, nullptr, 0.0);
+  }
+  {
+    ProfScope ps("fftgs_p5", s);
+    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_THREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
+  }
+  GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
 
@@ -256,6 +367,7 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
   double hs[2];
   GSS_HIP(hipMemcpy(hs, h->scal(), sizeof(hs), hipMemcpyDeviceToHost));
   GSS_REQUIRE(hs[0] > 0.0 && std::isfinite(hs[1]), "degenerate spectrum (sum F^2 = %g)", hs[0]);
+  GSS_TRY(fftgs_setup_fused(h, s));
   guard.h = nullptr;
   *out = h;
   return GSS_OK;
@@ -298,6 +410,16 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
   if (inds && h->Z.bytes < sizeof(double) * (size_t)N) GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N));
 
   for (int64_t r = 0; r < nreals; ++r) {
+    if (h->fused) {
+      double* zf = inds ? h->Z.as<double>() : so.as<double>() + r * N;
+      GSS_TRY(fftgs_fused_one(h, seed, first_real + r, noise ? sn.as<double>() + r * N : nullptr, zf, s));
+      if (inds) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
+                           ninds, so.as<double>() + r * ninds);
+        GSS_HIP(hipGetLastError());
+      }
+      continue;
+    }
     double* u = h->U.as<double>();
     if (noise) {
       u = sn.as<double>() + r * N;  // the forward transform does not overwrite its input

@@ -169,3 +169,50 @@ def test_conditional_simulation_matches_oracle(maxneighbors):
         assert np.max(np.abs(sol[r].z - ref)) < 1e-8
     # data are honoured at the data cells up to the centroid offset (fft.jl:112 vs :180-184)
     assert np.max(np.abs(sol[0].z[pre.dinds] - np.array(vals))) < 0.35
+
+
+POW2_GRIDS = [(32, 16, 16), (64, 32, 16), (32, 64, 128), (128, 16, 32)]
+
+
+@pytest.mark.parametrize("dims", POW2_GRIDS)
+def test_fused_pipeline_matches_oracle_and_rocfft_path(dims, monkeypatch):
+    """Power-of-two 3-D grids take the fused five-pass pipeline (csrc/fftgs_fused.h); it must agree with the
+    oracle and with the rocFFT pipeline of the same library."""
+    N = int(np.prod(dims))
+    kw = dict(range=0.2 * dims[0], sill=1.4, nugget=0.05)
+    pre = O.preprocess(Variogram("exponential", **kw), dims, mean=0.3)
+    h = _handle("exponential", dims, mean=0.3, **kw)
+    z = h.realize(11, 2, 3)
+    ref = O.realize(pre, 11, 2, 3)
+    assert np.max(np.abs(z - ref)) < 1e-9
+    noise = np.random.default_rng(N).uniform(size=(2, N))
+    zn = h.realize(0, 0, 2, noise=noise)
+    for r in range(2):
+        assert np.max(np.abs(zn[r] - O.solvesingle(pre, noise[r]))) < 1e-9
+    inds = np.arange(0, N, 7)
+    assert np.array_equal(h.realize(11, 2, 1, inds=inds)[0], z[0][inds])
+    h.close()
+    monkeypatch.setenv("GSS_FFTGS_PATH", "rocfft")
+    h2 = _handle("exponential", dims, mean=0.3, **kw)
+    z2 = h2.realize(11, 2, 3)
+    assert np.max(np.abs(z2 - z)) < 1e-10 and not np.array_equal(z2, z)     # two different code paths
+    h2.close()
+
+
+def test_fused_pipeline_512_cube_properties():
+    import torch
+    import gss
+    from gss.engine import FFTGSHandle
+    e = 512
+    N = e ** 3
+    h = FFTGSHandle(gss.ExponentialVariogram(range=50.0), (e, e, e), mean=1.0)
+    z = h.realize(4, 0, 1, device=True)
+    torch.cuda.synchronize()
+    zc = z[0] - 1.0
+    assert abs(float((zc * zc).sum()) / (N - 1) - 1.0) < 1e-8 and abs(float(zc.mean())) < 1e-10
+    F = torch.as_tensor(h.spectrum(), device="cuda").reshape(e, e, e)
+    A = torch.fft.fftn(zc.reshape(e, e, e)).abs()
+    sel = F > 1e-3 * F.max()
+    ratio = A[sel] / F[sel]
+    assert float((ratio.max() - ratio.min()) / ratio.mean()) < 1e-8
+    h.close()
