@@ -171,7 +171,7 @@ def test_conditional_simulation_matches_oracle(maxneighbors):
     assert np.max(np.abs(sol[0].z[pre.dinds] - np.array(vals))) < 0.35
 
 
-POW2_GRIDS = [(32, 16, 16), (64, 32, 16), (32, 64, 128), (128, 16, 32)]
+POW2_GRIDS = [(32, 16, 16), (64, 128, 64), (256, 64, 128), (1024, 32, 16)]
 
 
 @pytest.mark.parametrize("dims", POW2_GRIDS)
