@@ -54,7 +54,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gfx950 path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run: one rank per GPU
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
 
     import gss
@@ -62,7 +64,7 @@ def main():
     from gss.engine import KrigHandle, OK
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -75,7 +77,7 @@ def main():
     vg = gss.MaternVariogram(range=30.0, sill=1.0, nugget=0.0, order=1.5)
 
     def step():
-        if a.factor_broadcast and world > 1:
+        if a.factor_broadcast and use_dist:
             h = KrigHandle(vg, OK, x, z, factor=(rank == 0))
             t = h.factor_tensor()
             dist.broadcast(t, src=0)
@@ -109,7 +111,7 @@ def main():
     keep[0].close()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     value = world * m * a.steps / dt
@@ -176,7 +178,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -146,3 +146,53 @@ def test_reference_2d_problem_through_solve_api():
     Z = gss.asarray(sol, "z")
     assert abs(Z[24, 24] - 1.0) < 1e-3 and abs(Z[49, 74] - 0.0) < 1e-3 and abs(Z[74, 49] - 1.0) < 1e-3
     assert sol["z_variance"].shape == (10000,) and np.all(sol["z_variance"] >= 0)
+
+
+def test_factor_state_can_be_shipped_between_handles():
+    """The multi-GPU path broadcasts the factor state (W' and the dual weights) from rank 0 into handles created
+    with GSS_KRIG_NO_FACTOR (bench.py --factor-broadcast).  On one GPU: copy it between two handles."""
+    import torch
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(12)
+    x = rng.uniform(0, 100, (257, 3))
+    z = rng.normal(size=257)
+    x0 = rng.uniform(0, 100, (1000, 3))
+    vg = _vg("matern", range=30.0, nu=1.5)
+    a = KrigHandle(vg, K.UK, x, z, degree=1)
+    b = KrigHandle(vg, K.UK, x, z, degree=1, factor=False)
+    from gss import _lib
+    with pytest.raises(_lib.GSSError, match="no factor"):
+        b.predict_global(x0)
+    ta, tb = a.factor_tensor(), b.factor_tensor()
+    assert ta.is_cuda and ta.dtype == torch.float64 and ta.shape == tb.shape
+    tb.copy_(ta)                      # stands in for dist.broadcast(t, src=0) over RCCL
+    torch.cuda.synchronize()
+    b.adopt_factor()
+    mu_a, var_a, _ = a.predict_global(x0)
+    mu_b, var_b, _ = b.predict_global(x0)
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(var_a, var_b)
+
+
+def test_edge_sizes_empty_domain_single_datum_large_system():
+    from gss.engine import KrigHandle
+    vg = _vg("exponential", range=25.0)
+    ovg = Variogram("exponential", range=25.0)
+    # a single datum: OK returns the datum everywhere with variance from the 2x2 system
+    h = KrigHandle(vg, K.OK, np.array([[10.0, 10.0]]), np.array([2.5]))
+    mu, var, st = h.predict_global(np.array([[10.0, 10.0], [40.0, 50.0]]))
+    rmu, rvar = K.exactsolve(K.OK, ovg, np.array([[10.0, 10.0]]), np.array([2.5]), np.array([[10.0, 10.0], [40.0, 50.0]]))
+    assert np.allclose(mu, [2.5, 2.5]) and np.allclose(mu, rmu) and np.allclose(var, rvar, atol=1e-12)
+    # empty domain
+    mu0, var0, st0 = h.predict_global(np.empty((0, 2)))
+    assert mu0.shape == (0,) and var0.shape == (0,)
+    h.close()
+    # 3 001 x 3 001 system: several recursion levels, N1 not a multiple of the tile sizes
+    rng = np.random.default_rng(3000)
+    x = rng.uniform(0, 200, (3000, 3))
+    z = rng.normal(size=3000)
+    x0 = rng.uniform(0, 200, (513, 3))
+    hb = KrigHandle(_vg("matern", range=30.0, nu=1.5), K.OK, x, z)
+    mu, var, st = hb.predict_global(x0)
+    rmu, rvar = K.exactsolve(K.OK, Variogram("matern", range=30.0, nu=1.5), x, z, x0)
+    assert np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    hb.close()
