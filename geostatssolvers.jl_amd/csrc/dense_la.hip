@@ -26,46 +26,58 @@ struct GemmArgs {
   int lower_only;
 };
 
-constexpr size_t GEMM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
-
 // Register-staged, LDS double-buffered pipeline (one barrier per BK stage), bounds-checked scalar loads that
-// are coalesced along whichever index is contiguous.
-template <bool A_ICONTIG, bool B_JCONTIG>
+// are coalesced along whichever index is contiguous.  Two tile shapes: 128 x 128 (4 waves x 4x4 MFMA tiles) for
+// large problems and 64 x 64 (4 waves x 2x2 MFMA tiles) for the many small products of the recursions, where a
+// 128-tile grid would leave most CUs idle and waste 3/4 of the matrix work on padding.
+template <int T>
+struct GemmTile {
+  static constexpr int TILE = T;             // workgroup tile edge
+  static constexpr int WT = T / 32;          // MFMA tiles per wave edge (wave tile = T/2)
+  static constexpr int LD = T + 16;          // LDS row stride: 16 (mod 32) doubles
+  static constexpr int STAGE = BK * LD;      // doubles per operand stage
+  static constexpr int NLOAD = T * BK / 256; // elements per thread per operand per stage
+  static constexpr size_t LDS_BYTES = sizeof(double) * 4 * STAGE;
+};
+
+template <int T, bool A_ICONTIG, bool B_JCONTIG>
 __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
+  using G = GemmTile<T>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* As = smem;                 // [2][TILE_LDS]
-  double* Bs = smem + 2 * TILE_LDS;  // [2][TILE_LDS]
+  double* As = smem;                  // [2][STAGE]
+  double* Bs = smem + 2 * G::STAGE;   // [2][STAGE]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t i0 = (int64_t)blockIdx.y * BM;
-  const int64_t j0 = (int64_t)blockIdx.x * BN;
-  if (g.lower_only && j0 > i0 + BM - 1) return;
+  const int64_t i0 = (int64_t)blockIdx.y * T;
+  const int64_t j0 = (int64_t)blockIdx.x * T;
+  if (g.lower_only && j0 > i0 + T - 1) return;
 
-  // staging map of this thread: 8 elements of each operand tile per stage
-  int ai[8], ak[8], bj[8], bk[8];
+  // staging map of this thread: NLOAD elements of each operand tile per stage
+  int ai[G::NLOAD], ak[G::NLOAD], bj[G::NLOAD], bk[G::NLOAD];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < G::NLOAD; ++r) {
+    const int e = tid + r * 256;
     if (A_ICONTIG) {
-      ai[r] = tid & 127;
-      ak[r] = (tid >> 7) + 2 * r;
+      ai[r] = e % T;
+      ak[r] = e / T;
     } else {
-      ak[r] = tid & 15;
-      ai[r] = (tid >> 4) + 16 * r;
+      ak[r] = e % BK;
+      ai[r] = e / BK;
     }
     if (B_JCONTIG) {
-      bj[r] = tid & 127;
-      bk[r] = (tid >> 7) + 2 * r;
+      bj[r] = e % T;
+      bk[r] = e / T;
     } else {
-      bk[r] = tid & 15;
-      bj[r] = (tid >> 4) + 16 * r;
+      bk[r] = e % BK;
+      bj[r] = e / BK;
     }
   }
-  double ra[8], rb[8];
+  double ra[G::NLOAD], rb[G::NLOAD];
   auto load_stage = [&](int64_t k0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < G::NLOAD; ++r) {
       const int64_t gi = i0 + ai[r], gka = k0 + ak[r];
       ra[r] = (gi < g.M && gka < g.K) ? g.A[gi * g.sa_i + gka * g.sa_k] : 0.0;
       const int64_t gj = j0 + bj[r], gkb = k0 + bk[r];
@@ -73,17 +85,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
     }
   };
   auto store_stage = [&](int buf) {
-    double* a = As + buf * TILE_LDS;
-    double* b = Bs + buf * TILE_LDS;
+    double* a = As + buf * G::STAGE;
+    double* b = Bs + buf * G::STAGE;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      a[ak[r] * LDS_LD + ai[r]] = ra[r];
-      b[bk[r] * LDS_LD + bj[r]] = rb[r];
+    for (int r = 0; r < G::NLOAD; ++r) {
+      a[ak[r] * G::LD + ai[r]] = ra[r];
+      b[bk[r] * G::LD + bj[r]] = rb[r];
     }
   };
 
-  d4 acc[4][4];
-  zero_acc(acc);
+  d4 acc[G::WT][G::WT];
+#pragma unroll
+  for (int tm = 0; tm < G::WT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < G::WT; ++tn) acc[tm][tn] = d4{0.0, 0.0, 0.0, 0.0};
+  const int lr = lane & 15, lk = lane >> 4;
   const int64_t ntile = (g.K + BK - 1) / BK;
   if (ntile > 0) {
     load_stage(0);
@@ -94,20 +110,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
     const int cur = (int)(t & 1);
     const bool more = (t + 1) < ntile;
     if (more) load_stage((t + 1) * BK);
-    mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
+    const double* as = As + cur * G::STAGE;
+    const double* bs = Bs + cur * G::STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const double* ap = as + (kk * 4 + lk) * G::LD + wm * (T / 2) + lr;
+      const double* bp = bs + (kk * 4 + lk) * G::LD + wn * (T / 2) + lr;
+      double a[G::WT], b[G::WT];
+#pragma unroll
+      for (int q = 0; q < G::WT; ++q) {
+        a[q] = ap[q * 16];
+        b[q] = bp[q * 16];
+      }
+#pragma unroll
+      for (int tm = 0; tm < G::WT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < G::WT; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
     if (more) store_stage(cur ^ 1);
     __syncthreads();
   }
 
-  const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int tm = 0; tm < G::WT; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int tn = 0; tn < G::WT; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t gi = i0 + wm * 64 + tm * 16 + lk + 4 * r;
-        const int64_t gj = j0 + wn * 64 + tn * 16 + lr;
+        const int64_t gi = i0 + wm * (T / 2) + tm * 16 + lk + 4 * r;
+        const int64_t gj = j0 + wn * (T / 2) + tn * 16 + lr;
         if (gi < g.M && gj < g.N) {
           double* d = g.D + gi * g.sd_i + gj * g.sd_j;
           double v = g.alpha * acc[tm][tn][r];
@@ -117,17 +149,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
       }
 }
 
-template <bool AI, bool BJ>
-static int32_t gemm_launch(const GemmArgs& g, dim3 grid, hipStream_t s) {
+template <int T, bool AI, bool BJ>
+static int32_t gemm_launch(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_generic_kernel<AI, BJ>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_generic_kernel<T, AI, BJ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmTile<T>::LDS_BYTES));
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_f64_generic_kernel<AI, BJ>), grid, dim3(256), GEMM_LDS_BYTES, s, g);
+  dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T));
+  hipLaunchKernelGGL((gemm_f64_generic_kernel<T, AI, BJ>), grid, dim3(256), GemmTile<T>::LDS_BYTES, s, g);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
+}
+
+template <int T>
+static int32_t gemm_dispatch(const GemmArgs& g, bool ai, bool bj, hipStream_t s) {
+  if (ai && bj) return gemm_launch<T, true, true>(g, s);
+  if (ai && !bj) return gemm_launch<T, true, false>(g, s);
+  if (!ai && bj) return gemm_launch<T, false, true>(g, s);
+  return gemm_launch<T, false, false>(g, s);
 }
 
 int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
@@ -135,13 +176,12 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                  int64_t sd_j, bool lower_only, hipStream_t s) {
   if (M <= 0 || N <= 0) return GSS_OK;
   GemmArgs g{M, N, K, alpha, beta, A, sa_i, sa_k, B, sb_k, sb_j, D, sd_i, sd_j, lower_only ? 1 : 0};
-  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM));
   const bool ai = (sa_i == 1) || (sa_k != 1);
   const bool bj = (sb_j == 1) || (sb_k != 1);
-  if (ai && bj) return gemm_launch<true, true>(g, grid, s);
-  if (ai && !bj) return gemm_launch<true, false>(g, grid, s);
-  if (!ai && bj) return gemm_launch<false, true>(g, grid, s);
-  return gemm_launch<false, false>(g, grid, s);
+  // 128-tiles only when they can fill at least half of the 256 CUs; otherwise 64-tiles (4x the workgroups)
+  const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (big_tiles >= 128) return gemm_dispatch<128>(g, ai, bj, s);
+  return gemm_dispatch<64>(g, ai, bj, s);
 }
 
 // ---------------------------------------------------------------------------------------------
