@@ -63,10 +63,41 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Device allocations are recycled through a small exact-size free list: handles are created and destroyed once
+// per solve with identical sizes, and hipMalloc / hipFree cost 0.1-1 ms each (hipFree also synchronises the
+// device, which would stop the host from queueing the next solve behind the running one).  Re-use is ordered by
+// the stream the work is submitted on (one stream per process, handles are not thread-safe), so a block released
+// while a kernel still reads it cannot be overwritten before that kernel finishes.
+struct PoolBlock {
+  void* p;
+  size_t bytes;
+};
+static std::vector<PoolBlock> g_pool;
+static size_t g_pool_bytes = 0;
+constexpr size_t POOL_MAX_BYTES = (size_t)3 << 30;
+constexpr size_t POOL_MAX_BLOCK = (size_t)1 << 30;
+constexpr size_t POOL_MAX_COUNT = 64;
+
 int32_t DevBuf::alloc(size_t nbytes) {
   release();
   if (nbytes == 0) nbytes = 8;
+  for (size_t i = 0; i < g_pool.size(); ++i) {
+    if (g_pool[i].bytes == nbytes) {
+      p = g_pool[i].p;
+      bytes = nbytes;
+      g_pool_bytes -= nbytes;
+      g_pool[i] = g_pool.back();
+      g_pool.pop_back();
+      return GSS_OK;
+    }
+  }
   hipError_t e = hipMalloc(&p, nbytes);
+  if (e != hipSuccess && !g_pool.empty()) {  // give cached blocks back and retry once
+    for (auto& b : g_pool) (void)hipFree(b.p);
+    g_pool.clear();
+    g_pool_bytes = 0;
+    e = hipMalloc(&p, nbytes);
+  }
   if (e != hipSuccess) {
     p = nullptr;
     set_error("hipMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
@@ -77,7 +108,14 @@ int32_t DevBuf::alloc(size_t nbytes) {
 }
 
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) {
+    if (bytes <= POOL_MAX_BLOCK && g_pool.size() < POOL_MAX_COUNT && g_pool_bytes + bytes <= POOL_MAX_BYTES) {
+      g_pool.push_back(PoolBlock{p, bytes});
+      g_pool_bytes += bytes;
+    } else {
+      (void)hipFree(p);
+    }
+  }
   p = nullptr;
   bytes = 0;
 }
@@ -201,7 +239,12 @@ int32_t gss_init(int32_t device) {
   return GSS_OK;
 }
 
-int32_t gss_shutdown(void) { return GSS_OK; }
+int32_t gss_shutdown(void) {
+  for (auto& b : g_pool) (void)hipFree(b.p);
+  g_pool.clear();
+  g_pool_bytes = 0;
+  return GSS_OK;
+}
 
 int32_t gss_last_error(char* buf, int32_t len) {
   if (buf == nullptr || len <= 0) return GSS_ERR_INVALID;
