@@ -228,7 +228,7 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   f.n1 = (int)g.n1; f.n2 = (int)g.n2; f.n3 = (int)g.n3;
   f.l1 = ilog2(g.n1); f.l2 = ilog2(g.n2); f.l3 = ilog2(g.n3);
   f.nh = (int)g.nh;
-  f.nhp = (f.nh + FF_TX - 1) / FF_TX * FF_TX;
+  f.nhp = (f.nh + FF_PITCH_ALIGN - 1) / FF_PITCH_ALIGN * FF_PITCH_ALIGN;
   f.ntx = f.nhp / FF_TX;
   h->fg = f;
   GSS_TRY(upload_twiddles(h->tw1, f.n1, s));
@@ -268,7 +268,7 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
   double2* X = h->X.as<double2>();
   {
     ProfScope ps("fftgs_p1", s);
-    hipLaunchKernelGGL(ff_x_fwd_kernel, dim3(gx), dim3(FF_THREADS), ff_xfwd_lds(M), s, f,
+    hipLaunchKernelGGL(ff_x_fwd_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
                        h->tw1.as<double2>(), seed, (uint32_t)real, noise, X);
   }
   {
@@ -288,7 +288,7 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
   }
   {
     ProfScope ps("fftgs_p5", s);
-    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_THREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
+    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
   }
   GSS_HIP(hipGetLastError());
   return GSS_OK;

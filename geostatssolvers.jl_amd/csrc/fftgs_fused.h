@@ -23,15 +23,20 @@
 
 namespace gss {
 
-constexpr int FF_TX = 8;        // lines per tile in the strided passes (8 complex = 128 B per row)
-constexpr int FF_ROWS = 8;      // x lines per workgroup in P1 / P5
-constexpr int FF_THREADS = 256;
+constexpr int FF_TX_LOG = 2;
+constexpr int FF_TX = 1 << FF_TX_LOG;  // lines per tile in the strided passes: 4 complex = 64 B per row; tiles 2u and
+                                       // 2u + 1 (the two halves of a 128-B line) are given to workgroups b and b + 8,
+                                       // which share an XCD and are dispatched together, so the L2 merges the halves
+constexpr int FF_PITCH_ALIGN = 8;      // rows of the half-spectrum buffer start on 128-B boundaries
+constexpr int FF_ROWS = 4;      // x lines per workgroup in P1 / P5 (4 keeps 4+ workgroups per CU resident)
+constexpr int FF_THREADS = 256;   // strided passes
+constexpr int FF_XTHREADS = 256;  // x-line passes (128 threads measured slower: fewer waves to hide latency)
 
 struct FusedGrid {
   int n1, n2, n3;      // n1 fastest; all powers of two
   int l1, l2, l3;      // log2
   int nh;              // n1 / 2 + 1
-  int nhp;             // row pitch of the half-spectrum buffer: nh rounded up to FF_TX (rows start 128-B aligned)
+  int nhp;             // row pitch of the half-spectrum buffer: nh rounded up to FF_PITCH_ALIGN
   int ntx;             // nhp / FF_TX
 };
 
@@ -52,14 +57,14 @@ __host__ __device__ constexpr int lds_line_pitch(int L) { return L + (L >> 3) + 
 // tw[k] = exp(-2 pi i k / Lt) serves every length L that divides Lt: w_L^k = tw[k * tws], tws = Lt / L.
 
 // NS consecutive DIF stages s0 .. s0+NS-1 of a length-2^logL transform
-template <int NS>
+template <int NS, int NT>
 __device__ __forceinline__ void dif_pass(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
                                          int s0, int tid) {
   constexpr int R = 1 << NS;
   const int logd = logL - s0 - NS;  // spacing of the R elements: d = (L >> s0) / R
   const int d = 1 << logd;
   const int items_per_line = 1 << (logL - NS);
-  for (int it = tid; it < nlines * items_per_line; it += FF_THREADS) {
+  for (int it = tid; it < nlines * items_per_line; it += NT) {
     const int line = it >> (logL - NS);
     const int r = it & (items_per_line - 1);
     const int p = r & (d - 1);
@@ -95,14 +100,14 @@ __device__ __forceinline__ void dif_pass(double2* buf, int logL, int pitch, int 
 }
 
 // NS consecutive inverse DIT stages s0 .. s0+NS-1 (half = 1 << s)
-template <int NS>
+template <int NS, int NT>
 __device__ __forceinline__ void dit_pass(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
                                          int s0, int tid) {
   constexpr int R = 1 << NS;
   const int logd = s0;  // spacing d = 1 << s0
   const int d = 1 << logd;
   const int items_per_line = 1 << (logL - NS);
-  for (int it = tid; it < nlines * items_per_line; it += FF_THREADS) {
+  for (int it = tid; it < nlines * items_per_line; it += NT) {
     const int line = it >> (logL - NS);
     const int r = it & (items_per_line - 1);
     const int p = r & (d - 1);
@@ -137,25 +142,27 @@ __device__ __forceinline__ void dit_pass(double2* buf, int logL, int pitch, int 
   __syncthreads();
 }
 
+template <int NT>
 __device__ __forceinline__ void lds_fft_dif(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
                                             int tid) {
   int s = 0;
-  for (; s + 3 <= logL; s += 3) dif_pass<3>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  if (logL - s == 2) dif_pass<2>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  else if (logL - s == 1) dif_pass<1>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  for (; s + 3 <= logL; s += 3) dif_pass<3, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  if (logL - s == 2) dif_pass<2, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  else if (logL - s == 1) dif_pass<1, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
 }
 
+template <int NT>
 __device__ __forceinline__ void lds_fft_dit_inv(double2* buf, int logL, int pitch, int nlines, const double2* tw,
                                                 int tws, int tid) {
   int s = 0;
-  for (; s + 3 <= logL; s += 3) dit_pass<3>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  if (logL - s == 2) dit_pass<2>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  else if (logL - s == 1) dit_pass<1>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  for (; s + 3 <= logL; s += 3) dit_pass<3, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  if (logL - s == 2) dit_pass<2, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
+  else if (logL - s == 1) dit_pass<1, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
 }
 
 // ---- P1: noise -> half spectrum along x -------------------------------------------------------------
 // LDS: tw[n1/2] | Z[FF_ROWS][lds_line_pitch(n1/2)]
-__global__ __launch_bounds__(FF_THREADS) void ff_x_fwd_kernel(FusedGrid g, const double2* __restrict__ tw1,
+__global__ __launch_bounds__(FF_XTHREADS) void ff_x_fwd_kernel(FusedGrid g, const double2* __restrict__ tw1,
                                                               uint64_t seed, uint32_t real,
                                                               const double* __restrict__ noise,
                                                               double2* __restrict__ X) {
@@ -167,8 +174,8 @@ __global__ __launch_bounds__(FF_THREADS) void ff_x_fwd_kernel(FusedGrid g, const
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * FF_ROWS;
-  for (int k = tid; k < M; k += FF_THREADS) tw[k] = tw1[k];
-  for (int e = tid; e < FF_ROWS * M; e += FF_THREADS) {
+  for (int k = tid; k < M; k += FF_XTHREADS) tw[k] = tw1[k];
+  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
     const int r = e / M, nidx = e - r * M;
     const int64_t row = row0 + r;
     double2 v = make_double2(0.0, 0.0);
@@ -180,9 +187,9 @@ __global__ __launch_bounds__(FF_THREADS) void ff_x_fwd_kernel(FusedGrid g, const
     Z[r * MP + lphys(nidx)] = v;
   }
   __syncthreads();
-  lds_fft_dif(Z, logM, MP, FF_ROWS, tw, 2, tid);  // w_M^k = w_{n1}^{2k}
+  lds_fft_dif<FF_XTHREADS>(Z, logM, MP, FF_ROWS, tw, 2, tid);  // w_M^k = w_{n1}^{2k}
   // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2, k = 0 .. M
-  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_THREADS) {
+  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_XTHREADS) {
     const int r = e / (M + 1), k = e - r * (M + 1);
     const int64_t row = row0 + r;
     if (row >= nrows) continue;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(FF_THREADS) void ff_x_fwd_kernel(FusedGrid g, const
 
 // ---- P5: half spectrum -> realisation along x ------------------------------------------------------------
 // LDS: tw[n1/2] | Xs[FF_ROWS][M+1] | Z[FF_ROWS][lds_line_pitch(M)]
-__global__ __launch_bounds__(FF_THREADS) void ff_x_inv_kernel(FusedGrid g, const double2* __restrict__ tw1,
+__global__ __launch_bounds__(FF_XTHREADS) void ff_x_inv_kernel(FusedGrid g, const double2* __restrict__ tw1,
                                                               const double2* __restrict__ X,
                                                               double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double2 sm[];
@@ -210,15 +217,15 @@ __global__ __launch_bounds__(FF_THREADS) void ff_x_inv_kernel(FusedGrid g, const
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * FF_ROWS;
-  for (int k = tid; k < M; k += FF_THREADS) tw[k] = tw1[k];
-  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_THREADS) {
+  for (int k = tid; k < M; k += FF_XTHREADS) tw[k] = tw1[k];
+  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_XTHREADS) {
     const int r = e / (M + 1), k = e - r * (M + 1);
     const int64_t row = row0 + r;
     Xs[e] = row < nrows ? X[row * g.nhp + k] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   // Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})), stored at the bit-reversed position
-  for (int e = tid; e < FF_ROWS * M; e += FF_THREADS) {
+  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
     const int r = e / M, k = e - r * M;
     const double2* xs = Xs + r * (M + 1);
     const double2 a = xs[k], b = cconj(xs[M - k]);
@@ -227,8 +234,8 @@ __global__ __launch_bounds__(FF_THREADS) void ff_x_inv_kernel(FusedGrid g, const
     Z[r * MP + lphys(brev_bits(k, logM))] = make_double2(a.x + b.x - d.y, a.y + b.y + d.x);
   }
   __syncthreads();
-  lds_fft_dit_inv(Z, logM, MP, FF_ROWS, tw, 2, tid);
-  for (int e = tid; e < FF_ROWS * M; e += FF_THREADS) {
+  lds_fft_dit_inv<FF_XTHREADS>(Z, logM, MP, FF_ROWS, tw, 2, tid);
+  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
     const int r = e / M, nidx = e - r * M;
     const int64_t row = row0 + r;
     if (row < nrows) reinterpret_cast<double2*>(out)[row * M + nidx] = Z[r * MP + lphys(nidx)];  // (u[2n], u[2n+1])
@@ -250,23 +257,26 @@ __global__ __launch_bounds__(FF_THREADS) void ff_axis_kernel(FusedGrid g, int lo
   double2* tw = sm;
   double2* buf = sm + (L >> 1);
   const int tid = threadIdx.x;
-  const int t = blockIdx.x % g.ntx;
-  const int o = blockIdx.x / g.ntx;
+  // block b -> tile: within every group of 16 blocks, blocks x and x + 8 (same XCD) take tiles 2x and 2x + 1
+  const int bb = blockIdx.x;
+  const int tile = (bb & ~15) + ((bb & 7) << 1) + ((bb >> 3) & 1);
+  const int t = tile % g.ntx;
+  const int o = tile / g.ntx;
   const int kx0 = t * FF_TX;
   double2* base = X + (int64_t)o * ostride + kx0;
   for (int k = tid; k < (L >> 1); k += FF_THREADS) tw[k] = twL[k];
   for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-    const int c = e & (FF_TX - 1), j = e >> 3;
+    const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
     buf[c * LP + lphys(j)] = base[(int64_t)j * lstride + c];  // columns kx >= nh of the padded pitch hold zeros
   }
   __syncthreads();
-  if (MODE == 0 || MODE == 2) lds_fft_dif(buf, logL, LP, FF_TX, tw, 1, tid);
+  if (MODE == 0 || MODE == 2) lds_fft_dif<FF_THREADS>(buf, logL, LP, FF_TX, tw, 1, tid);
   if (MODE == 2) {
     // element j of the bit-reversed line is frequency brev(j); Fh_tiled is stored in exactly this order:
     // Fh_tiled[((o * ntx + t) * L + j) * TX + c]
     const double* fh = Fh_tiled + ((int64_t)o * g.ntx + t) * L * FF_TX;
     for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-      const int c = e & (FF_TX - 1), j = e >> 3;
+      const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
       const double2 x = buf[c * LP + lphys(j)];
       const double f = fh[e];
       const double mag2 = x.x * x.x + x.y * x.y;
@@ -282,9 +292,9 @@ __global__ __launch_bounds__(FF_THREADS) void ff_axis_kernel(FusedGrid g, int lo
     }
     __syncthreads();
   }
-  if (MODE == 1 || MODE == 2) lds_fft_dit_inv(buf, logL, LP, FF_TX, tw, 1, tid);
+  if (MODE == 1 || MODE == 2) lds_fft_dit_inv<FF_THREADS>(buf, logL, LP, FF_TX, tw, 1, tid);
   for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-    const int c = e & (FF_TX - 1), j = e >> 3;
+    const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
     base[(int64_t)j * lstride + c] = buf[c * LP + lphys(j)];
   }
 }
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void ff_tile_fh_kernel(FusedGrid g, const doub
   const int64_t total = (int64_t)g.n2 * g.ntx * g.n3 * FF_TX;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int c = (int)(e & (FF_TX - 1));
-    int64_t r = e >> 3;
+    int64_t r = e >> FF_TX_LOG;
     const int zp = (int)(r % g.n3);
     r /= g.n3;
     const int t = (int)(r % g.ntx);

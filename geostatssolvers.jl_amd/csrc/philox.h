@@ -18,8 +18,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-    const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+    // one 32 x 32 -> 64 multiply (v_mad_u64_u32) gives both halves
+    const uint64_t p0 = (uint64_t)PHILOX_M0 * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)PHILOX_M1 * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += PHILOX_W0;
