@@ -23,7 +23,7 @@
 
 namespace gss {
 
-constexpr int FF_TX_LOG = 2;
+constexpr int FF_TX_LOG = 1;
 constexpr int FF_TX = 1 << FF_TX_LOG;  // lines per tile in the strided passes: 4 complex = 64 B per row; tiles 2u and
                                        // 2u + 1 (the two halves of a 128-B line) are given to workgroups b and b + 8,
                                        // which share an XCD and are dispatched together, so the L2 merges the halves
@@ -259,7 +259,8 @@ __global__ __launch_bounds__(FF_THREADS) void ff_axis_kernel(FusedGrid g, int lo
   const int tid = threadIdx.x;
   // block b -> tile: within every group of 16 blocks, blocks x and x + 8 (same XCD) take tiles 2x and 2x + 1
   const int bb = blockIdx.x;
-  const int tile = (bb & ~15) + ((bb & 7) << 1) + ((bb >> 3) & 1);
+  constexpr int GL = 3 - FF_TX_LOG;  // log2 of the tiles that share one 128-B line
+  const int tile = (bb & ~((8 << GL) - 1)) + ((bb & 7) << GL) + ((bb >> 3) & ((1 << GL) - 1));
   const int t = tile % g.ntx;
   const int o = tile / g.ntx;
   const int kx0 = t * FF_TX;
