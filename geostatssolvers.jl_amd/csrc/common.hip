@@ -156,18 +156,45 @@ int32_t Staged::back(void* dst, size_t bytes, int32_t mem, hipStream_t s) {
   return GSS_OK;
 }
 
+static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
+  *mscale = 0.0;
+  switch (kind) {
+    case GSS_VG_GAUSSIAN:
+    case GSS_VG_EXPONENTIAL:
+    case GSS_VG_SPHERICAL:
+    case GSS_VG_CUBIC:
+    case GSS_VG_PENTASPHERICAL:
+      *out_kind = kind;
+      return GSS_OK;
+    case GSS_VG_MATERN:
+      if (nu == 0.5) *out_kind = VG_MATERN12;
+      else if (nu == 1.5) *out_kind = VG_MATERN32;
+      else if (nu == 2.5) *out_kind = VG_MATERN52;
+      else {
+        set_error("Matern order nu=%g is not available on the device (0.5, 1.5, 2.5 only)", nu);
+        return GSS_ERR_UNSUPPORTED;
+      }
+      *mscale = std::sqrt(2.0 * nu) * 3.0;
+      return GSS_OK;
+    default:
+      set_error("unknown variogram kind %d", kind);
+      return GSS_ERR_INVALID;
+  }
+}
+
 int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
   GSS_REQUIRE(vg != nullptr, "variogram is NULL");
   GSS_REQUIRE(vg->dim >= 1 && vg->dim <= 3, "variogram dim %d outside 1..3", vg->dim);
   GSS_REQUIRE(vg->sill > 0.0 && vg->nugget >= 0.0 && vg->nugget <= vg->sill, "invalid sill/nugget %g/%g",
               vg->sill, vg->nugget);
+  GSS_REQUIRE(vg->nextra >= 0 && vg->nextra <= 3, "nested variogram with %d extra structures (at most 3)", vg->nextra);
   VgDev v;
-  v.kind = vg->kind;
+  std::memset(&v, 0, sizeof(v));
   v.dim = vg->dim;
   v.aniso = vg->aniso ? 1 : 0;
+  v.nextra = vg->nextra;
   v.sill = vg->sill;
   v.cs = vg->sill - vg->nugget;
-  v.mscale = 0.0;
   for (int k = 0; k < 3; ++k) v.ir[k] = 1.0;
   if (v.aniso) {
     for (int k = 0; k < vg->dim; ++k) {
@@ -179,26 +206,25 @@ int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
     GSS_REQUIRE(vg->range > 0.0, "variogram range must be positive (got %g)", vg->range);
     v.inv_range = 1.0 / vg->range;
   }
-  switch (vg->kind) {
-    case GSS_VG_GAUSSIAN:
-    case GSS_VG_EXPONENTIAL:
-    case GSS_VG_SPHERICAL:
-    case GSS_VG_CUBIC:
-    case GSS_VG_PENTASPHERICAL:
-      break;
-    case GSS_VG_MATERN:
-      if (vg->nu == 0.5) v.kind = VG_MATERN12;
-      else if (vg->nu == 1.5) v.kind = VG_MATERN32;
-      else if (vg->nu == 2.5) v.kind = VG_MATERN52;
-      else {
-        set_error("Matern order nu=%g is not available on the device (0.5, 1.5, 2.5 only)", vg->nu);
-        return GSS_ERR_UNSUPPORTED;
+  GSS_TRY(device_kind(vg->kind, vg->nu, &v.kind, &v.mscale));
+  for (int e = 0; e < vg->nextra; ++e) {
+    VgExtra& x = v.ex[e];
+    GSS_REQUIRE(vg->extra[e].sill > 0.0, "nested structure %d needs a positive sill contribution", e + 1);
+    x.cs = vg->extra[e].sill;
+    x.aniso = vg->extra[e].aniso ? 1 : 0;
+    for (int k = 0; k < 3; ++k) x.ir[k] = 1.0;
+    if (x.aniso) {
+      for (int k = 0; k < vg->dim; ++k) {
+        GSS_REQUIRE(vg->extra[e].inv_radii[k] > 0.0, "anisotropic ball needs positive radii");
+        x.ir[k] = vg->extra[e].inv_radii[k];
       }
-      v.mscale = std::sqrt(2.0 * vg->nu) * 3.0;
-      break;
-    default:
-      set_error("unknown variogram kind %d", vg->kind);
-      return GSS_ERR_INVALID;
+      x.inv_range = 1.0;
+    } else {
+      GSS_REQUIRE(vg->extra[e].range > 0.0, "variogram range must be positive (got %g)", vg->extra[e].range);
+      x.inv_range = 1.0 / vg->extra[e].range;
+    }
+    GSS_TRY(device_kind(vg->extra[e].kind, vg->extra[e].nu, &x.kind, &x.mscale));
+    v.sill += x.cs;
   }
   *out = v;
   return GSS_OK;

@@ -26,8 +26,7 @@ __global__ __launch_bounds__(256) void cov_pairwise_kernel(VgDev vg, const doubl
     double x[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) x[k] = a[i * DIM + k];
-    const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
-    out[i * ldo + j] = cov_from_d2(vg, d2);
+    out[i * ldo + j] = cov_pair<DIM>(vg, x, c);
   }
 }
 

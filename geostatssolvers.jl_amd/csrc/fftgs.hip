@@ -52,8 +52,7 @@ __global__ __launch_bounds__(256) void fftgs_cov_kernel(VgDev vg, GridSpec g, do
     const int64_t i1 = e % g.n1, i2 = (e / g.n1) % g.n2, i3 = e / (g.n1 * g.n2);
     double a[3] = {(double)(i1 - g.c1) * g.s1, (double)(i2 - g.c2) * g.s2, (double)(i3 - g.c3) * g.s3};
     const double zero[3] = {0.0, 0.0, 0.0};
-    const double d2 = sqdist_nofma<3>(a, zero, vg.ir, vg.aniso != 0);
-    C[e] = cov_from_d2(vg, d2);
+    C[e] = cov_pair<3>(vg, a, zero);
   }
 }
 
@@ -305,7 +304,10 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
   gss_variogram_t v3 = *vg;
   GSS_REQUIRE(vg->dim == ndim, "variogram dimension %d does not match the grid dimension %d", vg->dim, ndim);
   v3.dim = 3;  // lags of absent axes are zero
-  for (int k = ndim; k < 3; ++k) v3.inv_radii[k] = 1.0;
+  for (int k = ndim; k < 3; ++k) {
+    v3.inv_radii[k] = 1.0;
+    for (int e = 0; e < 3; ++e) v3.extra[e].inv_radii[k] = 1.0;
+  }
   gss_fftgs* h = new (std::nothrow) gss_fftgs();
   if (!h) return GSS_ERR_ALLOC;
   struct Guard {

@@ -89,15 +89,26 @@ inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 // ---------------------------------------------------------------------------------------------
 // variogram on device
 // ---------------------------------------------------------------------------------------------
+struct VgExtra {
+  int kind;
+  int aniso;
+  double cs;         // contribution (partial sill) of this structure
+  double inv_range;
+  double mscale;
+  double ir[3];
+};
+
 struct VgDev {
   int kind;      // GSS_VG_* ; MATERN split into 30/31/32 for nu = 1/2, 3/2, 5/2
   int dim;
   int aniso;
-  double sill;
-  double cs;         // sill - nugget
+  int nextra;        // additional nested structures
+  double sill;       // total sill (all structures + nugget)
+  double cs;         // contribution of the first structure
   double inv_range;  // 1 / range (1 when aniso)
   double mscale;     // Matern: sqrt(2 nu) * 3
   double ir[3];      // inverse radii (aniso) or 1
+  VgExtra ex[3];
 };
 enum { VG_MATERN12 = 30, VG_MATERN32 = 31, VG_MATERN52 = 32 };
 
@@ -118,56 +129,49 @@ __device__ __forceinline__ double sqdist_nofma(const double* a, const double* b,
   return acc;
 }
 
-// C(h) = sill - gamma(h) from the squared distance; evaluated as cs * g(h/range) for h > 0, which is
-// algebraically identical to sill - ((sill-nugget) f + nugget) and avoids the cancellation.
-__device__ __forceinline__ double cov_from_d2(const VgDev& v, double d2) {
-  if (d2 <= 0.0) return v.sill;
-  double g;
-  switch (v.kind) {
-    case GSS_VG_GAUSSIAN: {
-      double x2 = d2 * v.inv_range * v.inv_range;
-      g = exp(-3.0 * x2);
-      break;
-    }
-    case GSS_VG_EXPONENTIAL: {
-      double x = sqrt(d2) * v.inv_range;
-      g = exp(-3.0 * x);
-      break;
-    }
+// g(h) = 1 - f(h / range): normalised covariance shape of one structure, from the squared distance (d2 > 0)
+__device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range, double mscale) {
+  switch (kind) {
+    case GSS_VG_GAUSSIAN: return exp(-3.0 * (d2 * inv_range * inv_range));
+    case GSS_VG_EXPONENTIAL: return exp(-3.0 * (sqrt(d2) * inv_range));
     case GSS_VG_SPHERICAL: {
-      double x = sqrt(d2) * v.inv_range;
-      g = x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
-      break;
+      const double x = sqrt(d2) * inv_range;
+      return x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
     }
-    case VG_MATERN12: {
-      double d = v.mscale * (sqrt(d2) * v.inv_range);
-      g = exp(-d);
-      break;
-    }
+    case VG_MATERN12: return exp(-(mscale * (sqrt(d2) * inv_range)));
     case VG_MATERN32: {
-      double d = v.mscale * (sqrt(d2) * v.inv_range);
-      g = (1.0 + d) * exp(-d);
-      break;
+      const double d = mscale * (sqrt(d2) * inv_range);
+      return (1.0 + d) * exp(-d);
     }
     case VG_MATERN52: {
-      double d = v.mscale * (sqrt(d2) * v.inv_range);
-      g = (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
-      break;
+      const double d = mscale * (sqrt(d2) * inv_range);
+      return (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
     }
     case GSS_VG_CUBIC: {
-      double x = sqrt(d2) * v.inv_range;
-      double x2 = x * x, x3 = x2 * x;
-      g = x < 1.0 ? 1.0 - (7.0 * x2 - 8.75 * x3 + 3.5 * x3 * x2 - 0.75 * x3 * x3 * x) : 0.0;
-      break;
+      const double x = sqrt(d2) * inv_range;
+      const double x2 = x * x, x3 = x2 * x;
+      return x < 1.0 ? 1.0 - (7.0 * x2 - 8.75 * x3 + 3.5 * x3 * x2 - 0.75 * x3 * x3 * x) : 0.0;
     }
     default: {  // GSS_VG_PENTASPHERICAL
-      double x = sqrt(d2) * v.inv_range;
-      double x2 = x * x, x3 = x2 * x;
-      g = x < 1.0 ? 1.0 - (1.875 * x - 1.25 * x3 + 0.375 * x3 * x2) : 0.0;
-      break;
+      const double x = sqrt(d2) * inv_range;
+      const double x2 = x * x, x3 = x2 * x;
+      return x < 1.0 ? 1.0 - (1.875 * x - 1.25 * x3 + 0.375 * x3 * x2) : 0.0;
     }
   }
-  return v.cs * g;
+}
+
+// C(a, b) = sill - gamma(a, b).  Per structure C_i = c_i g_i(h_i) for h > 0, which is algebraically identical to
+// c_i - c_i f_i and avoids the cancellation; a zero lag returns the total sill (nugget included).
+template <int DIM>
+__device__ __forceinline__ double cov_pair(const VgDev& v, const double* a, const double* b) {
+  const double d2 = sqdist_nofma<DIM>(a, b, v.ir, v.aniso != 0);
+  if (d2 <= 0.0) return v.sill;  // positive radii: d2 == 0 iff the points coincide
+  double c = v.cs * vg_shape(v.kind, d2, v.inv_range, v.mscale);
+  for (int e = 0; e < v.nextra; ++e) {
+    const double d2e = sqdist_nofma<DIM>(a, b, v.ex[e].ir, v.ex[e].aniso != 0);
+    c += v.ex[e].cs * vg_shape(v.ex[e].kind, d2e, v.ex[e].inv_range, v.ex[e].mscale);
+  }
+  return c;
 }
 
 // ---------------------------------------------------------------------------------------------

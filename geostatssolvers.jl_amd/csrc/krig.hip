@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* _
     double x[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
-    const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
-    const double cv = cov_from_d2(vg, d2);
+    const double cv = cov_pair<DIM>(vg, x, c);
     *rp = cv;
     rp += ldr;
     acc = fma(wd[j], cv, acc);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
 #pragma unroll
   for (int r = 0; r < LMAX_RHS; ++r) b[r] = 0.0;
   if (act) {
-    b[0] = cov_from_d2(vg, sqdist_nofma<DIM>(xj, c0, vg.ir, vg.aniso != 0));
+    b[0] = cov_pair<DIM>(vg, xj, c0);
     double zz = z[nj];
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
     b[1] = zz;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
       xi[a] = nx[i][a];
       xc[a] = nx[c][a];
     }
-    Lp[e] = cov_from_d2(vg, sqdist_nofma<DIM>(xi, xc, vg.ir, vg.aniso != 0));
+    Lp[e] = cov_pair<DIM>(vg, xi, xc);
   }
   __syncthreads();
 

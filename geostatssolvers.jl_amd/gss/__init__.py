@@ -9,6 +9,6 @@ from .geo import (CartesianGrid, DomainView, Ensemble, GeoTable, PointSet, asarr
 from .problems import EstimationProblem, SimulationProblem
 from .solvers import FFTGS, LUGS, KrigingSolver, kriging_ui, searcher_ui, solve
 from .variograms import (CubicVariogram, ExponentialVariogram, GaussianVariogram, MaternVariogram, MetricBall,
-                         PentasphericalVariogram, SphericalVariogram)
+                         NestedVariogram, PentasphericalVariogram, SphericalVariogram)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -31,10 +31,16 @@ class GSSError(RuntimeError):
         self.code = code
 
 
+class VariogramExtra(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("aniso", C.c_int32), ("sill", C.c_double), ("range", C.c_double),
+                ("nu", C.c_double), ("inv_radii", C.c_double * 3)]
+
+
 class Variogram(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("sill", C.c_double), ("nugget", C.c_double),
                 ("range", C.c_double), ("nu", C.c_double), ("aniso", C.c_int32), ("reserved", C.c_int32),
-                ("inv_radii", C.c_double * 3)]
+                ("inv_radii", C.c_double * 3), ("nextra", C.c_int32), ("reserved2", C.c_int32),
+                ("extra", VariogramExtra * 3)]
 
 
 _p = C.c_void_p
@@ -153,7 +159,8 @@ def current_stream():
 _KINDS = {"gaussian": 0, "exponential": 1, "spherical": 2, "matern": 3, "cubic": 4, "pentaspherical": 5}
 
 
-def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0, radii=None) -> Variogram:
+def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0, radii=None, extras=()) -> Variogram:
+    """`extras`: further nested structures as (kind, contribution, range, nu, radii) tuples (at most 3)."""
     v = Variogram()
     v.kind = _KINDS[kind]
     v.dim = int(dim)
@@ -168,6 +175,20 @@ def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0,
         v.range = 1.0
         for k, r in enumerate(radii):
             v.inv_radii[k] = 1.0 / float(r)
+    if len(extras) > 3:
+        raise ValueError("at most 4 nested structures are supported on the device")
+    v.nextra = len(extras)
+    for e, (ekind, esill, erange, enu, eradii) in enumerate(extras):
+        x = v.extra[e]
+        x.kind, x.aniso, x.sill, x.range, x.nu = _KINDS[ekind], 0, float(esill), float(erange), float(enu)
+        for k in (0, 1, 2):
+            x.inv_radii[k] = 1.0
+        if eradii is not None:
+            if len(eradii) != dim:
+                raise ValueError(f"anisotropic ball has {len(eradii)} radii but the domain is {dim}-D")
+            x.aniso, x.range = 1, 1.0
+            for k, r in enumerate(eradii):
+                x.inv_radii[k] = 1.0 / float(r)
     return v
 
 

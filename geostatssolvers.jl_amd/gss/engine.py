@@ -19,6 +19,15 @@ SK, OK, UK, EDK = 0, 1, 2, 3
 
 
 def _vg_struct(vg, dim):
+    if getattr(vg, "kind", None) == "nested":
+        # first structure carries the total nugget; every structure contributes c_i (sill_i - nugget_i)
+        terms = [(w, m) for w, m in vg.terms if w * (m.sill - m.nugget) > 0.0]
+        if not terms:
+            raise ValueError("nested variogram without a structured (non-nugget) component")
+        w0, m0 = terms[0]
+        nug = vg.nugget
+        extras = [(m.kind, w * (m.sill - m.nugget), m.range, m.nu, m.radii) for w, m in terms[1:]]
+        return make_variogram(m0.kind, dim, w0 * (m0.sill - m0.nugget) + nug, nug, m0.range, m0.nu, m0.radii, extras)
     return make_variogram(vg.kind, dim, vg.sill, vg.nugget, vg.range, vg.nu, vg.radii)
 
 

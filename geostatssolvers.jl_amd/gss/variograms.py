@@ -35,6 +35,42 @@ class VariogramModel:
     def isstationary(self):
         return True
 
+    # gamma1 + gamma2 and c * gamma build a NestedVariogram ([DEP] Variography)
+    def __add__(self, other):
+        return NestedVariogram(((1.0, self),)) + other
+
+    def __rmul__(self, c):
+        return NestedVariogram(((float(c), self),))
+
+    __mul__ = __rmul__
+
+
+@dataclass(frozen=True)
+class NestedVariogram:
+    """gamma = sum_i c_i gamma_i; sill and nugget are the weighted sums of the structures'."""
+    terms: Tuple[Tuple[float, VariogramModel], ...]
+    kind: str = "nested"
+
+    def __add__(self, other):
+        o = other.terms if isinstance(other, NestedVariogram) else ((1.0, other),)
+        return NestedVariogram(self.terms + tuple(o))
+
+    def __rmul__(self, c):
+        return NestedVariogram(tuple((float(c) * w, m) for w, m in self.terms))
+
+    __mul__ = __rmul__
+
+    @property
+    def sill(self):
+        return sum(w * m.sill for w, m in self.terms)
+
+    @property
+    def nugget(self):
+        return sum(w * m.nugget for w, m in self.terms)
+
+    def isstationary(self):
+        return True
+
 
 def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=None):
     radii = None

@@ -28,6 +28,15 @@ const GSS_MEM_HOST = Int32(0)
 const GSS_KRIG_NO_FACTOR = Int32(1)
 
 # ---- C structs ---------------------------------------------------------------------------
+struct GssVgExtra              # one additional nested structure of gss_variogram_t
+  kind::Int32
+  aniso::Int32
+  sill::Float64
+  range::Float64
+  nu::Float64
+  inv_radii::NTuple{3,Float64}
+end
+
 struct GssVariogram            # gss_variogram_t
   kind::Int32
   dim::Int32
@@ -38,7 +47,12 @@ struct GssVariogram            # gss_variogram_t
   aniso::Int32
   reserved::Int32
   inv_radii::NTuple{3,Float64}
+  nextra::Int32
+  reserved2::Int32
+  extra::NTuple{3,GssVgExtra}
 end
+
+const NOEXTRA = GssVgExtra(Int32(0), Int32(0), 0.0, 1.0, 1.0, (1.0, 1.0, 1.0))
 
 function check(code::Int32)
   code == 0 && return nothing
@@ -57,15 +71,34 @@ vgkind(::MaternVariogram) = Int32(3)
 vgkind(::CubicVariogram) = Int32(4)
 vgkind(::PentasphericalVariogram) = Int32(5)
 
-function cvariogram(γ, dim)
-  isstationary(γ) || throw(ArgumentError("variogram model must be stationary"))   # fft.jl:91-93, lu.jl:110
-  ball = metricball(γ)
-  rs = radii(ball)
+function structure(γ)            # (kind, aniso, range, nu, inv_radii) of one basic model
+  rs = radii(metricball(γ))
   aniso = length(rs) > 1
   ir = ntuple(i -> aniso && i <= length(rs) ? 1.0 / ustrip(rs[i]) : 1.0, 3)
   ν = γ isa MaternVariogram ? Float64(γ.order) : 1.0
-  GssVariogram(vgkind(γ), Int32(dim), Float64(sill(γ)), Float64(nugget(γ)),
-               aniso ? 1.0 : Float64(ustrip(range(γ))), ν, Int32(aniso), Int32(0), ir)
+  (vgkind(γ), Int32(aniso), aniso ? 1.0 : Float64(ustrip(range(γ))), ν, ir)
+end
+
+function cvariogram(γ, dim)
+  isstationary(γ) || throw(ArgumentError("variogram model must be stationary"))   # fft.jl:91-93, lu.jl:110
+  if γ isa NestedVariogram       # gamma = sum c_i gamma_i: first structure carries the total nugget
+    cs, γs = γ.cs, γ.γs
+    keep = [i for i in eachindex(γs) if cs[i] * (sill(γs[i]) - nugget(γs[i])) > 0]
+    length(keep) <= 4 || throw(ArgumentError("at most 4 nested structures are supported on the device"))
+    k0, a0, r0, ν0, ir0 = structure(γs[keep[1]])
+    nug = Float64(nugget(γ))
+    extras = ntuple(3) do j
+      j + 1 > length(keep) && return NOEXTRA
+      i = keep[j+1]
+      k, a, r, ν, ir = structure(γs[i])
+      GssVgExtra(k, a, Float64(cs[i] * (sill(γs[i]) - nugget(γs[i]))), r, ν, ir)
+    end
+    c0 = Float64(cs[keep[1]] * (sill(γs[keep[1]]) - nugget(γs[keep[1]])))
+    return GssVariogram(k0, Int32(dim), c0 + nug, nug, r0, ν0, a0, Int32(0), ir0, Int32(length(keep) - 1), Int32(0), extras)
+  end
+  k, a, r, ν, ir = structure(γ)
+  GssVariogram(k, Int32(dim), Float64(sill(γ)), Float64(nugget(γ)), r, ν, a, Int32(0), ir, Int32(0), Int32(0),
+               (NOEXTRA, NOEXTRA, NOEXTRA))
 end
 
 # point-major coordinates: a d x n Julia matrix is already in the layout the C-ABI wants

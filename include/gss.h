@@ -66,6 +66,19 @@ typedef struct gss_variogram {
   int32_t aniso;       /* 1: Mahalanobis distance with inv_radii (MetricBall((a,b))) */
   int32_t reserved;
   double inv_radii[3]; /* 1 / ball radii                                             */
+  /* nested models gamma = sum_i c_i gamma_i ([DEP] Variography NestedVariogram): the fields above describe the
+   * first structure (its `sill` includes the TOTAL nugget), each extra structure adds `sill` = its own contribution
+   * with its own kind / range / anisotropy.  Total sill = sill + sum extra[i].sill.                              */
+  int32_t nextra;      /* 0..3 */
+  int32_t reserved2;
+  struct {
+    int32_t kind;
+    int32_t aniso;
+    double sill;
+    double range;
+    double nu;
+    double inv_radii[3];
+  } extra[3];
 } gss_variogram_t;
 
 /* ---- kriging variant: replaces ui.jl:40-50 (kriging_ui) model choice ---------------------- */

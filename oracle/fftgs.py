@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import kriging, philox
-from .variogram import Variogram, cov_h, distance, isstationary
+from .variogram import Variogram, cov_pairwise, isstationary
 
 
 def grid_centroids(dims: Sequence[int], origin=None, spacing=None) -> np.ndarray:
@@ -50,7 +50,7 @@ def preprocess(vg: Variogram, dims: Sequence[int], origin=None, spacing=None, me
     cent = grid_centroids(dims, origin, spacing)               # fft.jl:97
     center = tuple(x // 2 for x in dims)                        # fft.jl:69 (1-based CartesianIndex)
     cindex = np.ravel_multi_index(tuple(c - 1 for c in center)[::-1], dims[::-1])  # fft.jl:70
-    cs = cov_h(vg, distance(vg, cent[cindex:cindex + 1], cent))[0]   # fft.jl:98
+    cs = cov_pairwise(vg, cent[cindex:cindex + 1], cent)[0]          # fft.jl:98
     C = cs.reshape(dims[::-1])                                  # fft.jl:99
     F = np.sqrt(np.abs(np.fft.fftn(np.fft.fftshift(C))))        # fft.jl:102
     F.flat[0] = 0.0                                             # fft.jl:103

@@ -50,7 +50,21 @@ class Variogram:
                 self.range = 1.0
 
 
-def isstationary(vg: Variogram) -> bool:
+@dataclass
+class Nested:
+    """[DEP] Variography NestedVariogram: gamma = sum_i c_i gamma_i (each structure keeps its own range / ball)."""
+    terms: Sequence  # of (coefficient, Variogram)
+
+    @property
+    def sill(self) -> float:
+        return float(sum(c * v.sill for c, v in self.terms))
+
+    @property
+    def nugget(self) -> float:
+        return float(sum(c * v.nugget for c, v in self.terms))
+
+
+def isstationary(vg) -> bool:
     """All supported models have a finite sill (fft.jl:91, lu.jl:110)."""
     return True
 
@@ -108,12 +122,14 @@ def cov_h(vg: Variogram, h: np.ndarray) -> np.ndarray:
     return vg.sill - gamma_h(vg, h)
 
 
-def pairwise(vg: Variogram, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+def pairwise(vg, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
     """[DEP] Variography.pairwise(gamma, A[, B]) -> |A| x |B| matrix of gamma."""
     if b is None:
         b = a
+    if isinstance(vg, Nested):
+        return sum(c * pairwise(v, a, b) for c, v in vg.terms)
     return gamma_h(vg, distance(vg, a, b))
 
 
-def cov_pairwise(vg: Variogram, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+def cov_pairwise(vg, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
     return vg.sill - pairwise(vg, a, b)

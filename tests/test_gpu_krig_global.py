@@ -196,3 +196,40 @@ def test_edge_sizes_empty_domain_single_datum_large_system():
     rmu, rvar = K.exactsolve(K.OK, Variogram("matern", range=30.0, nu=1.5), x, z, x0)
     assert np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
     hb.close()
+
+
+def test_nested_variograms_all_paths():
+    """gamma = gamma1 + 2 gamma2 + 0.5 gamma3 with per-structure anisotropy: pairwise
+    covariance, global and moving-neighbourhood kriging, FFTGS spectrum and LUGS factor against the oracle."""
+    import gss
+    from gss.engine import FFTGSHandle, HipEngine, KrigHandle, LUGSHandle
+    from oracle import fftgs as OF, lugs as OL
+    from oracle.variogram import Nested
+    g = gss.SphericalVariogram(range=10.0, nugget=0.1) + 2.0 * gss.ExponentialVariogram(range=30.0) \
+        + 0.5 * gss.GaussianVariogram(gss.MetricBall((20.0, 5.0)))
+    o = Nested([(1.0, Variogram("spherical", range=10.0, nugget=0.1)), (2.0, Variogram("exponential", range=30.0)),
+                (0.5, Variogram("gaussian", radii=(20.0, 5.0)))])
+    rng = np.random.default_rng(31)
+    x = rng.uniform(0, 60, (150, 2))
+    z = rng.normal(size=150)
+    x0 = rng.uniform(0, 60, (400, 2))
+    x0[:3] = x[:3]
+    got = HipEngine.cov_pairwise(g, x, x0)
+    assert np.max(np.abs(got - cov_pairwise(o, x, x0))) < 2e-14 and abs(got[0, 0] - 3.5) < 1e-15
+    h = KrigHandle(g, K.OK, x, z)
+    mu, var, _ = h.predict_global(x0)
+    rmu, rvar = K.exactsolve(K.OK, o, x, z, x0)
+    assert np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    hl = KrigHandle(g, K.UK, x, z, degree=1, factor=False)
+    mu, var, st, idx, _ = hl.predict_knn(x0, 12, return_idx=True)
+    rmu, rvar, rst, ridx, _ = K.approxsolve(K.UK, o, x, z, x0, 12, degree=1, return_idx=True)
+    assert np.array_equal(idx, ridx) and np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    f = FFTGSHandle(g, (32, 24), mean=0.0)
+    pre = OF.preprocess(o, (32, 24))
+    assert np.max(np.abs(f.spectrum() - pre.F.ravel())) < 1e-11 * pre.F.max()
+    assert np.max(np.abs(f.realize(3, 0, 1) - OF.realize(pre, 3, 0, 1))) < 1e-8
+    cent = OF.grid_centroids((12, 10))
+    lh = LUGSHandle(g, cent, [3, 40], [0.5, -0.5])
+    p = OL.preprocess(o, cent, cent[[3, 40]], [0.5, -0.5])
+    L22, d2 = lh.factor()
+    assert np.max(np.abs(L22 - p.L22)) < 1e-9 and np.max(np.abs(d2 - p.d2)) < 1e-9

@@ -177,3 +177,19 @@ def test_lugs_invariants():
     y1, w1 = lugs.realize(pu, 9, 0, 4000)
     y2, w2 = lugs.realize(pu, 9, 0, 4000, var_index=1, rho=0.95, w1=w1)
     assert abs(np.corrcoef(y1[:, 3], y2[:, 3])[0, 1] - 0.95) < 0.02
+
+
+def test_nested_variogram_is_the_weighted_sum():
+    from oracle.variogram import Nested
+    a = Variogram("spherical", range=10.0, nugget=0.1)
+    b = Variogram("exponential", range=30.0, radii=None)
+    c = Variogram("gaussian", radii=(20.0, 5.0))
+    nv = Nested([(1.0, a), (2.0, b), (0.5, c)])
+    assert abs(nv.sill - 3.5) < 1e-15 and abs(nv.nugget - 0.1) < 1e-15
+    x = RNG.uniform(0, 40, (7, 2))
+    y = RNG.uniform(0, 40, (9, 2))
+    y[0] = x[0]
+    ref = cov_pairwise(a, x, y) + 2.0 * cov_pairwise(b, x, y) + 0.5 * cov_pairwise(c, x, y)
+    assert np.allclose(cov_pairwise(nv, x, y), ref, atol=1e-15) and abs(cov_pairwise(nv, x, y)[0, 0] - 3.5) < 1e-15
+    mu, var = K.exactsolve(K.OK, nv, x, RNG.normal(size=7), x)
+    assert np.all(var < 1e-9)                                    # still exact at the data (zero lag = total sill)
