@@ -206,6 +206,20 @@ int32_t cov_pairwise_dev(const VgDev& vg, const double* a, int64_t na, const dou
                          int64_t ldo, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
+// neighbour search (knn.hip)
+// ---------------------------------------------------------------------------------------------
+struct KnnIndex {
+  DevBuf xs, perm, lo, hi;  // Morton-sorted coordinates (n x dim), original indices, batch box corners (nb x dim)
+  int64_t n = 0;
+  int nb = 0, dim = 0;
+};
+int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
+int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
+                           const double* inv_radii_host, int* idx, int* count, hipStream_t s);
+int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
+                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
 // noise (noise.hip)
 // ---------------------------------------------------------------------------------------------
 int32_t philox_uniform_dev(uint64_t seed, int64_t real, int64_t n, double* out, int64_t ld_pad_n1, int64_t n1,

@@ -13,7 +13,11 @@
 // one ballot each, and only qualifying candidates pay for an insertion (ballot + lane shift).
 #include "gss_internal.h"
 
+#include <algorithm>
 #include <climits>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 
 namespace gss {
 
@@ -115,12 +119,237 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pruned search.  The data are put in Morton order once (host, O(n log n), like the KD-tree build the reference
+// pays in Meshes/NearestNeighbors) and cut into batches of 64 consecutive points with bounding boxes.  One wave
+// owns one query: lane b first bounds the distance to batch b (min squared distance to its box, accumulated with
+// the same rounded operations as the point distance, hence never larger than the distance to any point inside);
+// batches are then visited nearest box first for the seed and in Morton order afterwards, and a batch whose bound
+// exceeds the current k-th distance is skipped.  Results are identical to the brute-force kernel: the ranking
+// key is still (d2, original index).
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t spread_bits(uint32_t v, int dim) {
+  // interleave the low 10 bits of v with dim-1 zero bits between consecutive bits
+  uint32_t r = 0;
+  for (int b = 0; b < 10; ++b) r |= ((v >> b) & 1u) << (b * dim);
+  return r;
+}
+
+int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, hipStream_t s) {
+  std::vector<double> lo(dim, 0.0), hi(dim, 0.0);
+  for (int a = 0; a < dim; ++a) lo[a] = hi[a] = xhost[a];
+  for (int64_t i = 1; i < n; ++i)
+    for (int a = 0; a < dim; ++a) {
+      const double v = xhost[i * dim + a];
+      lo[a] = v < lo[a] ? v : lo[a];
+      hi[a] = v > hi[a] ? v : hi[a];
+    }
+  std::vector<std::pair<uint32_t, int32_t>> key((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t code = 0;
+    for (int a = 0; a < dim; ++a) {
+      const double ext = hi[a] - lo[a];
+      const double u = ext > 0.0 ? (xhost[i * dim + a] - lo[a]) / ext : 0.0;
+      uint32_t q = (uint32_t)(u * 1023.0);
+      if (q > 1023u) q = 1023u;
+      code |= spread_bits(q, dim) << a;
+    }
+    key[(size_t)i] = {code, (int32_t)i};
+  }
+  std::sort(key.begin(), key.end());
+  const int nb = (int)((n + 63) / 64);
+  std::vector<double> xs((size_t)(n * dim)), blo((size_t)nb * dim), bhi((size_t)nb * dim);
+  std::vector<int32_t> perm((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t o = key[(size_t)i].second;
+    perm[(size_t)i] = o;
+    for (int a = 0; a < dim; ++a) xs[(size_t)(i * dim + a)] = xhost[(int64_t)o * dim + a];
+  }
+  for (int b = 0; b < nb; ++b) {
+    const int64_t j0 = (int64_t)b * 64, j1 = j0 + 64 < n ? j0 + 64 : n;
+    for (int a = 0; a < dim; ++a) {
+      double l = xs[(size_t)(j0 * dim + a)], h = l;
+      for (int64_t j = j0 + 1; j < j1; ++j) {
+        const double v = xs[(size_t)(j * dim + a)];
+        l = v < l ? v : l;
+        h = v > h ? v : h;
+      }
+      blo[(size_t)b * dim + a] = l;
+      bhi[(size_t)b * dim + a] = h;
+    }
+  }
+  GSS_TRY(ix->xs.alloc(sizeof(double) * xs.size()));
+  GSS_TRY(ix->perm.alloc(sizeof(int32_t) * perm.size()));
+  GSS_TRY(ix->lo.alloc(sizeof(double) * blo.size()));
+  GSS_TRY(ix->hi.alloc(sizeof(double) * bhi.size()));
+  GSS_HIP(hipMemcpyAsync(ix->xs.p, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(ix->perm.p, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(ix->lo.p, blo.data(), sizeof(double) * blo.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(ix->hi.p, bhi.data(), sizeof(double) * bhi.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+  ix->n = n;
+  ix->nb = nb;
+  ix->dim = dim;
+  return GSS_OK;
+}
+
+int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s) {
+  std::vector<double> xh((size_t)(n * dim));
+  GSS_HIP(hipMemcpyAsync(xh.data(), xdev, sizeof(double) * xh.size(), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return knn_index_build(xh.data(), n, dim, ix, s);
+}
+
+// lower bound of sqdist_nofma(point in box, q): same operation order, every step monotone in |t|
+template <int DIM>
+__device__ __forceinline__ double box_sqdist_nofma(const double* lo, const double* hi, const double* q,
+                                                   const double* ir, bool aniso) {
+#pragma clang fp contract(off)
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const double a = lo[k] - q[k], b = q[k] - hi[k];
+    double t = a > b ? a : b;
+    t = t > 0.0 ? t : 0.0;
+    if (aniso) t = t * ir[k];
+    const double tt = t * t;
+    acc = acc + tt;
+  }
+  return acc;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restrict__ xs, const int* __restrict__ perm,
+                                                         const double* __restrict__ blo, const double* __restrict__ bhi,
+                                                         int n, int nb, const double* __restrict__ centers, int64_t m,
+                                                         int k, double r2, int use_ball, int aniso, double ir0,
+                                                         double ir1, double ir2, int* __restrict__ idx_out,
+                                                         int* __restrict__ count_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= m) return;  // whole wave
+  const double ir[3] = {ir0, ir1, ir2};
+  double qc[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = centers[p * DIM + a];
+  const double INF = __builtin_huge_val();
+  double ld = INF;   // lane l: l-th nearest so far (INF / INT_MAX = empty)
+  int li = INT_MAX;
+
+  for (int c0 = 0; c0 < nb; c0 += 64) {
+    const int b = c0 + lane;
+    double dmin = INF;
+    if (b < nb) {
+      double lo[DIM], hi[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        lo[a] = blo[b * DIM + a];
+        hi[a] = bhi[b * DIM + a];
+      }
+      dmin = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
+    }
+    bool done = !(b < nb);
+    // seed: nearest box of this chunk first (ties: lowest lane), so that tau is tight before the sweep
+    double best = dmin;
+    int bl = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(best, off);
+      const int ol = __shfl_xor(bl, off);
+      if (od < best || (od == best && ol < bl)) {
+        best = od;
+        bl = ol;
+      }
+    }
+    bool seeded = false;
+    while (true) {
+      // current k-th best key, re-read from the list (lane k - 1) whenever it may have changed
+      double tau_d = readlane_f64(ld, k - 1);
+      int tau_i = __builtin_amdgcn_readlane(li, k - 1);
+      const bool cand = !done && dmin <= tau_d && (!use_ball || dmin <= r2);
+      const unsigned long long mask = __ballot(cand);
+      if (!mask) break;
+      int pick = __builtin_ctzll(mask);
+      if (!seeded) {
+        seeded = true;
+        if ((mask >> bl) & 1ull) pick = bl;
+      }
+      if (lane == pick) done = true;
+      const int j = (c0 + pick) * 64 + lane;
+      const bool valid = j < n;
+      double c[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
+      const int oidx = valid ? perm[j] : INT_MAX;
+      const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);
+      const bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
+      unsigned long long qm = __ballot(qual);
+      while (qm) {
+        const int src = __builtin_ctzll(qm);
+        qm &= qm - 1;
+        const double cd = readlane_f64(d2, src);
+        const int ci = __builtin_amdgcn_readlane(oidx, src);
+        if (!key_less(cd, ci, tau_d, tau_i)) continue;
+        const int pos = __popcll(__ballot(key_less(ld, li, cd, ci)));
+        const double up_d = __shfl_up(ld, 1);
+        const int up_i = __shfl_up(li, 1);
+        if (lane > pos) {
+          ld = up_d;
+          li = up_i;
+        } else if (lane == pos) {
+          ld = cd;
+          li = ci;
+        }
+        tau_d = readlane_f64(ld, k - 1);
+        tau_i = __builtin_amdgcn_readlane(li, k - 1);
+      }
+    }
+  }
+  const bool has = lane < k && li != INT_MAX;
+  const int cnt = __popcll(__ballot(has));
+  if (lane < k) idx_out[p * k + lane] = has ? li : -1;
+  if (lane == 0 && count_out) count_out[p] = cnt;
+}
+
+int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
+                           const double* inv_radii_host, int* idx, int* count, hipStream_t s) {
+  GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
+                                 "(use the global neighbourhood beyond that)", k);
+  if (m <= 0) return GSS_OK;
+  const int use_ball = (radius >= 0.0 || inv_radii_host != nullptr) ? 1 : 0;
+  const int aniso = inv_radii_host != nullptr ? 1 : 0;
+  const double r2 = aniso ? 1.0 : radius * radius;
+  double ir[3] = {1.0, 1.0, 1.0};
+  if (aniso)
+    for (int a = 0; a < ix.dim; ++a) ir[a] = inv_radii_host[a];
+  dim3 grid((unsigned)((m + 3) / 4));
+#define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), (int)ix.n, ix.nb, \
+                     centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], idx, count
+  switch (ix.dim) {
+    case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    case 2: hipLaunchKernelGGL((knn_pruned_kernel<2>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    default: hipLaunchKernelGGL((knn_pruned_kernel<3>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+  }
+#undef GSS_KNN_ARGS
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+// brute-force reference path (GSS_KNN_BRUTE=1), kept for A/B checks
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s) {
   GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
                                  "(use the global neighbourhood beyond that)", k);
   GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3, "knn: bad sizes");
   if (m <= 0) return GSS_OK;
+  const char* e = std::getenv("GSS_KNN_BRUTE");
+  if (!(e && e[0] == '1')) {
+    KnnIndex ix;
+    GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
+    GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s));
+    GSS_HIP(hipStreamSynchronize(s));  // the index is released on return
+    return GSS_OK;
+  }
   const int use_ball = (radius >= 0.0 || inv_radii_host != nullptr) ? 1 : 0;
   const int aniso = inv_radii_host != nullptr ? 1 : 0;
   const double r2 = aniso ? 1.0 : radius * radius;

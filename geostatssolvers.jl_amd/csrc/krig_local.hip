@@ -15,13 +15,11 @@
 #include "gss_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace gss {
-
-int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
-                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s);
 
 constexpr int LMAX_K = 64;
 constexpr int LMAX_NC = 10;
@@ -140,8 +138,17 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
     const bool mine = lane >= j && lane < cnt;
     if (mine) {
       const double* rowj = Lp + tri(j);
-      acc = rowi[j];
-      for (int c = 0; c < j; ++c) acc = fma(-rowi[c], rowj[c], acc);
+      // four partial sums: shorter dependency chains and a quarter of the loop overhead
+      double a0 = rowi[j], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int c = 0;
+      for (; c + 4 <= j; c += 4) {
+        a0 = fma(-rowi[c], rowj[c], a0);
+        a1 = fma(-rowi[c + 1], rowj[c + 1], a1);
+        a2 = fma(-rowi[c + 2], rowj[c + 2], a2);
+        a3 = fma(-rowi[c + 3], rowj[c + 3], a3);
+      }
+      for (; c < j; ++c) a0 = fma(-rowi[c], rowj[c], a0);
+      acc = (a0 + a1) + (a2 + a3);
     }
     const double d = __shfl(acc, j);
     if (!(d > 0.0)) {
@@ -282,6 +289,10 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   sp.sk_mean = sk_mean;
 
   const int64_t chunk = 1 << 20;
+  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
+  const char* brute = std::getenv("GSS_KNN_BRUTE");
+  const bool use_index = !(brute && brute[0] == '1');
+  if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s, st_s;
   if (!idx_out) GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
   if (!count_out) GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
@@ -293,7 +304,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     uint8_t* st = status ? status + off : st_s.as<uint8_t>();
     {
       ProfScope ps("knn", s);
-      GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
+      if (use_index) GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
+      else GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
     }
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
     ProfScope pl("krig_local", s);
@@ -313,7 +325,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     }
     GSS_HIP(hipGetLastError());
   }
-  if (!idx_out || !count_out || !status) GSS_HIP(hipStreamSynchronize(s));  // scratch is freed on return
+  GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return
   return GSS_OK;
 }
 
