@@ -1,0 +1,473 @@
+// IDW and LWR estimation on the exact k-NN kernel.
+//
+//   gss_idw_predict  <- /root/reference/src/estimation/idw.jl:111-142
+//   gss_lwr_predict  <- /root/reference/src/estimation/lwr.jl:114-147
+//
+// Two device paths, chosen by the neighbour count the searcher would return (ui.jl:16-23):
+//   * k <= 64     : K4 (Morton-ordered exact k-NN) then one wave per estimation point, lane = neighbour;
+//   * k == n > 64 : "all samples" (maxneighbors = nothing): no search at all, one thread per estimation
+//                   point sweeping the samples staged through LDS (broadcast reads).
+// LWR solves its (d+1) x (d+1) normal equations about the estimation point (same predictor, better conditioned
+// than the raw coordinates the reference uses) with an unpivoted Cholesky; a non-positive pivot is reported as
+// GSS_PT_SINGULAR where the reference's `\` would throw.
+#include "gss_internal.h"
+
+#include <climits>
+#include <cstring>
+
+namespace gss {
+
+struct EstSpec {
+  int method;       // 0 = IDW, 1 = LWR
+  int wkind;        // GSS_WEIGHT_*
+  double exponent;  // IDW
+  double wa, wp;    // LWR weight parameters
+};
+
+__device__ __forceinline__ double idw_weight(double d, double d2, double e) {
+  if (e == 1.0) return 1.0 / d;
+  if (e == 2.0) return 1.0 / d2;
+  return 1.0 / pow(d, e);
+}
+
+__device__ __forceinline__ double lwr_weight(int kind, double a, double p, double h) {
+  if (kind == GSS_WEIGHT_TRICUBE) {
+    const double t = 1.0 - h * h * h;
+    return t * t * t;
+  }
+  const double hp = (p == 2.0) ? h * h : (p == 1.0 ? h : pow(h, p));
+  return exp(-a * hp);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// Weighted least squares about the estimation point.  S1 = X'WX, S2 = X'W^2 X (packed lower triangles, NP = DIM+1,
+// u_0 = 1, u_a = x_a - x0_a), b = X'Wz.  mean = theta_0 with S1 theta = b; "variance" = |W X S1^-1 e_1| =
+// sqrt(a' S2 a) with S1 a = e_1 (lwr.jl:139-145).  Returns false when S1 is not positive definite.
+template <int NP>
+__device__ __forceinline__ bool lwr_solve(const double* S1, const double* S2, const double* b, double* mean,
+                                          double* var) {
+  double L[NP][NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i][j] = S1[i * (i + 1) / 2 + j];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const double ajj = L[j][j];
+    double d = ajj;
+#pragma unroll
+    for (int c = 0; c < j; ++c) d -= L[j][c] * L[j][c];
+    if (!(d > 1e-13 * ajj) || !(ajj > 0.0)) ok = false;
+    const double l = sqrt(d > 0.0 ? d : 1.0);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < NP; ++i) {
+      double s = L[i][j];
+#pragma unroll
+      for (int c = 0; c < j; ++c) s -= L[i][c] * L[j][c];
+      L[i][j] = s / l;
+    }
+  }
+  if (!ok) return false;
+  double t[NP], a[NP];
+  // theta = S1^-1 b
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int c = 0; c < i; ++c) s -= L[i][c] * t[c];
+    t[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = NP - 1; i >= 0; --i) {
+    double s = t[i];
+#pragma unroll
+    for (int c = i + 1; c < NP; ++c) s -= L[c][i] * t[c];
+    t[i] = s / L[i][i];
+  }
+  *mean = t[0];
+  // a = S1^-1 e_1
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double s = (i == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < i; ++c) s -= L[i][c] * a[c];
+    a[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = NP - 1; i >= 0; --i) {
+    double s = a[i];
+#pragma unroll
+    for (int c = i + 1; c < NP; ++c) s -= L[c][i] * a[c];
+    a[i] = s / L[i][i];
+  }
+  double q = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      q += a[i] * S2[hi * (hi + 1) / 2 + lo] * a[j];
+    }
+  *var = sqrt(q > 0.0 ? q : 0.0);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k <= 64: one wave per estimation point on the neighbour lists written by K4
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* __restrict__ xdata,
+                                                      const double* __restrict__ z, const double* __restrict__ x0,
+                                                      int64_t m, int k, int minneighbors,
+                                                      const int* __restrict__ idx, const int* __restrict__ count,
+                                                      int aniso, double ir0, double ir1, double ir2,
+                                                      double* __restrict__ mean_out, double* __restrict__ aux_out,
+                                                      uint8_t* __restrict__ status_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= m) return;  // whole wave
+  const double NaN = __builtin_nan("");
+  const int cnt = count[p];
+  if (cnt < minneighbors || cnt < 1) {  // idw.jl:123-124, lwr.jl:126-127
+    if (lane == 0) {
+      mean_out[p] = NaN;
+      aux_out[p] = NaN;
+      status_out[p] = GSS_PT_MISSING;
+    }
+    return;
+  }
+  const double ir[3] = {ir0, ir1, ir2};
+  double qc[DIM], c[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = x0[p * DIM + a];
+  const bool act = lane < cnt;
+  const int i = act ? idx[p * k + lane] : 0;
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) c[a] = xdata[(int64_t)i * DIM + a];
+  const double zi = z[i];
+  const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);  // the distance the search ranked by
+  const double d = sqrt(d2);
+
+  if (sp.method == 0) {
+    const unsigned long long zero = __ballot(act && d2 == 0.0);
+    if (zero) {  // idw.jl:131-134: some distance is zero -> copy the first such sample
+      const int j = __builtin_ctzll(zero);
+      const double zj = __shfl(zi, j);
+      if (lane == 0) {
+        mean_out[p] = zj;
+        aux_out[p] = 0.0;
+        status_out[p] = GSS_PT_OK;
+      }
+      return;
+    }
+    const double w = act ? idw_weight(d, d2, sp.exponent) : 0.0;
+    const double sw = wave_sum(w);
+    const double swz = wave_sum(w * zi);
+    const double dmin = wave_min(act ? d : __builtin_huge_val());
+    if (lane == 0) {
+      mean_out[p] = swz / sw;
+      aux_out[p] = dmin;  // idw.jl:139
+      status_out[p] = GSS_PT_OK;
+    }
+    return;
+  }
+
+  constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
+  const double dmax = wave_max(act ? d : 0.0);
+  const double w = act ? lwr_weight(sp.wkind, sp.wa, sp.wp, d / dmax) : 0.0;  // lwr.jl:132,136
+  double u[NP];
+  u[0] = 1.0;
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) u[a + 1] = c[a] - qc[a];
+  double S1[NT], S2[NT], b[NP];
+#pragma unroll
+  for (int r = 0; r < NP; ++r) {
+    b[r] = wave_sum(w * u[r] * zi);
+#pragma unroll
+    for (int q = 0; q <= r; ++q) {
+      const double t = w * u[r] * u[q];
+      S1[r * (r + 1) / 2 + q] = wave_sum(t);
+      S2[r * (r + 1) / 2 + q] = wave_sum(w * t);
+    }
+  }
+  double mu, var;
+  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  if (lane == 0) {
+    mean_out[p] = ok ? mu : NaN;
+    aux_out[p] = ok ? var : NaN;
+    status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k == n: every sample (inside the ball, if any) is a neighbour; one thread per estimation point
+// ---------------------------------------------------------------------------------------------
+constexpr int EST_TILE = 1024;
+
+template <int DIM>
+__global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* __restrict__ xdata,
+                                                      const double* __restrict__ z, int n,
+                                                      const double* __restrict__ x0, int64_t m, int minneighbors,
+                                                      double r2, int use_ball, int aniso, double ir0, double ir1,
+                                                      double ir2, double* __restrict__ mean_out,
+                                                      double* __restrict__ aux_out, uint8_t* __restrict__ status_out) {
+  __shared__ double sx[EST_TILE * DIM];
+  __shared__ double sz[EST_TILE];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < m;
+  const double ir[3] = {ir0, ir1, ir2};
+  const double NaN = __builtin_nan("");
+  double qc[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = live ? x0[p * DIM + a] : 0.0;
+  constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
+
+  int cnt = 0;
+  double dmax2 = 0.0, dmin2 = __builtin_huge_val();
+  double sw = 0.0, swz = 0.0, zzero = 0.0;
+  bool haszero = false;
+  // sweep 1: IDW sums (complete) / LWR farthest neighbour
+  for (int t0 = 0; t0 < n; t0 += EST_TILE) {
+    const int tn = (n - t0) < EST_TILE ? (n - t0) : EST_TILE;
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
+    for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
+    __syncthreads();
+    for (int j = 0; j < tn; ++j) {
+      const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+      if (use_ball && !(d2 <= r2)) continue;
+      ++cnt;
+      dmax2 = d2 > dmax2 ? d2 : dmax2;
+      dmin2 = d2 < dmin2 ? d2 : dmin2;
+      if (sp.method == 0) {
+        if (d2 == 0.0) {
+          if (!haszero) zzero = sz[j];
+          haszero = true;
+        } else {
+          const double w = idw_weight(sqrt(d2), d2, sp.exponent);
+          sw += w;
+          swz += w * sz[j];
+        }
+      }
+    }
+  }
+  const bool enough = cnt >= minneighbors && cnt >= 1;
+  if (sp.method == 0) {
+    if (!live) return;
+    if (!enough) {
+      mean_out[p] = NaN;
+      aux_out[p] = NaN;
+      status_out[p] = GSS_PT_MISSING;
+    } else if (haszero) {
+      mean_out[p] = zzero;
+      aux_out[p] = 0.0;
+      status_out[p] = GSS_PT_OK;
+    } else {
+      mean_out[p] = swz / sw;
+      aux_out[p] = sqrt(dmin2);
+      status_out[p] = GSS_PT_OK;
+    }
+    return;
+  }
+  // sweep 2 (LWR): moments with delta = d / dmax
+  const double dmax = sqrt(dmax2);
+  double S1[NT], S2[NT], b[NP];
+#pragma unroll
+  for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < NP; ++e) b[e] = 0.0;
+  for (int t0 = 0; t0 < n; t0 += EST_TILE) {
+    const int tn = (n - t0) < EST_TILE ? (n - t0) : EST_TILE;
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
+    for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
+    __syncthreads();
+    for (int j = 0; j < tn; ++j) {
+      const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+      if (use_ball && !(d2 <= r2)) continue;
+      const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, sqrt(d2) / dmax);
+      double u[NP];
+      u[0] = 1.0;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) u[a + 1] = sx[j * DIM + a] - qc[a];
+      const double zj = sz[j];
+#pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        const double wu = w * u[r];
+        b[r] += wu * zj;
+#pragma unroll
+        for (int q = 0; q <= r; ++q) {
+          const double t = wu * u[q];
+          S1[r * (r + 1) / 2 + q] += t;
+          S2[r * (r + 1) / 2 + q] += w * t;
+        }
+      }
+    }
+  }
+  if (!live) return;
+  if (!enough) {
+    mean_out[p] = NaN;
+    aux_out[p] = NaN;
+    status_out[p] = GSS_PT_MISSING;
+    return;
+  }
+  double mu, var;
+  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  mean_out[p] = ok ? mu : NaN;
+  aux_out[p] = ok ? var : NaN;
+  status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+}
+
+static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int dim,
+                             const double* x0, int64_t m, int k, int minneighbors, double radius,
+                             const double* inv_radii_host, double* mean, double* aux, uint8_t* status,
+                             hipStream_t s) {
+  const int use_ball = (radius >= 0.0 || inv_radii_host != nullptr) ? 1 : 0;
+  const int aniso = inv_radii_host != nullptr ? 1 : 0;
+  const double r2 = aniso ? 1.0 : radius * radius;
+  double ir[3] = {1.0, 1.0, 1.0};
+  if (aniso)
+    for (int a = 0; a < dim; ++a) ir[a] = inv_radii_host[a];
+  const char* pname = sp.method == 0 ? "idw" : "lwr";
+
+  if (k > 64) {
+    GSS_REQUIRE((int64_t)k == n, "maxneighbors = %d: the neighbour kernels hold at most 64 neighbours; beyond that "
+                                 "only maxneighbors = nothing (all %lld samples) is available", k, (long long)n);
+    ProfScope ps(pname, s);
+    dim3 grid((unsigned)((m + 255) / 256));
+#define GSS_EST_ALL_ARGS sp, xdata, z, (int)n, x0, m, minneighbors, r2, use_ball, aniso, ir[0], ir[1], ir[2], mean, \
+                         aux, status
+    switch (dim) {
+      case 1: hipLaunchKernelGGL((est_all_kernel<1>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
+      case 2: hipLaunchKernelGGL((est_all_kernel<2>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
+      default: hipLaunchKernelGGL((est_all_kernel<3>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
+    }
+#undef GSS_EST_ALL_ARGS
+    GSS_HIP(hipGetLastError());
+    return GSS_OK;
+  }
+
+  const int64_t chunk = 1 << 20;
+  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
+  GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
+  DevBuf idx_s, cnt_s;
+  GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
+  GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
+  for (int64_t off = 0; off < m; off += chunk) {
+    const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
+    {
+      ProfScope ps("knn", s);
+      GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                                 cnt_s.as<int>(), s));
+    }
+    ProfScope pl(pname, s);
+    dim3 grid((unsigned)((mv + 3) / 4));
+#define GSS_EST_KNN_ARGS sp, xdata, z, x0 + off * dim, mv, k, minneighbors, idx_s.as<int>(), cnt_s.as<int>(), aniso, \
+                         ir[0], ir[1], ir[2], mean + off, aux + off, status + off
+    switch (dim) {
+      case 1: hipLaunchKernelGGL((est_knn_kernel<1>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+      case 2: hipLaunchKernelGGL((est_knn_kernel<2>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+      default: hipLaunchKernelGGL((est_knn_kernel<3>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+    }
+#undef GSS_EST_KNN_ARGS
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return
+  return GSS_OK;
+}
+
+static int32_t est_predict(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int32_t dim,
+                           const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
+                           const double* inv_radii, double* mean, double* aux, uint8_t* status, int32_t mem,
+                           void* stream) {
+  GSS_REQUIRE(n >= 1 && n < INT_MAX, "estimation requires data");  // idw.jl:95
+  GSS_REQUIRE(dim >= 1 && dim <= 3, "dim = %d outside 1..3", dim);
+  GSS_REQUIRE(k >= 1 && k <= n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
+              (long long)n);
+  GSS_REQUIRE(minneighbors <= k, "invalid min/max number of neighbors");  // idw.jl:97, lwr.jl:99
+  GSS_REQUIRE(m >= 0 && (m == 0 || (xdata && z && xdom && mean && aux)), "NULL array");
+  if (m == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  Staged sxd, sz, sx, smean, saux, sstat;
+  GSS_TRY(sxd.in(xdata, sizeof(double) * n * dim, mem, s));
+  GSS_TRY(sz.in(z, sizeof(double) * n, mem, s));
+  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
+  GSS_TRY(saux.out(aux, sizeof(double) * m, mem));
+  DevBuf st_own;
+  uint8_t* st = nullptr;
+  if (status) {
+    GSS_TRY(sstat.out(status, (size_t)m, mem));
+    st = sstat.as<uint8_t>();
+  } else {
+    GSS_TRY(st_own.alloc((size_t)m));
+    st = st_own.as<uint8_t>();
+  }
+  GSS_TRY(est_local_dev(sp, sxd.as<double>(), sz.as<double>(), n, dim, sx.as<double>(), m, k, minneighbors, radius,
+                        inv_radii, smean.as<double>(), saux.as<double>(), st, s));
+  GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
+  GSS_TRY(saux.back(aux, sizeof(double) * m, mem, s));
+  if (status) GSS_TRY(sstat.back(status, (size_t)m, mem, s));
+  if (!status) GSS_HIP(hipStreamSynchronize(s));  // st_own is released on return
+  return GSS_OK;
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+extern "C" {
+
+int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
+                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, double exponent,
+                        double* mean, double* dist, uint8_t* status, int32_t mem, void* stream) {
+  GSS_REQUIRE(exponent > 0.0, "exponent must be positive");  // idw.jl:96
+  EstSpec sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.method = 0;
+  sp.exponent = exponent;
+  return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, dist, status, mem,
+                     stream);
+}
+
+int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
+                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t weight_kind,
+                        double weight_a, double weight_p, double* mean, double* var, uint8_t* status, int32_t mem,
+                        void* stream) {
+  GSS_REQUIRE(weight_kind == GSS_WEIGHT_EXP || weight_kind == GSS_WEIGHT_TRICUBE, "unknown weight function %d",
+              weight_kind);
+  GSS_REQUIRE(weight_kind != GSS_WEIGHT_EXP || weight_p > 0.0, "weight exponent must be positive");
+  EstSpec sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.method = 1;
+  sp.wkind = weight_kind;
+  sp.wa = weight_a;
+  sp.wp = weight_p;
+  return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, var, status, mem,
+                     stream);
+}
+
+}  // extern "C"

@@ -279,6 +279,35 @@ class HipEngine:
                                MEM_HOST, current_stream()))
         return idx, cnt
 
+    @staticmethod
+    def _estimate(fn_name, extra, xdata, z, xdom, k, minneighbors, radius, radii):
+        l = _lib.lib()
+        x = np.ascontiguousarray(xdata, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        zz = np.ascontiguousarray(z, dtype=np.float64)
+        c = np.ascontiguousarray(xdom, dtype=np.float64).reshape(-1, x.shape[1])
+        m = c.shape[0]
+        mean, aux, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
+        ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
+        r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
+        check(getattr(l, fn_name)(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k), int(minneighbors), r,
+                                  ptr(ir), *extra, ptr(mean), ptr(aux), ptr(st), MEM_HOST, current_stream()))
+        return mean, aux, st
+
+    @staticmethod
+    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None):
+        """gss_idw_predict (idw.jl:111-142) -> mean, distance to the nearest sample, status."""
+        return HipEngine._estimate("gss_idw_predict", (float(exponent),), xdata, z, xdom, k, minneighbors, radius,
+                                   radii)
+
+    @staticmethod
+    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None):
+        """gss_lwr_predict (lwr.jl:114-147); weight = (kind, a, p) -> mean, norm(r), status."""
+        kind, a, p = weight
+        return HipEngine._estimate("gss_lwr_predict", (int(kind), float(a), float(p)), xdata, z, xdom, k,
+                                   minneighbors, radius, radii)
+
 
 def default_engine():
     return HipEngine

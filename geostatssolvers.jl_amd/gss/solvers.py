@@ -1,6 +1,8 @@
 """Solver front-ends with the reference's parameter surface and `solve(problem, solver)` entry.
 
     KrigingSolver  <- /root/reference/src/estimation/krig.jl:64-234  (+ ui.jl:11-50)
+    IDWSolver      <- /root/reference/src/estimation/idw.jl:49-153
+    LWRSolver      <- /root/reference/src/estimation/lwr.jl:53-158
     FFTGS          <- /root/reference/src/simulation/fft.jl:51-198
     LUGS           <- /root/reference/src/simulation/lu.jl:67-224
 
@@ -192,6 +194,110 @@ class KrigingSolver(_Solver):
         if gather or ws == 1:
             return georef(cols, pdom)                                  # krig.jl:163
         return georef(cols, PointSet(xdom))
+
+
+# ------------------------------------------------------------------------------------------
+# IDWSolver / LWRSolver
+# ------------------------------------------------------------------------------------------
+class ExpWeight:
+    """Weight function h -> exp(-a h^p); the reference default is ExpWeight(3, 2) (lwr.jl:58)."""
+
+    def __init__(self, a=3.0, p=2.0):
+        self.a, self.p = float(a), float(p)
+
+    def spec(self):
+        return (0, self.a, self.p)
+
+    def __call__(self, h):
+        return np.exp(-self.a * np.asarray(h, dtype=np.float64) ** self.p)
+
+
+class TricubeWeight:
+    """Cleveland's tricube h -> (1 - h^3)^3."""
+
+    def spec(self):
+        return (1, 0.0, 0.0)
+
+    def __call__(self, h):
+        return (1.0 - np.asarray(h, dtype=np.float64) ** 3) ** 3
+
+
+class _NeighborEstimator(_Solver):
+    """Shared body of idw.jl:58-153 and lwr.jl:61-158 (they differ in the per-point arithmetic only)."""
+    AUX = ""
+
+    def _estimate(self, p, x, z, xdom, nmax, radius, radii):
+        raise NotImplementedError
+
+    def solve(self, problem: EstimationProblem, gather: bool = True):
+        pdom = problem.domain
+        coords = problem.data.domain.centroids()
+        xdom_all = pdom.centroids()
+        m = xdom_all.shape[0]
+        rank, ws = parallel.world()
+        lo, hi = parallel.shard_range(m, rank, ws)
+        xdom = xdom_all[lo:hi]
+        cols, aux = {}, {}
+        for var in problem.variables:
+            p = self.params(var)
+            zall = np.asarray(problem.data[var], dtype=np.float64)
+            inds = np.flatnonzero(~np.isnan(zall))                       # idw.jl:77, lwr.jl:80
+            n = inds.size
+            assert n > 0, "estimation requires data"                      # idw.jl:95
+            if p["distance"] not in ("euclidean", None):
+                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            if p["path"] not in ("linear", None):
+                raise NotImplementedError("only LinearPath is available (results are per-point independent)")
+            nmin = p["minneighbors"]
+            nmax = n if p["maxneighbors"] is None else min(p["maxneighbors"], n)      # idw.jl:93
+            self._check(p)
+            assert nmin <= nmax, "invalid min/max number of neighbors"    # idw.jl:97
+            vdom = PointSet(coords[inds])
+            _, k = searcher_ui(vdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # idw.jl:100
+            radius, radii = _ball(p["neighborhood"])
+            if hi > lo:
+                mu, ax, st = self._estimate(p, vdom.coords, zall[inds], xdom, k, nmin, radius, radii)
+            else:
+                mu, ax, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
+            mu = np.where(st == 0, mu, np.nan)                            # `missing`
+            ax = np.where(st == 0, ax, np.nan)
+            if gather and ws > 1:
+                mu = parallel.all_gather_concat(mu, m)
+                ax = parallel.all_gather_concat(ax, m)
+            cols[var] = mu
+            aux[f"{var}_{self.AUX}"] = ax
+        cols.update(aux)                                                  # (; mus..., sigmas...) idw.jl:152
+        if gather or ws == 1:
+            return georef(cols, pdom)
+        return georef(cols, PointSet(xdom))
+
+    def _check(self, p):
+        pass
+
+
+class IDWSolver(_NeighborEstimator):
+    PARAMS = dict(minneighbors=1, maxneighbors=None, neighborhood=None, distance="euclidean", exponent=1,
+                  path="linear")                                                               # idw.jl:49-56
+    AUX = "distance"                                                                           # idw.jl:149
+
+    def _check(self, p):
+        assert p["exponent"] > 0, "exponent must be positive"                                  # idw.jl:96
+
+    def _estimate(self, p, x, z, xdom, k, nmin, radius, radii):
+        return self.engine.idw(x, z, xdom, k, nmin, float(p["exponent"]), radius, radii)
+
+
+class LWRSolver(_NeighborEstimator):
+    PARAMS = dict(minneighbors=1, maxneighbors=None, neighborhood=None, distance="euclidean", weightfun=None,
+                  path="linear")                                                               # lwr.jl:53-60
+    AUX = "variance"                                                                           # lwr.jl:154
+
+    def _estimate(self, p, x, z, xdom, k, nmin, radius, radii):
+        wf = p["weightfun"] or ExpWeight()
+        if not hasattr(wf, "spec"):
+            raise NotImplementedError("weightfun must be ExpWeight(a, p) or TricubeWeight(): the weights are "
+                                      "evaluated inside the device kernel, arbitrary callables cannot cross the C-ABI")
+        return self.engine.lwr(x, z, xdom, k, nmin, wf.spec(), radius, radii)
 
 
 # ------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ using Random
 
 import GeoStatsBase: solve, preprocess, solvesingle
 
-export KrigingSolverHIP, FFTGSHIP, LUGSHIP
+export KrigingSolverHIP, IDWSolverHIP, LWRSolverHIP, ExpWeight, TricubeWeight, FFTGSHIP, LUGSHIP
 
 const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 
@@ -187,6 +187,92 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
   end
   georef((; μs..., σs...), pdomain)                                      # krig.jl:163
 end
+
+# ---- IDWSolver / LWRSolver (idw.jl:49-153, lwr.jl:53-158) -------------------------------------
+struct ExpWeight                 # h -> exp(-a h^p); ExpWeight(3, 2) is the reference default (lwr.jl:58)
+  a::Float64
+  p::Float64
+end
+struct TricubeWeight end         # h -> (1 - h^3)^3
+(w::ExpWeight)(h) = exp(-w.a * h^w.p)
+(::TricubeWeight)(h) = (1 - h^3)^3
+weightspec(w::ExpWeight) = (Int32(0), w.a, w.p)
+weightspec(::TricubeWeight) = (Int32(1), 0.0, 0.0)
+weightspec(f) = throw(ArgumentError("weightfun must be ExpWeight(a, p) or TricubeWeight(): weights are evaluated on the device"))
+
+@estimsolver IDWSolverHIP begin
+  @param minneighbors = 1
+  @param maxneighbors = nothing
+  @param neighborhood = nothing
+  @param distance = Euclidean()
+  @param exponent = 1
+  @param path = LinearPath()
+end
+
+@estimsolver LWRSolverHIP begin
+  @param minneighbors = 1
+  @param maxneighbors = nothing
+  @param neighborhood = nothing
+  @param distance = Euclidean()
+  @param weightfun = ExpWeight(3.0, 2.0)
+  @param path = LinearPath()
+end
+
+function neighbor_estimate(problem, solver, auxname, call)
+  pdata = data(problem)
+  pdomain = domain(problem)
+  dtable = values(pdata)
+  X0 = coordmatrix(pdomain)
+  d, m = size(X0)
+  μs, σs = [], []
+  for covars in covariables(problem, solver), var in covars.names
+    p = covars.params[Set([var])]
+    zcol = Tables.getcolumn(Tables.columns(dtable), var)
+    inds = findall(!ismissing, zcol)                                     # idw.jl:77, lwr.jl:80
+    n = length(inds)
+    @assert n > 0 "estimation requires data"
+    z = Float64.(ustrip.(collect(skipmissing(zcol))))                    # uadjust, idw.jl:109
+    X = coordmatrix(view(domain(pdata), inds))
+    nmax = isnothing(p.maxneighbors) ? n : min(p.maxneighbors, n)        # idw.jl:93
+    @assert p.minneighbors ≤ nmax "invalid min/max number of neighbors"
+    k = nmax
+    if !isnothing(p.maxneighbors) && (p.maxneighbors < 1 || p.maxneighbors > n)   # searcher_ui, ui.jl:18-20
+      @warn "Invalid maximum number of neighbors. Adjusting to $n..."
+      k = n
+    end
+    radius, ir = -1.0, C_NULL
+    if !isnothing(p.neighborhood)
+      rs = ustrip.(radii(p.neighborhood))
+      length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
+    end
+    μ = Vector{Float64}(undef, m); aux = similar(μ); status = Vector{UInt8}(undef, m)
+    GC.@preserve X z X0 ir μ aux status check(call(p, X, z, n, d, X0, m, Int32(k), radius, ir, μ, aux, status))
+    miss = status .!= 0                                                  # idw.jl:123-124
+    push!(μs, var => [miss[i] ? missing : μ[i] for i in 1:m])
+    push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] for i in 1:m])
+  end
+  georef((; μs..., σs...), pdomain)
+end
+
+solve(problem::EstimationProblem, solver::IDWSolverHIP) =
+  neighbor_estimate(problem, solver, "_distance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
+    @assert p.exponent > 0 "exponent must be positive"                   # idw.jl:96
+    ccall((:gss_idw_predict, libgss), Int32,
+          (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
+           Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, Float64(p.exponent), μ, aux, status,
+          GSS_MEM_HOST, C_NULL)
+  end)
+
+solve(problem::EstimationProblem, solver::LWRSolverHIP) =
+  neighbor_estimate(problem, solver, "_variance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
+    wk, wa, wp = weightspec(p.weightfun)
+    ccall((:gss_lwr_predict, libgss), Int32,
+          (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
+           Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, wk, wa, wp, μ, aux, status,
+          GSS_MEM_HOST, C_NULL)
+  end)
 
 # ---- FFTGS ----------------------------------------------------------------------------------
 @simsolver FFTGSHIP begin

@@ -163,6 +163,31 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
 int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t m, const double* zbatch,
                                       int64_t nbatch, double* mean_out, int32_t mem, void* stream);
 
+/* ---- IDWSolver / LWRSolver on the neighbour-search kernel -------------
+ * gss_idw_predict replaces the estimation loop idw.jl:111-142: neighbours by gss_knn_search's rule,
+ *   w_i = 1 / d_i^exponent, mean = sum w_i z_i / sum w_i, dist = min d_i; a zero distance copies that
+ *   sample and reports dist = 0 (idw.jl:131-134).  Output column `dist` is `<var>_distance` (idw.jl:149).
+ * gss_lwr_predict replaces lwr.jl:114-147: delta_i = d_i / max d, W = diag(weight(delta_i)),
+ *   theta = (X'WX)^-1 X'Wz with X = [1 x], mean = theta . [1; x0], var = |W X (X'WX)^-1 [1; x0]|
+ *   (stored under `<var>_variance` exactly as lwr.jl:145,154 does).
+ *   weight(h) = exp(-weight_a * h^weight_p) for GSS_WEIGHT_EXP (reference default a = 3, p = 2,
+ *   lwr.jl:58) or (1 - h^3)^3 for GSS_WEIGHT_TRICUBE.
+ * k = number of neighbours the searcher returns (ui.jl:16-23): 1..64, or k == n for
+ * `maxneighbors = nothing` (every sample, no search).  radius / inv_radii as gss_knn_search.
+ * status: GSS_PT_MISSING when fewer than minneighbors were found (idw.jl:123, lwr.jl:126),
+ * GSS_PT_SINGULAR when the LWR normal equations are not positive definite (the reference throws).
+ * xdata n x d and xdom m x d point-major; status may be NULL. */
+enum { GSS_WEIGHT_EXP = 0, GSS_WEIGHT_TRICUBE = 1 };
+
+int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom,
+                        int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
+                        double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
+                        void* stream);
+int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom,
+                        int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
+                        int32_t weight_kind, double weight_a, double weight_p, double* mean, double* var,
+                        uint8_t* status, int32_t mem, void* stream);
+
 /* ---- FFTGS ------------------------------------------------------------------------------
  * gss_fftgs_create replaces preprocess fft.jl:62-103 (unconditional part): covariance to the
  * centre cell, F = sqrt(|fft(fftshift(C))|), F[1] = 0.  dims[0] is the fastest axis (Julia

@@ -61,8 +61,34 @@ def main():
     y, w = lugs.realize(p, 123, 0, 2)
     np.savez_compressed(os.path.join(HERE, "lugs_line100.npz"), dlocs=p.dlocs, z1=p.z1, d2=p.d2,
                         L22_diag=np.diag(p.L22), L22_row50=p.L22[50], y=y, w=w)
+    idw_lwr_vectors()
     print("golden vectors written to", HERE)
 
 
+def idw_lwr_vectors():
+    """test/estimation/idw.jl:3-9 and test/estimation/lwr.jl:18-27 inputs (3 / 4 data -> 100x100 grid) plus a
+    seeded 3-D k = 12 case; `python tests/golden/make_golden.py idw_lwr` writes only this file."""
+    from oracle import idw_lwr as E
+    grid = fftgs.grid_centroids((100, 100), (0.5, 0.5), (1.0, 1.0))
+    x3 = np.array([(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)])
+    z3 = np.array([1.0, 0.0, 1.0])
+    imu, isd, _ = E.idw(x3, z3, grid, 3)
+    x4 = np.array([(25.0, 25.0), (50.0, 75.0), (75.0, 50.0), (75.0, 25.0)])
+    z4 = np.array([1.0, 0.0, 1.0, 0.0])
+    lmu3, lvar3, _ = E.lwr(x4, z4, grid, 3)
+    lmu4, lvar4, _ = E.lwr(x4, z4, grid, 4)
+    xs = np.random.default_rng(12).uniform(0.0, 50.0, (400, 3))
+    zs = np.cos(xs[:, 0] / 9.0) + 0.02 * xs[:, 1] * xs[:, 2] / 50.0
+    dom = np.random.default_rng(13).uniform(0.0, 50.0, (300, 3))
+    smu_i, ssd_i, _ = E.idw(xs, zs, dom, 12, exponent=2)
+    smu_l, svar_l, _ = E.lwr(xs, zs, dom, 12)
+    np.savez_compressed(os.path.join(HERE, "idw_lwr.npz"), grid=grid, x3=x3, z3=z3, idw_mu=imu, idw_dist=isd, x4=x4,
+                        z4=z4, lwr_mu3=lmu3, lwr_var3=lvar3, lwr_mu4=lmu4, lwr_var4=lvar4, xs=xs, zs=zs, dom=dom,
+                        idw_mu_s=smu_i, idw_dist_s=ssd_i, lwr_mu_s=smu_l, lwr_var_s=svar_l)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["idw_lwr"]:
+        idw_lwr_vectors()
+    else:
+        main()

@@ -87,3 +87,15 @@ class OracleEngine:
     @staticmethod
     def knn_search(xdata, centers, k, radius=None, radii=None):
         return OK_.knn_search(xdata, centers, k, radius, radii)
+
+    @staticmethod
+    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None):
+        from oracle import idw_lwr
+        return idw_lwr.idw(xdata, z, xdom, k, minneighbors, exponent, radius, radii)
+
+    @staticmethod
+    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None):
+        from oracle import idw_lwr
+        kind, a, p = weight
+        wf = idw_lwr.tricube if kind == 1 else idw_lwr.exp_weight(a, p)
+        return idw_lwr.lwr(xdata, z, xdom, k, minneighbors, wf, radius, radii)

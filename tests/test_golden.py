@@ -36,6 +36,36 @@ def test_oracle_reproduces_golden_vectors():
     assert np.allclose(lugs.realize(p, 123, 0, 2)[0], l["y"], atol=1e-12)
 
 
+def test_oracle_reproduces_idw_lwr_vectors():
+    from oracle import idw_lwr as E
+    g = _load("idw_lwr.npz")
+    mu, sd, _ = E.idw(g["x3"], g["z3"], g["grid"], 3)
+    assert np.allclose(mu, g["idw_mu"], atol=1e-13) and np.allclose(sd, g["idw_dist"], atol=1e-13)
+    mu, var, st = E.lwr(g["x4"], g["z4"], g["grid"], 4)
+    assert np.allclose(mu, g["lwr_mu4"], atol=1e-11) and np.allclose(var, g["lwr_var4"], atol=1e-11) and not st.any()
+    # three non-collinear points: the local plane interpolates them, whatever the weights (lwr.jl:139-143)
+    mu3 = g["lwr_mu3"].reshape(100, 100).T
+    assert abs(mu3[24, 24] - 1.0) < 0.05 and np.all(np.isfinite(g["lwr_var3"]))
+    mu, var, _ = E.lwr(g["xs"], g["zs"], g["dom"], 12)
+    assert np.allclose(mu, g["lwr_mu_s"], atol=1e-11) and np.allclose(var, g["lwr_var_s"], atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_device_reproduces_idw_lwr_vectors():
+    from gss.engine import HipEngine
+    g = _load("idw_lwr.npz")
+    mu, sd, st = HipEngine.idw(g["x3"], g["z3"], g["grid"], 3)
+    assert np.max(np.abs(mu - g["idw_mu"])) < 1e-12 and np.max(np.abs(sd - g["idw_dist"])) < 1e-12 and not st.any()
+    for k, key in ((3, "3"), (4, "4")):
+        mu, var, st = HipEngine.lwr(g["x4"], g["z4"], g["grid"], k)
+        assert not st.any()
+        assert np.max(np.abs(mu - g["lwr_mu" + key])) < 1e-8 and np.max(np.abs(var - g["lwr_var" + key])) < 1e-8
+    mu, sd, _ = HipEngine.idw(g["xs"], g["zs"], g["dom"], 12, 1, 2.0)
+    assert np.max(np.abs(mu - g["idw_mu_s"])) < 1e-12 and np.max(np.abs(sd - g["idw_dist_s"])) < 1e-12
+    mu, var, _ = HipEngine.lwr(g["xs"], g["zs"], g["dom"], 12)
+    assert np.max(np.abs(mu - g["lwr_mu_s"])) < 1e-10 and np.max(np.abs(var - g["lwr_var_s"])) < 1e-10
+
+
 @pytest.mark.gpu
 def test_device_reproduces_golden_vectors():
     import gss

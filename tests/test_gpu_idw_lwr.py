@@ -1,0 +1,113 @@
+"""IDW / LWR on the device (gss_idw_predict / gss_lwr_predict) vs the oracle restatement of idw.jl:111-142 and
+lwr.jl:114-147.  Tolerance: 1e-10 relative-or-absolute on means and the auxiliary column (sums are reduced
+in a different order on the device; LWR solves about the estimation point), statuses bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import idw_lwr as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-10):
+    a, b = np.asarray(a), np.asarray(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    ok = ~np.isnan(a)
+    return np.all(np.abs(a[ok] - b[ok]) <= tol * (1.0 + np.abs(b[ok])))
+
+
+def _data(n, m, dim, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 100, (n, dim))
+    z = np.sin(x[:, 0] / 17.0) + 0.01 * x.sum(axis=1) + 0.1 * rng.normal(size=n)
+    c = rng.uniform(-5, 105, (m, dim))
+    c[:4] = x[:4]                                   # zero distances (idw.jl:131-134)
+    return x, z, c
+
+
+@pytest.mark.parametrize("n,m,dim,k", [(500, 700, 2, 8), (3000, 900, 3, 64), (40, 300, 1, 5), (64, 200, 3, 64),
+                                       (2000, 500, 3, None), (70, 129, 2, None), (1500, 300, 1, None)])
+@pytest.mark.parametrize("exponent", [1, 2, 2.5])
+def test_idw_matches_oracle(n, m, dim, k, exponent):
+    from gss.engine import HipEngine
+    x, z, c = _data(n, m, dim, n + dim)
+    mu, sd, st = HipEngine.idw(x, z, c, n if k is None else k, 1, exponent)
+    rmu, rsd, rst = E.idw(x, z, c, k, 1, exponent)
+    assert np.array_equal(st, rst) and _close(mu, rmu) and _close(sd, rsd)
+    assert np.array_equal(mu[:4], z[:4]) and np.all(sd[:4] == 0.0)
+
+
+@pytest.mark.parametrize("n,m,dim,k", [(500, 700, 2, 8), (3000, 900, 3, 64), (40, 300, 1, 5), (64, 200, 3, 64),
+                                       (2000, 500, 3, None), (70, 129, 2, None), (1500, 300, 1, None)])
+@pytest.mark.parametrize("weight", ["default", "tricube", "exp1"])
+def test_lwr_matches_oracle(n, m, dim, k, weight):
+    from gss.engine import HipEngine
+    x, z, c = _data(n, m, dim, 3 * n + dim)
+    spec, wf = dict(default=((0, 3.0, 2.0), E.default_weightfun), tricube=((1, 0.0, 0.0), E.tricube),
+                    exp1=((0, 2.0, 1.0), E.exp_weight(2.0, 1.0)))[weight]
+    if weight == "tricube" and (k is not None and k <= dim + 1):
+        pytest.skip("tricube zeroes the farthest neighbour: fewer than d+1 effective points")
+    mu, var, st = HipEngine.lwr(x, z, c, n if k is None else k, 1, spec)
+    rmu, rvar, rst = E.lwr(x, z, c, k, 1, wf)
+    assert np.array_equal(st, rst) and not st.any()
+    assert _close(mu, rmu, 1e-9) and _close(var, rvar, 1e-9)
+
+
+def test_balls_minneighbors_and_singular_points():
+    from gss.engine import HipEngine
+    x, z, c = _data(800, 600, 2, 11)
+    for kw in (dict(radius=6.0), dict(radii=(9.0, 4.0))):
+        for k in (12, None):
+            kk = 800 if k is None else k
+            mu, sd, st = HipEngine.idw(x, z, c, kk, 3, 1.0, **kw)
+            rmu, rsd, rst = E.idw(x, z, c, k, 3, 1.0, **kw)
+            assert np.array_equal(st, rst) and (st == 1).any() and (st == 0).any()
+            assert _close(mu, rmu) and _close(sd, rsd)
+            mu, var, st = HipEngine.lwr(x, z, c, kk, 4, (0, 3.0, 2.0), **kw)
+            rmu, rvar, rst = E.lwr(x, z, c, k, 4, E.default_weightfun, **kw)
+            assert np.array_equal(st == 1, rst == 1)
+            ok = (st == 0) & (rst == 0)
+            assert ok.sum() > 100 and _close(mu[ok], rmu[ok], 1e-8) and _close(var[ok], rvar[ok], 1e-8)
+    # one neighbour cannot carry a line: GSS_PT_SINGULAR, NaN outputs (the reference's `\` throws)
+    mu, var, st = HipEngine.lwr(x, z, c[10:20], 1, 1, (0, 3.0, 2.0))
+    assert np.all(st == 2) and np.all(np.isnan(mu))
+
+
+def test_linear_field_and_convexity_properties_at_scale():
+    """Size-independent properties on 2e5 points x 5e4 samples: LWR reproduces a linear field; IDW stays inside the
+    data range and interpolates the samples."""
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 1000, (50_000, 3))
+    z = 2.0 + 0.01 * x[:, 0] - 0.02 * x[:, 1] + 0.005 * x[:, 2]
+    c = rng.uniform(0, 1000, (200_000, 3))
+    mu, var, st = HipEngine.lwr(x, z, c, 32)
+    assert not st.any()
+    assert np.max(np.abs(mu - (2.0 + 0.01 * c[:, 0] - 0.02 * c[:, 1] + 0.005 * c[:, 2]))) < 1e-8
+    zi = rng.normal(size=50_000)
+    mu, sd, st = HipEngine.idw(x, zi, np.concatenate([c[:1000], x[:1000]]), 16, 1, 2.0)
+    assert mu.min() >= zi.min() and mu.max() <= zi.max()
+    assert np.array_equal(mu[1000:], zi[:1000]) and np.all(sd[1000:] == 0) and np.all(sd[:1000] > 0)
+
+
+def test_solvers_through_solve_and_argument_errors():
+    import gss
+    from gss import _lib
+    rng = np.random.default_rng(2)
+    xs = rng.uniform(0, 20, (50, 2))
+    zs = np.cos(xs[:, 0] / 3.0) + 0.05 * xs[:, 1]
+    zs[5] = np.nan
+    prob = gss.EstimationProblem(gss.georef(dict(z=zs), xs), gss.CartesianGrid(20, 20), "z")
+    keep = ~np.isnan(zs)
+    grid = prob.domain.centroids()
+    sol = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=6))))
+    rmu, rsd, _ = E.idw(xs[keep], zs[keep], grid, 6)
+    assert sol.names() == ["z", "z_distance"] and _close(sol["z"], rmu) and _close(sol["z_distance"], rsd)
+    sol = gss.solve(prob, gss.LWRSolver())
+    rmu, rvar, _ = E.lwr(xs[keep], zs[keep], grid)
+    assert sol.names() == ["z", "z_variance"] and _close(sol["z"], rmu, 1e-9) and _close(sol["z_variance"], rvar, 1e-9)
+    with pytest.raises(_lib.GSSError, match="at most 64"):
+        from gss.engine import HipEngine
+        HipEngine.idw(rng.uniform(size=(200, 2)), rng.uniform(size=200), grid, 100)
+    with pytest.raises(_lib.GSSError, match="exponent must be positive"):
+        HipEngine.idw(xs[keep], zs[keep], grid, 5, 1, 0.0)

@@ -33,6 +33,31 @@ def test_knn_indices_bit_exact(n, m, dim, k):
     assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
 
 
+@pytest.mark.parametrize("dim,k,ball", [(3, 64, False), (2, 10, False), (3, 24, True), (1, 7, False)])
+def test_knn_pruned_equals_brute_force_on_large_clustered_data(monkeypatch, dim, k, ball):
+    """The Morton-ordered, box-pruned search is an optimisation only: on 150k clustered samples with exact
+    duplicates (ties) it must return the same neighbour lists as the exhaustive kernel (GSS_KNN_BRUTE=1)
+    and as the float64 numpy ranking by (d2, index) on a subset."""
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(17 + dim + k)
+    n, m = 150_000, 4000
+    centres_of_mass = rng.uniform(0, 1000, (40, dim))
+    x = centres_of_mass[rng.integers(0, 40, n)] + rng.normal(0, 15.0, (n, dim))
+    x[1000:1200] = x[:200]                                   # exact duplicates -> ties broken by index
+    c = np.concatenate([x[rng.integers(0, n, m // 2)] + rng.normal(0, 1.0, (m // 2, dim)),
+                        rng.uniform(-200, 1200, (m - m // 2, dim))])  # includes centres far outside the data
+    kw = dict(radius=12.0) if ball else {}
+    idx, cnt = HipEngine.knn_search(x, c, k, **kw)
+    monkeypatch.setenv("GSS_KNN_BRUTE", "1")
+    bidx, bcnt = HipEngine.knn_search(x, c, k, **kw)
+    monkeypatch.delenv("GSS_KNN_BRUTE")
+    assert np.array_equal(cnt, bcnt) and np.array_equal(idx, bidx)
+    ridx, rcnt = K.knn_search(x, c[::40], k, **kw)
+    assert np.array_equal(idx[::40], ridx) and np.array_equal(cnt[::40], rcnt)
+    if ball:
+        assert cnt.min() == 0 and cnt.max() == k
+
+
 def test_knn_lattice_ties_and_balls():
     from gss.engine import HipEngine
     g = offt.grid_centroids((12, 12))                     # lattice -> many exactly equal distances

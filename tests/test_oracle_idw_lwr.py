@@ -1,0 +1,129 @@
+"""IDW / LWR oracle known answers and the host front-ends IDWSolver / LWRSolver (no GPU).
+
+The reference's tests for these solvers (test/estimation/idw.jl, test/estimation/lwr.jl) run them on tiny
+inputs and assert units only; the numeric pins below are closed forms of idw.jl:128-139 and lwr.jl:132-145."""
+import numpy as np
+import pytest
+
+import gss
+from oracle import fftgs as offt, idw_lwr as E
+from oracle_engine import OracleEngine
+
+
+def test_idw_closed_forms():
+    x = np.array([[0.0], [3.0]])
+    z = np.array([2.0, 8.0])
+    mu, sd, st = E.idw(x, z, np.array([[1.0], [0.0], [4.5]]))
+    # weights 1/1 and 1/2 -> (2 + 4) / 1.5 ; zero distance copies the sample (idw.jl:131-134)
+    assert np.allclose(mu, [4.0, 2.0, (2 / 4.5 + 8 / 1.5) / (1 / 4.5 + 1 / 1.5)], atol=1e-15)
+    assert np.allclose(sd, [1.0, 0.0, 1.5]) and not st.any()
+    mu2, _, _ = E.idw(x, z, np.array([[1.0]]), exponent=2)
+    assert np.isclose(mu2[0], (2 / 1 + 8 / 4) / (1 + 1 / 4))
+    # maxneighbors = 1 -> nearest sample value; ball that holds nothing -> missing (idw.jl:123-124)
+    mu1, sd1, st1 = E.idw(x, z, np.array([[1.0], [2.9]]), maxneighbors=1)
+    assert np.allclose(mu1, [2.0, 8.0])
+    _, _, stb = E.idw(x, z, np.array([[10.0]]), maxneighbors=2, radius=1.0)
+    assert stb[0] == 1
+    with pytest.raises(AssertionError):
+        E.idw(x, z, x, exponent=0)
+    with pytest.raises(AssertionError):
+        E.idw(x, z, x, maxneighbors=1, minneighbors=2)
+
+
+def test_idw_reference_test_inputs():                    # test/estimation/idw.jl:3-9, 57-71 (scalar analogue)
+    x = np.array([(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)])
+    z = np.array([1.0, 0.0, 1.0])
+    grid = offt.grid_centroids((100, 100))
+    mu, sd, st = E.idw(x, z, grid, maxneighbors=3)
+    Z = mu.reshape(100, 100).T
+    assert abs(Z[24, 24] - 1) < 5e-2 and abs(Z[49, 74]) < 5e-2 and abs(Z[74, 49] - 1) < 5e-2
+    assert mu.min() >= 0.0 and mu.max() <= 1.0 and not st.any()       # convex combination of the data
+    assert np.isclose(sd.reshape(100, 100).T[24, 24], np.hypot(0.5, 0.5))
+
+
+def test_lwr_reproduces_linear_fields_and_reference_1d_case():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 10, (60, 2))
+    z = 1.5 - 0.7 * x[:, 0] + 0.2 * x[:, 1]
+    dom = rng.uniform(0, 10, (25, 2))
+    for k in (5, 12, None):
+        mu, var, st = E.lwr(x, z, dom, maxneighbors=k)
+        assert np.allclose(mu, 1.5 - 0.7 * dom[:, 0] + 0.2 * dom[:, 1], atol=1e-9) and not st.any()
+        assert np.all(var > 0)
+    # test/estimation/lwr.jl:3-16: y = x^2 + small noise on 100 points, maxneighbors = 10
+    N = 100
+    xs = np.linspace(0, 1, N)
+    y = xs ** 2 + np.array([i / 1000 for i in range(1, N + 1)]) * np.random.default_rng(2017).normal(size=N)
+    cent = offt.grid_centroids((N,), (0.0,), (1.0 / N,))
+    yhat, yvar, st = E.lwr(xs[:, None], y, cent, maxneighbors=10)
+    assert np.max(np.abs(yhat - cent[:, 0] ** 2)) < 0.15 and np.all(np.isfinite(yvar))
+    # k = 2 collinear-free 1-D fit is the chord; k = 1 cannot fit a line -> singular
+    mu, _, st = E.lwr(np.array([[0.0], [2.0]]), np.array([1.0, 3.0]), np.array([[0.5]]), maxneighbors=2)
+    assert np.isclose(mu[0], 1.5)
+    _, _, st = E.lwr(np.array([[0.0], [2.0]]), np.array([1.0, 3.0]), np.array([[0.5]]), maxneighbors=1)
+    assert st[0] == 2
+
+
+def test_lwr_variance_is_norm_of_the_linear_smoother_row():
+    # mean = r' z / (weights) : the predictor is linear in z with coefficients r_l / w_l ... check lwr.jl:144-145
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (30, 1))
+    z = rng.normal(size=30)
+    p = np.array([[0.4]])
+    mu, var, _ = E.lwr(x, z, p, maxneighbors=8)
+    order = np.argsort(np.abs(x[:, 0] - 0.4), kind="stable")[:8]
+    d = np.abs(x[order, 0] - 0.4)
+    W = np.exp(-3 * (d / d.max()) ** 2)
+    X = np.c_[np.ones(8), x[order]]
+    A = X.T @ (W[:, None] * X)
+    r = W * (X @ np.linalg.solve(A, np.array([1.0, 0.4])))
+    assert np.isclose(var[0], np.linalg.norm(r)) and np.isclose(mu[0], r @ z[order])
+
+
+def _problem(n=40, dims=(12, 10), seed=0, missing=True):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 10, (n, 2))
+    z = np.sin(x[:, 0]) + 0.1 * x[:, 1]
+    if missing:
+        z[::7] = np.nan
+    data = gss.georef(dict(z=z), x)
+    return gss.EstimationProblem(data, gss.CartesianGrid(*dims), "z"), x, z
+
+
+def test_idw_and_lwr_solvers_through_solve_with_stand_in():
+    prob, x, z = _problem()
+    keep = ~np.isnan(z)
+    grid = prob.domain.centroids()
+    sol = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=5, exponent=2)), engine=OracleEngine))
+    mu, sd, _ = E.idw(x[keep], z[keep], grid, 5, exponent=2)
+    assert sol.names()[:2] == ["z", "z_distance"]                            # idw.jl:148-149
+    assert np.allclose(sol["z"], mu) and np.allclose(sol["z_distance"], sd)
+    sol = gss.solve(prob, gss.IDWSolver(engine=OracleEngine))                        # all samples (idw.jl:93)
+    mu, sd, _ = E.idw(x[keep], z[keep], grid)
+    assert np.allclose(sol["z"], mu)
+    sol = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9)), engine=OracleEngine))
+    mu, var, _ = E.lwr(x[keep], z[keep], grid, 9)
+    assert sol.names()[:2] == ["z", "z_variance"]                            # lwr.jl:153-154
+    assert np.allclose(sol["z"], mu) and np.allclose(sol["z_variance"], var)
+    sol = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9, weightfun=gss.TricubeWeight(),
+                                                    neighborhood=gss.MetricBall(4.0), minneighbors=4)),
+                                        engine=OracleEngine))
+    mu, var, st = E.lwr(x[keep], z[keep], grid, 9, 4, E.tricube, radius=4.0)
+    assert np.array_equal(np.isnan(sol["z"]), st != 0)
+    assert np.allclose(sol["z"][st == 0], mu[st == 0])
+
+
+def test_idw_lwr_parameter_errors():
+    prob, _, _ = _problem(missing=False)
+    with pytest.raises(AssertionError, match="exponent must be positive"):
+        gss.solve(prob, gss.IDWSolver(("z", dict(exponent=0)), engine=OracleEngine))
+    with pytest.raises(AssertionError, match="invalid min/max number of neighbors"):
+        gss.solve(prob, gss.LWRSolver(("z", dict(minneighbors=5, maxneighbors=3)), engine=OracleEngine))
+    with pytest.raises(NotImplementedError):
+        gss.solve(prob, gss.LWRSolver(("z", dict(weightfun=lambda h: 1 - h)), engine=OracleEngine))
+    with pytest.raises(NotImplementedError):
+        gss.solve(prob, gss.IDWSolver(("z", dict(distance="haversine")), engine=OracleEngine))
+    with pytest.raises(ValueError):
+        gss.IDWSolver(("z", dict(variogram=None)))
+    with pytest.warns(UserWarning, match="Invalid maximum number of neighbors"):
+        gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=10 ** 6)), engine=OracleEngine))
