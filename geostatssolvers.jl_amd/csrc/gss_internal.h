@@ -213,9 +213,12 @@ struct KnnIndex {
   int64_t n = 0;
   int nb = 0, dim = 0;
 };
+int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
 int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
+// rank / qrank / bminrank (all or none): masked search of sequential simulation, see knn.hip
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
-                           const double* inv_radii_host, int* idx, int* count, hipStream_t s);
+                           const double* inv_radii_host, int* idx, int* count, hipStream_t s,
+                           const int* rank = nullptr, const int* qrank = nullptr, const int* bminrank = nullptr);
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s);
 

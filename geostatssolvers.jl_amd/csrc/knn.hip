@@ -218,16 +218,22 @@ __device__ __forceinline__ double box_sqdist_nofma(const double* lo, const doubl
   return acc;
 }
 
-template <int DIM>
+// MASKED (sequential simulation, seq.jl:105 `search!(..., mask=simulated)`): a sample qualifies only if its
+// visiting rank is lower than the query's (rank[] per original index, qrank[] per query, bminrank[] = lowest
+// rank inside each batch so that batches with nothing simulated yet are skipped).
+template <int DIM, bool MASKED>
 __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restrict__ xs, const int* __restrict__ perm,
                                                          const double* __restrict__ blo, const double* __restrict__ bhi,
                                                          int n, int nb, const double* __restrict__ centers, int64_t m,
                                                          int k, double r2, int use_ball, int aniso, double ir0,
-                                                         double ir1, double ir2, int* __restrict__ idx_out,
+                                                         double ir1, double ir2, const int* __restrict__ rank,
+                                                         const int* __restrict__ qrank,
+                                                         const int* __restrict__ bminrank, int* __restrict__ idx_out,
                                                          int* __restrict__ count_out) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= m) return;  // whole wave
+  const int myrank = MASKED ? qrank[p] : 0;
   const double ir[3] = {ir0, ir1, ir2};
   double qc[DIM];
 #pragma unroll
@@ -249,6 +255,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
       dmin = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
     }
     bool done = !(b < nb);
+    if (MASKED && !done && !(bminrank[b] < myrank)) done = true;
+    if (done) dmin = INF;
     // seed: nearest box of this chunk first (ties: lowest lane), so that tau is tight before the sweep
     double best = dmin;
     int bl = lane;
@@ -282,7 +290,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
       for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
       const int oidx = valid ? perm[j] : INT_MAX;
       const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);
-      const bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
+      bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
+      if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
       unsigned long long qm = __ballot(qual);
       while (qm) {
         const int src = __builtin_ctzll(qm);
@@ -312,7 +321,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
 }
 
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
-                           const double* inv_radii_host, int* idx, int* count, hipStream_t s) {
+                           const double* inv_radii_host, int* idx, int* count, hipStream_t s, const int* rank,
+                           const int* qrank, const int* bminrank) {
   GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
                                  "(use the global neighbourhood beyond that)", k);
   if (m <= 0) return GSS_OK;
@@ -324,11 +334,20 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
     for (int a = 0; a < ix.dim; ++a) ir[a] = inv_radii_host[a];
   dim3 grid((unsigned)((m + 3) / 4));
 #define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), (int)ix.n, ix.nb, \
-                     centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], idx, count
-  switch (ix.dim) {
-    case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    case 2: hipLaunchKernelGGL((knn_pruned_kernel<2>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    default: hipLaunchKernelGGL((knn_pruned_kernel<3>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+                     centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count
+  if (rank) {
+    GSS_REQUIRE(qrank && bminrank, "masked search needs query ranks and per-batch minimum ranks");
+    switch (ix.dim) {
+      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      default: hipLaunchKernelGGL((knn_pruned_kernel<3, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    }
+  } else {
+    switch (ix.dim) {
+      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    }
   }
 #undef GSS_KNN_ARGS
   GSS_HIP(hipGetLastError());

@@ -1,0 +1,355 @@
+// SGS: sequential Gaussian simulation.
+// Replaces SGS.preprocess (/root/reference/src/simulation/sgs.jl:56-85) and the SeqSim path loop
+// (/root/reference/src/simulation/seq.jl:76-141) for the estimator/marginal pair SGS always builds
+// (SimpleKriging(variogram, mean), Normal(mean, sqrt(sill)), sgs.jl:62-67).
+//
+// The reference walks the path once per realisation and, at every node, searches the already simulated
+// cells (seq.jl:105), fits a simple-kriging system (seq.jl:121) and draws from Normal(mu, sigma) (seq.jl:129).
+// Which cells are "already simulated" depends on the path and on the data cells only, never on the drawn
+// values, and simple-kriging weights do not depend on the values either.  So the device splits the work:
+//
+//   stage A (gss_sgs_create, data parallel over the N nodes, done once for every realisation):
+//     masked exact k-NN (rank[neighbour] < rank[node]; knn.hip)  -> neighbours of every node
+//     one wave per node: k x k covariance, Cholesky, lambda = C^-1 c0, sigma^2 = sill - |L^-1 c0|^2
+//     fewer than minneighbors neighbours, or a failed factorisation (`status(fitted)`, seq.jl:124-128)
+//     -> marginal: no weights, sigma = sqrt(sill)
+//   stage B (gss_sgs_realize, parallel over realisations, sequential along the path):
+//     z[node] = mean + sum_j lambda_j (z[nb_j] - mean) + sigma * eps(seed, realisation, node)
+//     one lane per realisation; the field is kept node-major [N][R] so that the gathers coalesce.
+#include "gss_internal.h"
+#include "philox.h"
+
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace gss {
+
+constexpr int SGS_MAX_K = 64;
+
+__device__ __forceinline__ int sgs_tri(int i) { return (i * (i + 1)) >> 1; }
+
+__device__ __forceinline__ double sgs_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// lowest visiting rank inside each Morton batch of the search index
+__global__ __launch_bounds__(256) void sgs_batch_minrank_kernel(const int* __restrict__ perm,
+                                                                const int* __restrict__ rank, int n, int nb,
+                                                                int* __restrict__ bmin) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= nb) return;
+  const int j = b * 64 + lane;
+  int r = j < n ? rank[perm[j]] : INT_MAX;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int o = __shfl_xor(r, off);
+    r = o < r ? o : r;
+  }
+  if (lane == 0) bmin[b] = r;
+}
+
+// stage A: simple-kriging weights of one node per wave
+template <int DIM>
+__global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double* __restrict__ cent,
+                                                         const int* __restrict__ rank, int64_t N, int k,
+                                                         int minneighbors, const int* __restrict__ idx,
+                                                         const int* __restrict__ count, int* __restrict__ ncond,
+                                                         double* __restrict__ w_out, double* __restrict__ sigma_out) {
+  __shared__ double Lp[SGS_MAX_K * (SGS_MAX_K + 1) / 2];
+  __shared__ double nx[SGS_MAX_K][3];
+  const int64_t p = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (rank[p] < 0) {  // data cell: never simulated (seq.jl:103)
+    if (lane == 0) {
+      ncond[p] = 0;
+      sigma_out[p] = 0.0;
+    }
+    return;
+  }
+  const int cnt = count[p];
+  const double smarg = sqrt(vg.sill);  // sgs.jl:66
+  if (cnt < minneighbors || cnt <= 0) {  // seq.jl:107-109
+    if (lane == 0) {
+      ncond[p] = 0;
+      sigma_out[p] = smarg;
+    }
+    return;
+  }
+  double c0[DIM], xj[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) c0[a] = cent[p * DIM + a];
+  const bool act = lane < cnt;
+  const int nj = act ? idx[p * k + lane] : 0;
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) {
+    xj[a] = act ? cent[(int64_t)nj * DIM + a] : 0.0;
+    nx[lane][a] = xj[a];
+  }
+  double b = act ? cov_pair<DIM>(vg, xj, c0) : 0.0;
+  __syncthreads();
+  const int nent = sgs_tri(cnt);
+  for (int e = lane; e < nent; e += 64) {
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (sgs_tri(i + 1) <= e) ++i;
+    while (sgs_tri(i) > e) --i;
+    const int c = e - sgs_tri(i);
+    double xi[DIM], xc[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      xi[a] = nx[i][a];
+      xc[a] = nx[c][a];
+    }
+    Lp[e] = cov_pair<DIM>(vg, xi, xc);
+  }
+  __syncthreads();
+  // Cholesky, left-looking by columns: lane i owns row i
+  bool bad = false;
+  const double* rowi = Lp + sgs_tri(lane < cnt ? lane : 0);
+  for (int j = 0; j < cnt; ++j) {
+    double acc = 0.0;
+    const bool mine = lane >= j && lane < cnt;
+    if (mine) {
+      const double* rowj = Lp + sgs_tri(j);
+      acc = rowi[j];
+      for (int c = 0; c < j; ++c) acc = fma(-rowi[c], rowj[c], acc);
+    }
+    const double d = __shfl(acc, j);
+    if (!(d > 0.0)) {
+      bad = true;
+      break;
+    }
+    const double sq = sqrt(d);
+    if (mine) Lp[sgs_tri(lane) + j] = (lane == j) ? sq : acc / sq;
+    __syncthreads();
+  }
+  if (bad) {  // status(fitted) == false -> marginal (seq.jl:124-128)
+    if (lane == 0) {
+      ncond[p] = 0;
+      sigma_out[p] = smarg;
+    }
+    return;
+  }
+  // y = L^-1 c0 (column sweep)
+  for (int j = 0; j < cnt; ++j) {
+    const double ljj = Lp[sgs_tri(j) + j];
+    const double lij = (lane > j && lane < cnt) ? rowi[j] : 0.0;
+    const double yj = __shfl(b, j) / ljj;
+    if (lane == j) b = yj;
+    else b = fma(-lij, yj, b);
+  }
+  const double q = sgs_wave_sum(act ? b * b : 0.0);
+  // lambda = L^-T y (row j of L is contiguous: lane i < j reads L[j][i])
+  for (int j = cnt - 1; j >= 0; --j) {
+    const double ljj = Lp[sgs_tri(j) + j];
+    const double lj = __shfl(b, j) / ljj;
+    if (lane == j) b = lj;
+    else if (lane < j) b = fma(-Lp[sgs_tri(j) + lane], lj, b);
+  }
+  if (act) w_out[p * k + lane] = b;
+  if (lane == 0) {
+    const double v = vg.sill - q;
+    ncond[p] = cnt;
+    sigma_out[p] = sqrt(v > 0.0 ? v : 0.0);
+  }
+}
+
+// zt[dloc][r] = out[r][dloc] = zdata for the conditioning cells
+__global__ __launch_bounds__(256) void sgs_seed_data_kernel(const int64_t* __restrict__ dlocs,
+                                                            const double* __restrict__ zd, int64_t nd, int64_t N,
+                                                            int R, double* __restrict__ zt,
+                                                            double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nd * R) return;
+  const int64_t j = e / R;
+  const int r = (int)(e % R);
+  const int64_t c = dlocs[j];
+  zt[c * R + r] = zd[j];
+  out[(int64_t)r * N + c] = zd[j];
+}
+
+// stage B: the path recursion, one lane per realisation (all lanes visit the same node, so the neighbour list
+// and the weights are wave-uniform loads and the field gathers are contiguous across lanes)
+__global__ __launch_bounds__(64) void sgs_sweep_kernel(const int64_t* __restrict__ path, const int* __restrict__ rank,
+                                                       const int* __restrict__ idx, const int* __restrict__ ncond,
+                                                       const double* __restrict__ w, const double* __restrict__ sigma,
+                                                       int k, int64_t N, int R, double mean, uint64_t seed,
+                                                       int64_t first_real, const double* __restrict__ noise,
+                                                       double* __restrict__ zt, double* __restrict__ out) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= R) return;
+  for (int64_t t = 0; t < N; ++t) {
+    const int64_t node = path[t];
+    if (rank[node] < 0) continue;  // conditioning cell
+    const int c = ncond[node];
+    const double eps = noise ? noise[(int64_t)r * N + node]
+                             : philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)node);
+    double acc = 0.0;
+    for (int j = 0; j < c; ++j) acc = fma(w[node * k + j], zt[(int64_t)idx[node * k + j] * R + r] - mean, acc);
+    const double v = mean + acc + sigma[node] * eps;
+    zt[node * R + r] = v;
+    out[(int64_t)r * N + node] = v;
+  }
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+struct gss_sgs {
+  VgDev vg;
+  int dim = 0, k = 0;
+  int64_t N = 0, nd = 0;
+  double mean = 0.0;
+  DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;
+};
+
+extern "C" {
+
+int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
+                       int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
+                       int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
+                       int32_t flags, void* stream) {
+  GSS_REQUIRE(out != nullptr, "gss_sgs_create: out is NULL");
+  *out = nullptr;
+  GSS_REQUIRE(vg && centroids, "gss_sgs_create: NULL argument");
+  GSS_REQUIRE(N >= 1 && N < INT_MAX && dim >= 1 && dim <= 3, "gss_sgs_create: bad sizes");
+  GSS_REQUIRE(nd >= 0 && nd <= N && (nd == 0 || (dlocs && zdata)), "gss_sgs_create: bad conditioning data");
+  GSS_REQUIRE(maxneighbors >= 1 && maxneighbors <= N, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, "
+              "ui.jl:18-20)", maxneighbors, (long long)N);
+  GSS_REQUIRE(maxneighbors <= SGS_MAX_K, "maxneighbors = %d: the neighbour kernels hold at most %d neighbours",
+              maxneighbors, SGS_MAX_K);
+  (void)flags;
+  hipStream_t s = to_stream(stream);
+  auto* h = new gss_sgs();
+  struct Guard {
+    gss_sgs* p;
+    ~Guard() { delete p; }
+  } guard{h};
+  GSS_TRY(make_vgdev(vg, &h->vg));
+  GSS_REQUIRE(h->vg.dim == dim, "variogram dimension %d != domain dimension %d", h->vg.dim, dim);
+  h->dim = dim;
+  h->k = maxneighbors;
+  h->N = N;
+  h->nd = nd;
+  h->mean = mean;
+
+  // visiting rank of every cell (-1 = conditioning cell); path must be a permutation of 0..N-1
+  std::vector<int64_t> hpath((size_t)N);
+  std::vector<int> hrank((size_t)N, INT_MAX);
+  for (int64_t t = 0; t < N; ++t) {
+    const int64_t c = path ? path[t] : t;  // LinearPath (seq.jl:33)
+    GSS_REQUIRE(c >= 0 && c < N && hrank[(size_t)c] == INT_MAX, "path is not a permutation of the domain (step %lld)",
+                (long long)t);
+    hpath[(size_t)t] = c;
+    hrank[(size_t)c] = (int)t;
+  }
+  for (int64_t j = 0; j < nd; ++j) {
+    GSS_REQUIRE(dlocs[j] >= 0 && dlocs[j] < N, "data location %lld outside the domain", (long long)dlocs[j]);
+    GSS_REQUIRE(hrank[(size_t)dlocs[j]] >= 0, "data location %lld given twice", (long long)dlocs[j]);
+    hrank[(size_t)dlocs[j]] = -1;
+  }
+
+  DevBuf cent, bmin, cnt;
+  GSS_TRY(cent.alloc(sizeof(double) * (size_t)(N * dim)));
+  GSS_TRY(h->path.alloc(sizeof(int64_t) * (size_t)N));
+  GSS_TRY(h->rank.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(h->idx.alloc(sizeof(int) * (size_t)(N * h->k)));
+  GSS_TRY(h->ncond.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(cnt.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(h->w.alloc(sizeof(double) * (size_t)(N * h->k)));
+  GSS_TRY(h->sigma.alloc(sizeof(double) * (size_t)N));
+  GSS_HIP(hipMemcpyAsync(cent.p, centroids, cent.bytes, hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(h->path.p, hpath.data(), h->path.bytes, hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(h->rank.p, hrank.data(), h->rank.bytes, hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemsetAsync(h->w.p, 0, h->w.bytes, s));
+  if (nd > 0) {
+    GSS_TRY(h->dlocs.alloc(sizeof(int64_t) * (size_t)nd));
+    GSS_TRY(h->zd.alloc(sizeof(double) * (size_t)nd));
+    GSS_HIP(hipMemcpyAsync(h->dlocs.p, dlocs, h->dlocs.bytes, hipMemcpyHostToDevice, s));
+    GSS_HIP(hipMemcpyAsync(h->zd.p, zdata, h->zd.bytes, hipMemcpyHostToDevice, s));
+  }
+  KnnIndex ix;
+  GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
+  GSS_TRY(bmin.alloc(sizeof(int) * (size_t)ix.nb));
+  hipLaunchKernelGGL(sgs_batch_minrank_kernel, dim3((unsigned)((ix.nb + 3) / 4)), dim3(256), 0, s, ix.perm.as<int>(),
+                     h->rank.as<int>(), (int)N, ix.nb, bmin.as<int>());
+  GSS_HIP(hipGetLastError());
+  {
+    ProfScope ps("sgs_search", s);
+    GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, h->idx.as<int>(), cnt.as<int>(), s,
+                               h->rank.as<int>(), h->rank.as<int>(), bmin.as<int>()));
+  }
+  {
+    ProfScope ps("sgs_weights", s);
+#define GSS_SGS_ARGS h->vg, cent.as<double>(), h->rank.as<int>(), N, h->k, minneighbors, h->idx.as<int>(), \
+                     cnt.as<int>(), h->ncond.as<int>(), h->w.as<double>(), h->sigma.as<double>()
+    switch (dim) {
+      case 1: hipLaunchKernelGGL((sgs_weights_kernel<1>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+      case 2: hipLaunchKernelGGL((sgs_weights_kernel<2>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+      default: hipLaunchKernelGGL((sgs_weights_kernel<3>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+    }
+#undef GSS_SGS_ARGS
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_HIP(hipStreamSynchronize(s));  // host staging vectors and scratch are released on return
+  guard.p = nullptr;
+  *out = h;
+  return GSS_OK;
+}
+
+int32_t gss_sgs_destroy(gss_sgs_t* h) {
+  delete h;
+  return GSS_OK;
+}
+
+int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, double* sigma, int32_t mem,
+                        void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  hipStream_t s = to_stream(stream);
+  const hipMemcpyKind kind = mem == GSS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (idx) GSS_HIP(hipMemcpyAsync(idx, h->idx.p, h->idx.bytes, kind, s));
+  if (ncond) GSS_HIP(hipMemcpyAsync(ncond, h->ncond.p, h->ncond.bytes, kind, s));
+  if (w) GSS_HIP(hipMemcpyAsync(w, h->w.p, h->w.bytes, kind, s));
+  if (sigma) GSS_HIP(hipMemcpyAsync(sigma, h->sigma.p, h->sigma.bytes, kind, s));
+  if (mem == GSS_MEM_HOST) GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                        double* out, int32_t mem, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_REQUIRE(nreals >= 0 && first_real >= 0 && nreals < INT_MAX, "bad realisation range");
+  if (nreals == 0) return GSS_OK;
+  GSS_REQUIRE(out != nullptr, "gss_sgs_realize: out is NULL");
+  hipStream_t s = to_stream(stream);
+  const int64_t N = h->N;
+  const int R = (int)nreals;
+  Staged sn, so;
+  if (noise) GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(N * R), mem, s));
+  GSS_TRY(so.out(out, sizeof(double) * (size_t)(N * R), mem));
+  DevBuf zt;
+  GSS_TRY(zt.alloc(sizeof(double) * (size_t)(N * R)));
+  if (h->nd > 0) {
+    hipLaunchKernelGGL(sgs_seed_data_kernel, dim3((unsigned)((h->nd * R + 255) / 256)), dim3(256), 0, s,
+                       h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zt.as<double>(), so.as<double>());
+    GSS_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps("sgs_sweep", s);
+    hipLaunchKernelGGL(sgs_sweep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
+                       h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
+                       h->sigma.as<double>(), h->k, N, R, h->mean, seed, first_real,
+                       noise ? sn.as<double>() : nullptr, zt.as<double>(), so.as<double>());
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
+  GSS_HIP(hipStreamSynchronize(s));  // zt is released on return
+  return GSS_OK;
+}
+
+}  // extern "C"

@@ -7,7 +7,7 @@ solver front-ends (`solvers`) that mirror the reference's `solve(problem, solver
 from .geo import (CartesianGrid, DomainView, Ensemble, GeoTable, PointSet, asarray, domain, georef, parent,
                   parentindices, view)
 from .problems import EstimationProblem, SimulationProblem
-from .solvers import (FFTGS, LUGS, ExpWeight, IDWSolver, KrigingSolver, LWRSolver, TricubeWeight, kriging_ui,
+from .solvers import (FFTGS, LUGS, SGS, ExpWeight, IDWSolver, KrigingSolver, LWRSolver, TricubeWeight, kriging_ui,
                       searcher_ui, solve)
 from .variograms import (CubicVariogram, ExponentialVariogram, GaussianVariogram, MaternVariogram, MetricBall,
                          NestedVariogram, PentasphericalVariogram, SphericalVariogram)

@@ -243,12 +243,58 @@ class LUGSHandle:
         return out, wout
 
 
+class SGSHandle:
+    """gss_sgs_t*: neighbour lists, simple-kriging weights and sigmas of every path node in HBM."""
+
+    def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
+                 radii=None):
+        self._l = _lib.lib()
+        c = np.ascontiguousarray(centroids, dtype=np.float64)
+        if c.ndim == 1:
+            c = c[:, None]
+        self.N, dim = c.shape
+        self.k = int(maxneighbors)
+        pa = None if path is None else np.ascontiguousarray(path, dtype=np.int64)
+        dl = np.ascontiguousarray(dlocs if dlocs is not None else [], dtype=np.int64)
+        zd = np.ascontiguousarray(zdata if zdata is not None else [], dtype=np.float64)
+        ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
+        r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
+        v = _vg_struct(vg, dim)
+        h = C.c_void_p()
+        check(self._l.gss_sgs_create(C.byref(h), C.byref(v), float(mean), ptr(c), self.N, dim, ptr(pa), ptr(dl),
+                                     ptr(zd), dl.size, self.k, int(minneighbors), r, ptr(ir), 0, current_stream()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.gss_sgs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def weights(self):
+        idx = np.empty((self.N, self.k), dtype=np.int32)
+        nc = np.empty(self.N, dtype=np.int32)
+        w = np.empty((self.N, self.k))
+        sg = np.empty(self.N)
+        check(self._l.gss_sgs_weights(self._h, ptr(idx), ptr(nc), ptr(w), ptr(sg), MEM_HOST, current_stream()))
+        return idx, nc, w, sg
+
+    def realize(self, seed, first_real, nreals, noise=None):
+        noise = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
+        out = np.empty((nreals, self.N))
+        check(self._l.gss_sgs_realize(self._h, int(seed), int(first_real), int(nreals), ptr(noise), ptr(out),
+                                      MEM_HOST, current_stream()))
+        return out
+
+
 class HipEngine:
     """The product engine: every call lands in a gfx950 kernel."""
     name = "hip"
     Krig = KrigHandle
     FFTGS = FFTGSHandle
     LUGS = LUGSHandle
+    SGS = SGSHandle
 
     @staticmethod
     def cov_pairwise(vg, a, b=None):

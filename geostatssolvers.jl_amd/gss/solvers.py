@@ -3,6 +3,7 @@
     KrigingSolver  <- /root/reference/src/estimation/krig.jl:64-234  (+ ui.jl:11-50)
     IDWSolver      <- /root/reference/src/estimation/idw.jl:49-153
     LWRSolver      <- /root/reference/src/estimation/lwr.jl:53-158
+    SGS            <- /root/reference/src/simulation/sgs.jl:45-89 + seq.jl:42-141
     FFTGS          <- /root/reference/src/simulation/fft.jl:51-198
     LUGS           <- /root/reference/src/simulation/lu.jl:67-224
 
@@ -460,6 +461,71 @@ class LUGS(_Solver):
                     y = parallel.all_gather_concat(y, problem.nreals)
                 reals[v] = [y[r] for r in range(y.shape[0])]
         return Ensemble(problem.domain, {v: reals[v] for v in problem.variables})
+
+
+# ------------------------------------------------------------------------------------------
+# SGS
+# ------------------------------------------------------------------------------------------
+class SGS(_Solver):
+    """sgs.jl:45-89 on top of seq.jl:42-141.  `path` is "linear" (LinearPath), ("random", seed) or an explicit
+    visiting order; every realisation of one solve shares it (the device computes the neighbour lists and
+    simple-kriging weights of the path once and reuses them for all realisations)."""
+    PARAMS = dict(variogram=GaussianVariogram(), mean=0.0, path="linear", minneighbors=1, maxneighbors=10,
+                  neighborhood=None, distance="euclidean")                                     # sgs.jl:45-55
+    GLOBALS = dict(init="nearest", rng=None)
+
+    def preprocess(self, problem: SimulationProblem):
+        pdom = problem.domain
+        cent = pdom.centroids()
+        N = cent.shape[0]
+        if self.globals.get("init", "nearest") != "nearest":
+            raise NotImplementedError("only NearestInit is available")
+        pre = {}
+        for (var,) in [g for g in self.covariables(problem)]:
+            p = self.params(var)
+            if p["distance"] not in ("euclidean", None):
+                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            path = p["path"]
+            if path is None or (isinstance(path, str) and path == "linear"):
+                order = None
+            elif isinstance(path, tuple) and path[0] == "random":
+                order = np.random.default_rng(path[1]).permutation(N)
+            elif isinstance(path, str):
+                raise NotImplementedError(f"path {path!r}: give 'linear', ('random', seed) or a visiting order")
+            else:
+                order = np.asarray(path, dtype=np.int64)
+            dlocs, zd = np.empty(0, dtype=np.int64), np.empty(0)
+            pdata = problem.data
+            if pdata is not None and var in pdata.table:                              # initbuff, seq.jl:85
+                xd = pdata.domain.centroids()
+                zv = np.asarray(pdata[var], dtype=np.float64)
+                keep = ~np.isnan(zv)
+                idx, _ = self.engine.knn_search(cent, xd[keep], 1)
+                buff = {}
+                for j, v in zip(idx[:, 0], zv[keep]):
+                    buff[int(j)] = v
+                dlocs = np.array(sorted(buff), dtype=np.int64)
+                zd = np.array([buff[j] for j in dlocs])
+            _, nmax = searcher_ui(pdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # seq.jl:65
+            radius, radii = _ball(p["neighborhood"])
+            pre[var] = self.engine.SGS(p["variogram"], cent, order, dlocs, zd, float(p["mean"]), nmax,
+                                       p["minneighbors"], radius, radii)
+        return pre
+
+    def solve(self, problem: SimulationProblem, gather: bool = True):
+        pre = self.preprocess(problem)
+        seed = _seed_from(self.globals.get("rng"))
+        rank, ws = parallel.world()
+        lo, hi = parallel.shard_range(problem.nreals, rank, ws)
+        reals = {}
+        for vi, var in enumerate(problem.variables):
+            h = pre[var]
+            y = h.realize(seed + vi, lo, hi - lo) if hi > lo else np.empty((0, problem.domain.nelements()))
+            h.close()
+            if gather and ws > 1:
+                y = parallel.all_gather_concat(y, problem.nreals)
+            reals[var] = [y[r] for r in range(y.shape[0])]
+        return Ensemble(problem.domain, reals)
 
 
 def solve(problem, solver, **kw):

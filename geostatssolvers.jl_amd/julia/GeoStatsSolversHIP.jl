@@ -20,7 +20,7 @@ using Random
 
 import GeoStatsBase: solve, preprocess, solvesingle
 
-export KrigingSolverHIP, IDWSolverHIP, LWRSolverHIP, ExpWeight, TricubeWeight, FFTGSHIP, LUGSHIP
+export KrigingSolverHIP, IDWSolverHIP, LWRSolverHIP, ExpWeight, TricubeWeight, FFTGSHIP, LUGSHIP, SGSHIP
 
 const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 
@@ -380,6 +380,64 @@ function solvesingle(::SimulationProblem, covars::NamedTuple, solver::LUGSHIP, p
     push!(result, v₂ => Y₂)
   end
   result
+end
+
+# ---- SGS (sgs.jl:45-89 over seq.jl:42-141) -----------------------------------------------------
+@simsolver SGSHIP begin
+  @param variogram = GaussianVariogram()
+  @param mean = 0.0
+  @param path = LinearPath()
+  @param minneighbors = 1
+  @param maxneighbors = 10
+  @param neighborhood = nothing
+  @param distance = Euclidean()
+  @global init = NearestInit()
+  @global seed = rand(UInt64)
+end
+
+function preprocess(problem::SimulationProblem, solver::SGSHIP)
+  pdomain = domain(problem)
+  buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # seq.jl:85
+  C = coordmatrix(pdomain)
+  d, N = size(C)
+  preproc = Dict()
+  for covars in covariables(problem, solver), var in covars.names
+    p = covars.params[Set([var])]
+    path = Int64.(collect(traverse(pdomain, p.path)) .- 1)               # one visiting order for all realisations
+    dlocs = Int64.(findall(mask[var]) .- 1)
+    zdata = Float64.(buff[var][mask[var]])
+    k = p.maxneighbors
+    if k < 1 || k > N                                                     # searcher_ui, ui.jl:18-20
+      @warn "Invalid maximum number of neighbors. Adjusting to $N..."
+      k = N
+    end
+    radius, ir = -1.0, C_NULL
+    if !isnothing(p.neighborhood)
+      rs = ustrip.(radii(p.neighborhood))
+      length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
+    end
+    vg = Ref(cvariogram(p.variogram, d))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve C path dlocs zdata ir check(ccall((:gss_sgs_create, libgss), Int32,
+      (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Float64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
+       Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
+      h, vg, Float64(p.mean), C, N, Int32(d), path, dlocs, zdata, length(dlocs), Int32(k), Int32(p.minneighbors),
+      radius, ir, Int32(0), C_NULL))
+    preproc[var] = (handle=h[], N=N)
+  end
+  preproc
+end
+
+function solvesingle(::SimulationProblem, covars::NamedTuple, solver::SGSHIP, preproc; real::Int=0)
+  varreal = map(collect(covars.names)) do var
+    h, N = preproc[var]
+    out = Vector{Float64}(undef, N)
+    GC.@preserve out check(ccall((:gss_sgs_realize, libgss), Int32,
+      (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Cvoid}),
+      h, solver.seed, Int64(real), Int64(1), C_NULL, out, GSS_MEM_HOST, C_NULL))
+    var => out
+  end
+  Dict(varreal)
 end
 
 end # module

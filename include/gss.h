@@ -90,6 +90,7 @@ enum { GSS_PT_OK = 0, GSS_PT_MISSING = 1, GSS_PT_SINGULAR = 2 };
 typedef struct gss_krig gss_krig_t;
 typedef struct gss_fftgs gss_fftgs_t;
 typedef struct gss_lugs gss_lugs_t;
+typedef struct gss_sgs gss_sgs_t;
 
 /* ---- library ------------------------------------------------------------------------------ */
 int32_t gss_version(void);
@@ -230,6 +231,30 @@ int32_t gss_lugs_adopt_state(gss_lugs_t* h);
 int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t nreals,
                          const double* noise, double rho, const double* w1, double* out, double* w_out,
                          int32_t mem, void* stream);
+
+/* ---- SGS -----------------------------------------------------------
+ * gss_sgs_create replaces SGS.preprocess (sgs.jl:56-85: SimpleKriging(variogram, mean) and the marginal
+ *   Normal(mean, sqrt(sill))) and the realisation-independent part of the SeqSim path loop: for every
+ *   node of `path` the masked search among already simulated cells (seq.jl:105), the fit (seq.jl:121)
+ *   and the simple-kriging weights / standard deviation behind predictprob (seq.jl:126).  Nodes with
+ *   fewer than minneighbors simulated neighbours, or a failed fit, draw from the marginal (seq.jl:107-109,
+ *   124-128).  centroids N x d (host), path = visiting order (N 0-based cell indices, NULL = LinearPath),
+ *   dlocs / zdata = conditioning cells and their values (initbuff with NearestInit, seq.jl:85);
+ *   maxneighbors <= 64; radius / inv_radii as gss_knn_search.  All realisations of a handle share the path.
+ * gss_sgs_realize replaces solvesingle (seq.jl:76-141) for realisations first_real..first_real+nreals-1:
+ *   z[node] = mean + sum_j lambda_j (z[nb_j] - mean) + sigma eps, eps = Philox normal (seed, realisation,
+ *   cell) or noise[r * N + cell] when given.  out is nreals x N.
+ * gss_sgs_weights (test support): per node the neighbour list (N x k), the number of conditioning
+ *   neighbours actually used (0 = marginal or data cell), the weights (N x k) and sigma (N). */
+int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
+                       int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
+                       int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
+                       int32_t flags, void* stream);
+int32_t gss_sgs_destroy(gss_sgs_t* h);
+int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, double* sigma, int32_t mem,
+                        void* stream);
+int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                        double* out, int32_t mem, void* stream);
 
 /* ---- noise (test support): the Philox streams used above, n values for one realisation ----- */
 int32_t gss_philox_uniform(uint64_t seed, int64_t real, int64_t n, double* out, int32_t mem, void* stream);

@@ -76,9 +76,24 @@ class _LUGS:
         return (np.stack(ys), np.stack(ws)) if nreals else (np.empty((0, self.N)), np.empty((0, self.ns)))
 
 
+class _SGS:
+    def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
+                 radii=None):
+        self.a = (_ovg(vg), mean, np.asarray(centroids, dtype=np.float64), path, np.asarray(dlocs, dtype=np.int64),
+                  np.asarray(zdata, dtype=np.float64))
+        self.kw = dict(maxneighbors=maxneighbors, minneighbors=minneighbors, radius=radius, radii=radii)
+
+    def close(self):
+        pass
+
+    def realize(self, seed, first_real, nreals, noise=None):
+        from oracle import sgs
+        return sgs.realize(*self.a, seed, first_real, nreals, **self.kw)
+
+
 class OracleEngine:
     name = "oracle-stand-in"
-    Krig, FFTGS, LUGS = _Krig, _FFTGS, _LUGS
+    Krig, FFTGS, LUGS, SGS = _Krig, _FFTGS, _LUGS, _SGS
 
     @staticmethod
     def cov_pairwise(vg, a, b=None):

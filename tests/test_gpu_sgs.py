@@ -1,0 +1,127 @@
+"""SGS on the device (gss_sgs_create / gss_sgs_realize) vs the oracle's per-realisation path loop
+(seq.jl:76-141).  Neighbour lists bit-exact; realisations 1e-9 (well-conditioned models: the recursion
+propagates rounding along the path); conditioning cells exact."""
+import numpy as np
+import pytest
+
+from oracle import fftgs as offt, philox, sgs as S
+from oracle.variogram import Variogram, cov_h
+
+pytestmark = pytest.mark.gpu
+
+
+def _vg(kind, **kw):
+    import gss
+    ctor = dict(spherical=gss.SphericalVariogram, exponential=gss.ExponentialVariogram,
+                matern=gss.MaternVariogram)[kind]
+    okw = dict(kw)
+    if "nu" in kw:
+        kw = dict(kw)
+        kw["order"] = kw.pop("nu")
+    return ctor(**kw), Variogram(kind, **okw)
+
+
+CASES = [
+    # dims, variogram, mean, k, minneighbors, ball, ndata, random path
+    ((40, 30), ("spherical", dict(range=9.0, sill=1.3)), 0.5, 10, 1, dict(radius=8.0), 6, False),
+    ((300,), ("exponential", dict(range=12.0)), 0.0, 6, 1, {}, 4, False),
+    ((12, 10, 8), ("matern", dict(range=6.0, nu=1.5)), -1.0, 16, 2, {}, 9, True),
+    ((35, 35), ("spherical", dict(range=7.0, nugget=0.1)), 0.0, 12, 3, dict(radii=(9.0, 4.0)), 0, True),
+    ((9, 7), ("exponential", dict(range=4.0)), 2.0, 63, 1, {}, 2, False),           # k == N: everything simulated
+]
+
+
+@pytest.mark.parametrize("dims,vgspec,mean,k,nmin,ball,nd,rpath", CASES)
+def test_realisations_match_oracle(dims, vgspec, mean, k, nmin, ball, nd, rpath):
+    from gss.engine import SGSHandle
+    gvg, ovg = _vg(vgspec[0], **vgspec[1])
+    cent = offt.grid_centroids(dims)
+    N = cent.shape[0]
+    rng = np.random.default_rng(N + k)
+    dl = np.sort(rng.choice(N, nd, replace=False)) if nd else np.empty(0, dtype=np.int64)
+    zd = rng.normal(size=nd)
+    path = rng.permutation(N) if rpath else None
+    h = SGSHandle(gvg, cent, path, dl, zd, mean, k, nmin, ball.get("radius"), ball.get("radii"))
+    z = h.realize(42, 3, 3)
+    ref = S.realize(ovg, mean, cent, path, dl, zd, 42, 3, 3, maxneighbors=k, minneighbors=nmin, **ball)
+    assert np.max(np.abs(z - ref)) < 1e-9
+    if nd:
+        assert np.array_equal(z[:, dl], np.tile(zd, (3, 1)))                  # test/simulation/sgs.jl:18-20
+    # the same normals passed in explicitly give the same field; realisation r depends on (seed, r) only
+    eps = np.stack([philox.normal(42, 3 + r, N) for r in range(3)])
+    assert np.max(np.abs(h.realize(0, 0, 3, noise=eps) - z)) < 1e-9      # device vs numpy Box-Muller: ulps
+    assert np.array_equal(h.realize(42, 4, 1)[0], z[1])
+    h.close()
+
+
+def test_weights_are_the_simple_kriging_weights():
+    from gss.engine import SGSHandle
+    gvg, ovg = _vg("spherical", range=10.0)
+    cent = offt.grid_centroids((30, 20))
+    N = cent.shape[0]
+    dl = np.array([77, 300, 512])
+    h = SGSHandle(gvg, cent, None, dl, np.array([1.0, -1.0, 0.5]), 0.0, 8, 1)
+    idx, nc, w, sg = h.weights()
+    from oracle.variogram import cov_pairwise
+    sim = np.zeros(N, dtype=bool)
+    sim[dl] = True
+    for node in range(N):
+        if node in dl:
+            assert nc[node] == 0
+            continue
+        if node in (0, 1, 150, 599):
+            cand = np.flatnonzero(sim)
+            d2 = ((cent[cand] - cent[node]) ** 2)
+            d2 = d2[:, 0] + d2[:, 1]
+            nb = cand[np.argsort(d2, kind="stable")[:8]]
+            assert nc[node] == nb.size and np.array_equal(idx[node, :nb.size], nb)
+            lam = np.linalg.solve(cov_pairwise(ovg, cent[nb]), cov_pairwise(ovg, cent[nb], cent[node][None])[:, 0])
+            assert np.allclose(w[node, :nb.size], lam, atol=1e-11)
+            assert np.isclose(sg[node] ** 2, 1.0 - lam @ cov_pairwise(ovg, cent[nb], cent[node][None])[:, 0], atol=1e-11)
+        sim[node] = True
+    h.close()
+
+
+def test_statistics_and_conditioning_at_scale():
+    """256 x 256 cells, 128 realisations in one sweep: hard data exact, marginal moments and the lag-1
+    covariance of the model within sampling error (size-independent properties)."""
+    from gss.engine import SGSHandle
+    gvg, ovg = _vg("exponential", range=15.0, sill=2.0)
+    cent = offt.grid_centroids((256, 256))
+    N = cent.shape[0]
+    rng = np.random.default_rng(5)
+    h = SGSHandle(gvg, cent, rng.permutation(N), None, None, 1.0, 16, 1)
+    z = h.realize(9, 0, 128)
+    h.close()
+    assert abs(z.mean() - 1.0) < 0.05 and abs(z.var() - 2.0) < 0.1
+    g = z.reshape(128, 256, 256) - 1.0
+    for lag in (1, 4):
+        emp = np.mean(g[:, :, lag:] * g[:, :, :-lag])
+        assert abs(emp - float(cov_h(ovg, np.array(float(lag))))) < 0.08
+    dl = np.sort(rng.choice(N, 200, replace=False))
+    zd = rng.normal(size=200)
+    hc = SGSHandle(gvg, cent, None, dl, zd, 0.0, 12, 1, 40.0)
+    zc = hc.realize(1, 0, 8)
+    hc.close()
+    assert np.array_equal(zc[:, dl], np.tile(zd, (8, 1))) and np.all(np.isfinite(zc))
+
+
+def test_solver_through_solve_and_errors():
+    import gss
+    from gss import _lib
+    grid = gss.CartesianGrid((100, 100), (0.5, 0.5), (1.0, 1.0))          # test/simulation/sgs.jl:2-20
+    data = gss.georef(dict(z=[1.0, 0.0, 1.0]), [(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)])
+    solver = gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=35.0), neighborhood=gss.MetricBall(30.0))),
+                     rng=2017)
+    sol1 = gss.solve(gss.SimulationProblem(data, grid, "z", 3), solver)
+    sol2 = gss.solve(gss.SimulationProblem(grid, {"z": float}, 3), solver)
+    reals = sol1["z"]
+    li = lambda i, j: (j - 1) * 100 + (i - 1)
+    assert all(r[li(25, 25)] == 1.0 and r[li(50, 75)] == 0.0 and r[li(75, 50)] == 1.0 for r in reals)
+    assert len(sol2["z"]) == 3 and np.all(np.isfinite(sol2["z"][2]))
+    cent = grid.centroids()
+    with pytest.raises(_lib.GSSError, match="at most 64"):
+        from gss.engine import SGSHandle
+        SGSHandle(gss.SphericalVariogram(range=35.0), cent, None, None, None, 0.0, 65)
+    with pytest.raises(_lib.GSSError, match="not a permutation"):
+        SGSHandle(gss.SphericalVariogram(range=35.0), cent[:10], np.zeros(10, dtype=np.int64), None, None, 0.0, 3)
