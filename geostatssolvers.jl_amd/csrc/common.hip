@@ -164,6 +164,7 @@ static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
     case GSS_VG_SPHERICAL:
     case GSS_VG_CUBIC:
     case GSS_VG_PENTASPHERICAL:
+    case GSS_VG_SINEHOLE:
       *out_kind = kind;
       return GSS_OK;
     case GSS_VG_MATERN:
@@ -205,6 +206,20 @@ int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
   } else {
     GSS_REQUIRE(vg->range > 0.0, "variogram range must be positive (got %g)", vg->range);
     v.inv_range = 1.0 / vg->range;
+  }
+  if (vg->kind == GSS_VG_POWER) {
+    // gamma(h) = scaling h^exponent + nugget: no sill.  The device works with the pseudo-covariance
+    // A - gamma(h) (A = `sill` field); with the unbiasedness constraint the estimates do not depend on A.
+    GSS_REQUIRE(vg->nextra == 0, "a power variogram cannot be nested on the device");
+    GSS_REQUIRE(vg->nu > 0.0 && vg->nu < 2.0, "power variogram exponent %g outside (0, 2)", vg->nu);
+    GSS_REQUIRE(vg->sill > vg->nugget, "power variogram: pseudo-sill %g must exceed the nugget %g", vg->sill,
+                vg->nugget);
+    v.kind = GSS_VG_POWER;
+    v.mscale = vg->range / v.cs;  // `range` carries the scaling factor
+    v.pw = 0.5 * vg->nu;
+    v.inv_range = 1.0;
+    *out = v;
+    return GSS_OK;
   }
   GSS_TRY(device_kind(vg->kind, vg->nu, &v.kind, &v.mscale));
   for (int e = 0; e < vg->nextra; ++e) {

@@ -314,6 +314,7 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
     gss_fftgs* h;
     ~Guard() { delete h; }
   } guard{h};
+  GSS_REQUIRE(vg_is_stationary(&v3), "variogram model must be stationary");  // fft.jl:91, lu.jl:110
   GSS_TRY(make_vgdev(&v3, &h->vg));
   int64_t d[3] = {1, 1, 1};
   double sp[3] = {1.0, 1.0, 1.0};

@@ -95,6 +95,7 @@ struct VgExtra {
   double cs;         // contribution (partial sill) of this structure
   double inv_range;
   double mscale;
+  double pw;
   double ir[3];
 };
 
@@ -106,13 +107,16 @@ struct VgDev {
   double sill;       // total sill (all structures + nugget)
   double cs;         // contribution of the first structure
   double inv_range;  // 1 / range (1 when aniso)
-  double mscale;     // Matern: sqrt(2 nu) * 3
+  double mscale;     // Matern: sqrt(2 nu) * 3; power: scaling / cs
+  double pw;         // power: exponent / 2 (applied to the squared distance)
   double ir[3];      // inverse radii (aniso) or 1
   VgExtra ex[3];
 };
 enum { VG_MATERN12 = 30, VG_MATERN32 = 31, VG_MATERN52 = 32 };
 
 int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out);
+// fft.jl:91, lu.jl:110: the simulation solvers need a finite sill
+inline bool vg_is_stationary(const gss_variogram_t* vg) { return vg->kind != GSS_VG_POWER; }
 
 // squared (possibly Mahalanobis) distance, dimension order, no FMA contraction (kNN tie contract)
 template <int DIM>
@@ -130,7 +134,7 @@ __device__ __forceinline__ double sqdist_nofma(const double* a, const double* b,
 }
 
 // g(h) = 1 - f(h / range): normalised covariance shape of one structure, from the squared distance (d2 > 0)
-__device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range, double mscale) {
+__device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range, double mscale, double pw) {
   switch (kind) {
     case GSS_VG_GAUSSIAN: return exp(-3.0 * (d2 * inv_range * inv_range));
     case GSS_VG_EXPONENTIAL: return exp(-3.0 * (sqrt(d2) * inv_range));
@@ -152,6 +156,11 @@ __device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range
       const double x2 = x * x, x3 = x2 * x;
       return x < 1.0 ? 1.0 - (7.0 * x2 - 8.75 * x3 + 3.5 * x3 * x2 - 0.75 * x3 * x3 * x) : 0.0;
     }
+    case GSS_VG_SINEHOLE: {
+      const double t = 3.14159265358979323846 * (sqrt(d2) * inv_range);
+      return sin(t) / t;
+    }
+    case GSS_VG_POWER: return 1.0 - mscale * pow(d2, pw);  // pseudo-covariance A - gamma(h), see gss.h
     default: {  // GSS_VG_PENTASPHERICAL
       const double x = sqrt(d2) * inv_range;
       const double x2 = x * x, x3 = x2 * x;
@@ -166,10 +175,10 @@ template <int DIM>
 __device__ __forceinline__ double cov_pair(const VgDev& v, const double* a, const double* b) {
   const double d2 = sqdist_nofma<DIM>(a, b, v.ir, v.aniso != 0);
   if (d2 <= 0.0) return v.sill;  // positive radii: d2 == 0 iff the points coincide
-  double c = v.cs * vg_shape(v.kind, d2, v.inv_range, v.mscale);
+  double c = v.cs * vg_shape(v.kind, d2, v.inv_range, v.mscale, v.pw);
   for (int e = 0; e < v.nextra; ++e) {
     const double d2e = sqdist_nofma<DIM>(a, b, v.ex[e].ir, v.ex[e].aniso != 0);
-    c += v.ex[e].cs * vg_shape(v.ex[e].kind, d2e, v.ex[e].inv_range, v.ex[e].mscale);
+    c += v.ex[e].cs * vg_shape(v.ex[e].kind, d2e, v.ex[e].inv_range, v.ex[e].mscale, v.ex[e].pw);
   }
   return c;
 }

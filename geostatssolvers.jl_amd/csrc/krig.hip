@@ -572,6 +572,8 @@ int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t var
     ~Guard() { delete h; }
   } guard{h};
   GSS_TRY(make_vgdev(vg, &h->vg));
+  GSS_REQUIRE(variant != GSS_KRIG_SIMPLE || vg_is_stationary(vg),
+              "simple kriging needs a stationary variogram (a power variogram has no sill)");
   h->variant = variant;
   h->sk_mean = sk_mean;
   h->degree = degree;

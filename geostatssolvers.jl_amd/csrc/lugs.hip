@@ -96,6 +96,7 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
     gss_lugs* h;
     ~Guard() { delete h; }
   } guard{h};
+  GSS_REQUIRE(vg_is_stationary(vg), "variogram model must be stationary");  // fft.jl:91, lu.jl:110
   GSS_TRY(make_vgdev(vg, &h->vg));
   const int dim = h->dim = h->vg.dim;
   h->N = N;

@@ -230,6 +230,7 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
     gss_sgs* p;
     ~Guard() { delete p; }
   } guard{h};
+  GSS_REQUIRE(vg_is_stationary(vg), "variogram model must be stationary");  // fft.jl:91, lu.jl:110
   GSS_TRY(make_vgdev(vg, &h->vg));
   GSS_REQUIRE(h->vg.dim == dim, "variogram dimension %d != domain dimension %d", h->vg.dim, dim);
   h->dim = dim;

@@ -10,6 +10,7 @@ from .problems import EstimationProblem, SimulationProblem
 from .solvers import (FFTGS, LUGS, SGS, ExpWeight, IDWSolver, KrigingSolver, LWRSolver, TricubeWeight, kriging_ui,
                       searcher_ui, solve)
 from .variograms import (CubicVariogram, ExponentialVariogram, GaussianVariogram, MaternVariogram, MetricBall,
-                         NestedVariogram, PentasphericalVariogram, SphericalVariogram)
+                         NestedVariogram, PentasphericalVariogram, PowerVariogram, SineHoleVariogram,
+                         SphericalVariogram)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

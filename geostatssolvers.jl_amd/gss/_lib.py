@@ -162,7 +162,8 @@ def current_stream():
     return None
 
 
-_KINDS = {"gaussian": 0, "exponential": 1, "spherical": 2, "matern": 3, "cubic": 4, "pentaspherical": 5}
+_KINDS = {"gaussian": 0, "exponential": 1, "spherical": 2, "matern": 3, "cubic": 4, "pentaspherical": 5,
+          "sinehole": 6, "power": 7}
 
 
 def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0, radii=None, extras=()) -> Variogram:
@@ -178,7 +179,8 @@ def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0,
         if len(radii) != dim:
             raise ValueError(f"anisotropic ball has {len(radii)} radii but the domain is {dim}-D")
         v.aniso = 1
-        v.range = 1.0
+        if kind != "power":            # power: `range` carries the scaling factor
+            v.range = 1.0
         for k, r in enumerate(radii):
             v.inv_radii[k] = 1.0 / float(r)
     if len(extras) > 3:

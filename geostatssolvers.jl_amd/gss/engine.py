@@ -18,7 +18,14 @@ from ._lib import MEM_DEVICE, MEM_HOST, check, current_stream, is_torch, make_va
 SK, OK, UK, EDK = 0, 1, 2, 3
 
 
-def _vg_struct(vg, dim):
+def _vg_struct(vg, dim, extent=None):
+    if getattr(vg, "kind", None) == "power":
+        # pseudo-covariance A - gamma(h): A = 2 gamma(diameter of the data box) keeps the data block positive
+        # definite; constrained kriging results do not depend on A (gss.h, GSS_VG_POWER)
+        if extent is None:
+            raise ValueError("a power variogram is not stationary: only kriging with data can use it")
+        a = 2.0 * (vg.range * max(float(extent), 1e-300) ** vg.nu) + vg.nugget + 1e-300
+        return make_variogram("power", dim, a, vg.nugget, vg.range, vg.nu, None)
     if getattr(vg, "kind", None) == "nested":
         # first structure carries the total nugget; every structure contributes c_i (sill_i - nugget_i)
         terms = [(w, m) for w, m in vg.terms if w * (m.sill - m.nugget) > 0.0]
@@ -29,6 +36,14 @@ def _vg_struct(vg, dim):
         extras = [(m.kind, w * (m.sill - m.nugget), m.range, m.nu, m.radii) for w, m in terms[1:]]
         return make_variogram(m0.kind, dim, w0 * (m0.sill - m0.nugget) + nug, nug, m0.range, m0.nu, m0.radii, extras)
     return make_variogram(vg.kind, dim, vg.sill, vg.nugget, vg.range, vg.nu, vg.radii)
+
+
+def _extent(x):
+    """Diameter of the bounding box of point-major coordinates (numpy or CUDA tensor)."""
+    if is_torch(x):
+        return float(((x.max(dim=0).values - x.min(dim=0).values) ** 2).sum().sqrt())
+    x = np.asarray(x)
+    return float(np.sqrt(((x.max(axis=0) - x.min(axis=0)) ** 2).sum()))
 
 
 def _space(x):
@@ -70,7 +85,7 @@ class KrigHandle:
         self.ndrift = 0 if dd is None else dd.shape[1]
         self.variant = variant
         h = C.c_void_p()
-        v = _vg_struct(vg, self.dim)
+        v = _vg_struct(vg, self.dim, extent=_extent(x))
         check(self._l.gss_krig_create(C.byref(h), C.byref(v), variant, float(mean or 0.0), int(degree or 0),
                                       self.ndrift, ptr(x), ptr(zz), ptr(dd), self.n,
                                       0 if factor else _lib.KRIG_NO_FACTOR, current_stream()))

@@ -33,7 +33,7 @@ class VariogramModel:
     radii: Optional[Tuple[float, ...]] = None
 
     def isstationary(self):
-        return True
+        return self.kind != "power"
 
     # gamma1 + gamma2 and c * gamma build a NestedVariogram ([DEP] Variography)
     def __add__(self, other):
@@ -107,3 +107,15 @@ def CubicVariogram(ball=None, **kw):
 
 def PentasphericalVariogram(ball=None, **kw):
     return _make("pentaspherical", ball, **kw)
+
+
+def SineHoleVariogram(ball=None, **kw):
+    return _make("sinehole", ball, **kw)
+
+
+def PowerVariogram(*, scaling=1.0, nugget=0.0, exponent=1.0):
+    """gamma(h) = scaling h^exponent + nugget ([DEP] Variography PowerVariogram): not stationary, so only the
+    constrained kriging variants accept it.  Stored as range := scaling, nu := exponent, sill := inf."""
+    if not 0.0 < exponent < 2.0:
+        raise ValueError("exponent must be in (0, 2)")
+    return VariogramModel("power", float("inf"), float(nugget), float(scaling), float(exponent), None)

@@ -70,6 +70,7 @@ vgkind(::SphericalVariogram) = Int32(2)
 vgkind(::MaternVariogram) = Int32(3)
 vgkind(::CubicVariogram) = Int32(4)
 vgkind(::PentasphericalVariogram) = Int32(5)
+vgkind(::SineHoleVariogram) = Int32(6)
 
 function structure(γ)            # (kind, aniso, range, nu, inv_radii) of one basic model
   rs = radii(metricball(γ))
@@ -79,7 +80,15 @@ function structure(γ)            # (kind, aniso, range, nu, inv_radii) of one b
   (vgkind(γ), Int32(aniso), aniso ? 1.0 : Float64(ustrip(range(γ))), ν, ir)
 end
 
-function cvariogram(γ, dim)
+# `extent` = diameter of the data bounding box: only needed for the non-stationary PowerVariogram, which the
+# device handles through the pseudo-covariance A - gamma(h) with A = 2 gamma(extent) (gss.h, GSS_VG_POWER);
+# the kriging solver passes it, the simulation solvers do not and therefore keep the reference's assertion.
+function cvariogram(γ, dim; extent=nothing)
+  if γ isa PowerVariogram && !isnothing(extent)
+    A = 2 * Float64(γ.scaling) * Float64(extent)^Float64(γ.exponent) + Float64(nugget(γ)) + floatmin(Float64)
+    return GssVariogram(Int32(7), Int32(dim), A, Float64(nugget(γ)), Float64(γ.scaling), Float64(γ.exponent), Int32(0),
+                        Int32(0), (1.0, 1.0, 1.0), Int32(0), Int32(0), (NOEXTRA, NOEXTRA, NOEXTRA))
+  end
   isstationary(γ) || throw(ArgumentError("variogram model must be stationary"))   # fft.jl:91-93, lu.jl:110
   if γ isa NestedVariogram       # gamma = sum c_i gamma_i: first structure carries the total nugget
     cs, γs = γ.cs, γ.γs
@@ -152,7 +161,8 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
       @warn "Invalid maximum number of neighbors. Adjusting to $n..."
       k = n
     end
-    vg = Ref(cvariogram(p.variogram, d))
+    extent = sqrt(sum(abs2, maximum(X, dims=2) .- minimum(X, dims=2)))
+    vg = Ref(cvariogram(p.variogram, d; extent))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     μ = Vector{Float64}(undef, m); σ² = similar(μ); status = Vector{UInt8}(undef, m)
     GC.@preserve X z X0 Fd F0 μ σ² status begin

@@ -53,7 +53,13 @@ enum {
   GSS_VG_SPHERICAL = 2,
   GSS_VG_MATERN = 3,         /* nu in {0.5, 1.5, 2.5} on device */
   GSS_VG_CUBIC = 4,
-  GSS_VG_PENTASPHERICAL = 5
+  GSS_VG_PENTASPHERICAL = 5,
+  GSS_VG_SINEHOLE = 6,       /* gamma = (sill - nugget) (1 - sin(pi h/r) / (pi h/r)) + nugget          */
+  GSS_VG_POWER = 7           /* gamma = scaling h^exponent + nugget: NOT stationary.  Fields: range = scaling,
+                              * nu = exponent in (0,2), sill = constant A of the pseudo-covariance A - gamma(h)
+                              * (any A >= max gamma over the data; ordinary / universal / external-drift
+                              * kriging results do not depend on it).  Rejected by simple kriging and by the
+                              * simulation solvers (fft.jl:91, lu.jl:110).                                  */
 };
 
 typedef struct gss_variogram {

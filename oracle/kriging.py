@@ -23,7 +23,7 @@ from typing import Optional, Sequence
 import numpy as np
 import scipy.linalg as sla
 
-from .variogram import Variogram, cov_pairwise
+from .variogram import Variogram, cov_pairwise, isstationary, pairwise
 
 SK, OK, UK, EDK = 0, 1, 2, 3
 
@@ -111,7 +111,8 @@ def fit(variant: int, vg: Variogram, x: np.ndarray, z: np.ndarray, mean: float =
     F = drift_matrix(variant, x, degree, drift_data)
     nc = F.shape[1]
     lhs = np.zeros((n + nc, n + nc))
-    lhs[:n, :n] = cov_pairwise(vg, x)
+    # stationary: covariance form; otherwise (power model) the variogram form [G F; F' 0]
+    lhs[:n, :n] = cov_pairwise(vg, x) if isstationary(vg) else pairwise(vg, x)
     lhs[:n, n:] = F
     lhs[n:, :n] = F.T
     ok = True
@@ -139,7 +140,8 @@ def predict(fk: FittedKriging, x0: np.ndarray, drift_dom: Optional[np.ndarray] =
     x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
     m = x0.shape[0]
     rhs = np.empty((fk.n + fk.nc, m))
-    rhs[:fk.n] = cov_pairwise(fk.vg, fk.x, x0)
+    stat = isstationary(fk.vg)
+    rhs[:fk.n] = cov_pairwise(fk.vg, fk.x, x0) if stat else pairwise(fk.vg, fk.x, x0)
     if fk.nc:
         rhs[fk.n:] = drift_matrix(fk.variant, x0, fk.degree, drift_dom).T
     w = _solve(fk, rhs)
@@ -148,7 +150,7 @@ def predict(fk: FittedKriging, x0: np.ndarray, drift_dom: Optional[np.ndarray] =
         mu = fk.mean + lam.T @ (fk.z - fk.mean)
     else:
         mu = lam.T @ fk.z
-    var = fk.vg.sill - np.sum(rhs * w, axis=0)
+    var = fk.vg.sill - np.sum(rhs * w, axis=0) if stat else np.sum(rhs * w, axis=0)
     return mu, np.maximum(var, 0.0)
 
 

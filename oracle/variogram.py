@@ -14,6 +14,10 @@ with the "practical range" convention (factor 3) of Variography:
     Matern(nu)      f = 1 - 2^(1-nu)/Gamma(nu) * d^nu * K_nu(d),  d = sqrt(2 nu) * 3 x
     Cubic           f = 7x^2 - 8.75x^3 + 3.5x^5 - 0.75x^7   (x < 1), 1 otherwise
     Pentaspherical  f = 1.875x - 1.25x^3 + 0.375x^5         (x < 1), 1 otherwise
+    SineHole        f = 1 - sin(pi x) / (pi x)
+and the one non-stationary model of the zoo,
+    Power           gamma(h) = scaling * h^exponent + nugget * (h > 0)        (no sill; `range` holds the
+                    scaling and `nu` the exponent; kriging then uses the variogram form of the system)
 
 Anisotropy: `MetricBall((a, b, ...))` gives a Mahalanobis distance
 h = sqrt(sum(((x_i - y_i) / r_i)^2)) with range 1
@@ -26,7 +30,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-KINDS = ("gaussian", "exponential", "spherical", "matern", "cubic", "pentaspherical")
+KINDS = ("gaussian", "exponential", "spherical", "matern", "cubic", "pentaspherical", "sinehole", "power")
 
 
 @dataclass
@@ -46,8 +50,10 @@ class Variogram:
             if len(self.radii) == 1:       # MetricBall(r) is isotropic with range r
                 self.range = self.radii[0]
                 self.radii = None
-            else:
+            elif self.kind != "power":
                 self.range = 1.0
+        if self.kind == "power":
+            self.sill = float("inf")
 
 
 @dataclass
@@ -65,8 +71,8 @@ class Nested:
 
 
 def isstationary(vg) -> bool:
-    """All supported models have a finite sill (fft.jl:91, lu.jl:110)."""
-    return True
+    """Finite sill (fft.jl:91, lu.jl:110): everything but the power model."""
+    return getattr(vg, "kind", None) != "power"
 
 
 def sill(vg: Variogram) -> float:
@@ -96,6 +102,10 @@ def _shape(vg: Variogram, x: np.ndarray) -> np.ndarray:
         return np.where(x < 1.0, 7 * x ** 2 - 8.75 * x ** 3 + 3.5 * x ** 5 - 0.75 * x ** 7, 1.0)
     if k == "pentaspherical":
         return np.where(x < 1.0, 1.875 * x - 1.25 * x ** 3 + 0.375 * x ** 5, 1.0)
+    if k == "sinehole":
+        t = np.pi * np.asarray(x, dtype=np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(t > 0, 1.0 - np.sin(t) / t, 0.0)
     if k == "matern":
         nu = float(vg.nu)
         d = np.sqrt(2.0 * nu) * 3.0 * x
@@ -114,6 +124,8 @@ def _shape(vg: Variogram, x: np.ndarray) -> np.ndarray:
 
 def gamma_h(vg: Variogram, h: np.ndarray) -> np.ndarray:
     h = np.asarray(h, dtype=np.float64)
+    if vg.kind == "power":
+        return vg.range * h ** vg.nu + vg.nugget * (h > 0)
     return (vg.sill - vg.nugget) * _shape(vg, h / vg.range) + vg.nugget * (h > 0)
 
 
