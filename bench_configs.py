@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 2,3,4] [--quick]
+    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs] [--quick]
 """
 import argparse
 import json
@@ -155,6 +155,107 @@ def cfg4_local(a, gss, _lib):
                              "sample": "oracle.kriging.approxsolve (search + fit + predict per point as krig.jl:205-228), %d points in %.1f s" % (ns, cdt)}}
 
 
+def _est(a, gss, _lib, which):
+    """Section 8f.3 rows: IDW / LWR with k = 16 neighbours, 50 000 3-D samples, 1.25e6 estimation points."""
+    from gss.engine import HipEngine
+    n, k = 50_000, 16
+    m = 100_000 if a.quick else 1_250_000
+    x = np.random.default_rng(16).uniform(0, 100, (n, 3))
+    z = np.sin(x[:, 0] / 9.0) + 0.01 * x[:, 1] + np.random.default_rng(61).normal(size=n) * 0.1
+    x0 = np.random.default_rng(17).uniform(0, 100, (m, 3))
+    xd, zd, x0d = (torch.as_tensor(v, device="cuda") for v in (x, z, x0))
+    run = (lambda q: HipEngine.idw(xd, zd, q, k, 1, 2.0)) if which == "idw" else (lambda q: HipEngine.lwr(xd, zd, q, k))
+    run(x0d[:50000])
+    sync()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    mu, aux, st = run(x0d)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    knn = _lib.profile_read("knn")
+    est = _lib.profile_read(which)
+    from oracle import idw_lwr as E
+    ns = 400
+    t1 = time.perf_counter()
+    r = E.idw(x, z, x0[:ns], k, exponent=2.0) if which == "idw" else E.lwr(x, z, x0[:ns], k)
+    cdt = time.perf_counter() - t1
+    err = float(np.max(np.abs(mu[:ns].cpu().numpy() - r[0])))
+    # algorithmic HBM bytes per point of the estimator kernel: k neighbour indices (4 B) + k gathered samples
+    # (3 coordinates + value, 32 B) + the point (24 B) + 17 B of outputs
+    bytes_pt = k * 36 + 41
+    return {"config": "8f.3 %s k=%d, %d 3-D samples, %d points on this GPU" % (which.upper(), k, n, m),
+            "metric": "estimated points/s", "value": round(m / dt, 1), "unit": "points/s",
+            "roofline": {"bound": "hbm", "kernel": which, "achieved": round(bytes_pt * m / (est[0] * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK, "unit": "GB/s", "frac": round(bytes_pt * m / (est[0] * 1e-3) / 1e9 / HBM_PEAK, 4)},
+            "kernel_ms": {"knn": round(knn[0], 2), which: round(est[0], 2)}, "missing": int(st.sum().item()),
+            "parity_max_abs_err_first_%d" % ns: err,
+            "cpu_baseline": {"value": round(ns / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                             "sample": "oracle.idw_lwr.%s, %d points in %.1f s" % (which, ns, cdt)}}
+
+
+def cfg_idw(a, gss, _lib):
+    return _est(a, gss, _lib, "idw")
+
+
+def cfg_lwr(a, gss, _lib):
+    return _est(a, gss, _lib, "lwr")
+
+
+def cfg_sgs(a, gss, _lib):
+    """Section 8f.4 row: SGS on a 512 x 512 grid, spherical range 35, k = 16, ball 30, 200 conditioning cells,
+    1024 realisations per sweep (the recursion is sequential along the path, parallel over realisations)."""
+    from gss.engine import SGSHandle
+    from oracle import fftgs as offt
+    e = 128 if a.quick else 512
+    R = 1024          # one wave carries 64 realisations through the path; 16 waves run side by side
+    cent = offt.grid_centroids((e, e))
+    N = cent.shape[0]
+    rng = np.random.default_rng(5)
+    dl = np.sort(rng.choice(N, 200, replace=False))
+    zd = rng.normal(size=200)
+    vg = gss.SphericalVariogram(range=35.0)
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    h = SGSHandle(vg, cent, None, dl, zd, 0.0, 16, 1, 30.0)
+    sync()
+    t_pre = time.perf_counter() - t0
+    h.realize(1, 0, R, device=True)
+    sync()
+    _lib.profile_reset()
+    t0 = time.perf_counter()
+    z = h.realize(1, 0, R, device=True)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    sweep = _lib.profile_read("sgs_sweep")
+    zc = z.cpu().numpy()
+    honoured = bool(np.array_equal(zc[:, dl], np.tile(zd, (R, 1))))
+    h.close()
+    # CPU baseline: the oracle's per-realisation path loop on a 64 x 64 grid (cost per node grows with N)
+    from oracle import sgs as S
+    from oracle.variogram import Variogram
+    ce = 64
+    cc = offt.grid_centroids((ce, ce))
+    t1 = time.perf_counter()
+    S.realize(Variogram("spherical", range=35.0), 0.0, cc, None, np.array([100, 2000]), np.array([1.0, 0.0]), 1, 0, 1,
+              maxneighbors=16, radius=30.0)
+    cdt = time.perf_counter() - t1
+    # stage B algorithmic bytes per node and realisation: k gathered values + the value written twice
+    bytes_nr = (16 + 2) * 8
+    return {"config": "8f.4 SGS %dx%d grid, spherical range 35, k=16, ball 30, 200 data, %d realisations" % (e, e, R),
+            "metric": "simulated cells/s (all realisations)", "value": round(N * R / dt, 1), "unit": "cells/s",
+            "preprocess_s": round(t_pre, 3), "realize_s": round(dt, 4),
+            "roofline": {"bound": "latency (path recursion)", "kernel": "sgs_sweep",
+                         "achieved": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9 / HBM_PEAK, 5)},
+            "kernel_ms": {"sgs_sweep": round(sweep[0], 2)}, "us_per_path_node": round(sweep[0] * 1e3 / N, 3),
+            "hard_data_honoured": honoured,
+            "field_std": round(float(zc.std()), 4),
+            "cpu_baseline": {"value": round(ce * ce / cdt, 1), "unit": "cells/s", "cores": 1, "kind": "port",
+                             "sample": "oracle.sgs.realize, one realisation of a %dx%d grid in %.1f s" % (ce, ce, cdt)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4")
@@ -163,7 +264,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local}
+    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -158,18 +158,47 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double*
   }
 }
 
-// zt[dloc][r] = out[r][dloc] = zdata for the conditioning cells
+// zt[dloc][r] = zdata for the conditioning cells
 __global__ __launch_bounds__(256) void sgs_seed_data_kernel(const int64_t* __restrict__ dlocs,
                                                             const double* __restrict__ zd, int64_t nd, int64_t N,
-                                                            int R, double* __restrict__ zt,
-                                                            double* __restrict__ out) {
+                                                            int R, double* __restrict__ zt) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= nd * R) return;
   const int64_t j = e / R;
   const int r = (int)(e % R);
   const int64_t c = dlocs[j];
   zt[c * R + r] = zd[j];
-  out[(int64_t)r * N + c] = zd[j];
+}
+
+// zt[cell][r] = eps(seed, realisation, cell): the standard normals the sweep consumes, drawn up front by the whole
+// device (a single wave walking the path would otherwise spend half of every step inside Philox + Box-Muller)
+__global__ __launch_bounds__(256) void sgs_noise_kernel(uint64_t seed, int64_t first_real, int64_t N, int R,
+                                                        const double* __restrict__ noise, double* __restrict__ zt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * R) return;
+  const int64_t cell = e / R;
+  const int r = (int)(e % R);
+  zt[e] = noise ? noise[(int64_t)r * N + cell] : philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)cell);
+}
+
+// out[r][cell] = zt[cell][r] through a 64 x 64 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void sgs_transpose_kernel(const double* __restrict__ zt, int64_t N, int R,
+                                                            double* __restrict__ out) {
+  __shared__ double tile[64][65];
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i;
+    const int r = r0 + tx;
+    if (c < N && r < R) tile[i][tx] = zt[c * R + r];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i;
+    const int64_t c = c0 + tx;
+    if (c < N && r < R) out[(int64_t)r * N + c] = tile[tx][i];
+  }
 }
 
 // stage B: the path recursion, one lane per realisation (all lanes visit the same node, so the neighbour list
@@ -177,22 +206,54 @@ __global__ __launch_bounds__(256) void sgs_seed_data_kernel(const int64_t* __res
 __global__ __launch_bounds__(64) void sgs_sweep_kernel(const int64_t* __restrict__ path, const int* __restrict__ rank,
                                                        const int* __restrict__ idx, const int* __restrict__ ncond,
                                                        const double* __restrict__ w, const double* __restrict__ sigma,
-                                                       int k, int64_t N, int R, double mean, uint64_t seed,
-                                                       int64_t first_real, const double* __restrict__ noise,
-                                                       double* __restrict__ zt, double* __restrict__ out) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
-  if (r >= R) return;
+                                                       int k, int64_t N, int R, double mean,
+                                                       double* __restrict__ zt) {
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x * 64 + lane;
+  const bool live = r < R;
+  const int rr = live ? r : R - 1;  // idle lanes shadow the last realisation (no stores): the wave stays uniform
+  // Everything that does not depend on simulated values is fetched one node ahead (two for the path itself):
+  // lane u holds neighbour u's index and weight of the NEXT node, read back with readlane when it is consumed.
+  int64_t node_n = path[0];
+  int64_t node_nn = N > 1 ? path[1] : 0;
+  int pc = ncond[node_n], prank = rank[node_n];
+  double psg = sigma[node_n];
+  int pidx = lane < k ? idx[node_n * k + lane] : 0;
+  double pw = lane < k ? w[node_n * k + lane] : 0.0;
+  double peps = zt[node_n * R + rr];  // the cell's own slot holds its normal until it is simulated
   for (int64_t t = 0; t < N; ++t) {
-    const int64_t node = path[t];
-    if (rank[node] < 0) continue;  // conditioning cell
-    const int c = ncond[node];
-    const double eps = noise ? noise[(int64_t)r * N + node]
-                             : philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)node);
+    const int64_t node = node_n;
+    const int c = pc, rk = prank, myidx = pidx;
+    const double sg = psg, myw = pw, eps = peps;
+    if (t + 1 < N) {
+      node_n = node_nn;
+      node_nn = t + 2 < N ? path[t + 2] : 0;
+      pc = ncond[node_n];
+      prank = rank[node_n];
+      psg = sigma[node_n];
+      pidx = lane < k ? idx[node_n * k + lane] : 0;
+      pw = lane < k ? w[node_n * k + lane] : 0.0;
+      peps = zt[node_n * R + rr];
+    }
+    if (rk < 0) continue;  // conditioning cell
     double acc = 0.0;
-    for (int j = 0; j < c; ++j) acc = fma(w[node * k + j], zt[(int64_t)idx[node * k + j] * R + r] - mean, acc);
-    const double v = mean + acc + sigma[node] * eps;
-    zt[node * R + r] = v;
-    out[(int64_t)r * N + node] = v;
+    // sixteen neighbours per trip, all gathers of a trip in flight together: a node costs about one memory round trip
+    for (int j0 = 0; j0 < c; j0 += 16) {
+      double ww[16], zz[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int j = j0 + u < c ? j0 + u : c - 1;
+        const int id = __builtin_amdgcn_readlane(myidx, j);
+        const int wl = __builtin_amdgcn_readlane(__double2loint(myw), j);
+        const int wh = __builtin_amdgcn_readlane(__double2hiint(myw), j);
+        ww[u] = j0 + u < c ? __hiloint2double(wh, wl) : 0.0;
+        zz[u] = zt[(int64_t)id * R + rr];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(ww[u], zz[u] - mean, acc);
+    }
+    const double v = mean + acc + sg * eps;
+    if (live) zt[node * R + r] = v;
   }
 }
 
@@ -335,19 +396,27 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
   GSS_TRY(so.out(out, sizeof(double) * (size_t)(N * R), mem));
   DevBuf zt;
   GSS_TRY(zt.alloc(sizeof(double) * (size_t)(N * R)));
+  {
+    ProfScope ps("sgs_noise", s);
+    hipLaunchKernelGGL(sgs_noise_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real, N, R,
+                       noise ? sn.as<double>() : nullptr, zt.as<double>());
+    GSS_HIP(hipGetLastError());
+  }
   if (h->nd > 0) {
     hipLaunchKernelGGL(sgs_seed_data_kernel, dim3((unsigned)((h->nd * R + 255) / 256)), dim3(256), 0, s,
-                       h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zt.as<double>(), so.as<double>());
+                       h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zt.as<double>());
     GSS_HIP(hipGetLastError());
   }
   {
     ProfScope ps("sgs_sweep", s);
     hipLaunchKernelGGL(sgs_sweep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
                        h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
-                       h->sigma.as<double>(), h->k, N, R, h->mean, seed, first_real,
-                       noise ? sn.as<double>() : nullptr, zt.as<double>(), so.as<double>());
+                       h->sigma.as<double>(), h->k, N, R, h->mean, zt.as<double>());
     GSS_HIP(hipGetLastError());
   }
+  hipLaunchKernelGGL(sgs_transpose_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, s,
+                     zt.as<double>(), N, R, so.as<double>());
+  GSS_HIP(hipGetLastError());
   GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
   GSS_HIP(hipStreamSynchronize(s));  // zt is released on return
   return GSS_OK;

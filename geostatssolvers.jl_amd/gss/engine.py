@@ -295,11 +295,15 @@ class SGSHandle:
         check(self._l.gss_sgs_weights(self._h, ptr(idx), ptr(nc), ptr(w), ptr(sg), MEM_HOST, current_stream()))
         return idx, nc, w, sg
 
-    def realize(self, seed, first_real, nreals, noise=None):
-        noise = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
-        out = np.empty((nreals, self.N))
+    def realize(self, seed, first_real, nreals, noise=None, device=False):
+        noise = _prep_in(noise)
+        if device or is_torch(noise):
+            import torch
+            out = torch.empty((nreals, self.N), dtype=torch.float64, device="cuda")
+        else:
+            out = np.empty((nreals, self.N))
         check(self._l.gss_sgs_realize(self._h, int(seed), int(first_real), int(nreals), ptr(noise), ptr(out),
-                                      MEM_HOST, current_stream()))
+                                      _space(out), current_stream()))
         return out
 
 
@@ -342,18 +346,32 @@ class HipEngine:
 
     @staticmethod
     def _estimate(fn_name, extra, xdata, z, xdom, k, minneighbors, radius, radii):
+        """Host arrays in -> host arrays out; if `xdom` is a CUDA tensor everything stays in HBM."""
         l = _lib.lib()
-        x = np.ascontiguousarray(xdata, dtype=np.float64)
-        if x.ndim == 1:
-            x = x[:, None]
-        zz = np.ascontiguousarray(z, dtype=np.float64)
-        c = np.ascontiguousarray(xdom, dtype=np.float64).reshape(-1, x.shape[1])
-        m = c.shape[0]
-        mean, aux, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
+        dev = is_torch(xdom) and xdom.is_cuda
+        if dev:
+            import torch
+            x = xdata if is_torch(xdata) else torch.as_tensor(np.asarray(xdata, dtype=np.float64), device="cuda")
+            x = _prep_in(x.reshape(x.shape[0], -1))
+            zz = _prep_in(z if is_torch(z) else torch.as_tensor(np.asarray(z, dtype=np.float64), device="cuda"))
+            c = _prep_in(xdom.reshape(-1, x.shape[1]))
+            m = c.shape[0]
+            mean = torch.empty(m, dtype=torch.float64, device="cuda")
+            aux = torch.empty(m, dtype=torch.float64, device="cuda")
+            st = torch.empty(m, dtype=torch.uint8, device="cuda")
+        else:
+            x = np.ascontiguousarray(xdata, dtype=np.float64)
+            if x.ndim == 1:
+                x = x[:, None]
+            zz = np.ascontiguousarray(z, dtype=np.float64)
+            c = np.ascontiguousarray(xdom, dtype=np.float64).reshape(-1, x.shape[1])
+            m = c.shape[0]
+            mean, aux, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
         check(getattr(l, fn_name)(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k), int(minneighbors), r,
-                                  ptr(ir), *extra, ptr(mean), ptr(aux), ptr(st), MEM_HOST, current_stream()))
+                                  ptr(ir), *extra, ptr(mean), ptr(aux), ptr(st), MEM_DEVICE if dev else MEM_HOST,
+                                  current_stream()))
         return mean, aux, st
 
     @staticmethod
