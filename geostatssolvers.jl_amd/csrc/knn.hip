@@ -23,6 +23,8 @@ namespace gss {
 
 constexpr int KNN_Q = 4;
 constexpr int KNN_TILE = 2048;
+constexpr int KNN_SORT_MIN = 12;   // candidates per batch from which sort + merge beats serial insertion ...
+constexpr int KNN_SORT_MIN_K = 8;  // ... for lists of at least this length (measured, tools/knn_sweep.py)
 
 __device__ __forceinline__ bool key_less(double ad, int ai, double bd, int bi) {
   return ad < bd || (ad == bd && ai < bi);
@@ -32,6 +34,49 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// one compare-exchange stage of a bitonic network on (d, i) keys: lanes `stride` apart, ascending when `up`
+__device__ __forceinline__ void bitonic_cx(double& d, int& i, int lane, int stride, bool up) {
+  const double od = __shfl_xor(d, stride);
+  const int oi = __shfl_xor(i, stride);
+  const bool lower = (lane & stride) == 0;
+  const bool take = (lower == up) ? key_less(od, oi, d, i) : key_less(d, i, od, oi);
+  if (take) {
+    d = od;
+    i = oi;
+  }
+}
+
+// full ascending sort of 64 keys held one per lane
+__device__ __forceinline__ void bitonic_sort64(double& d, int& i, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+    const bool up = (lane & size) == 0;
+#pragma unroll
+    for (int stride = size >> 1; stride >= 1; stride >>= 1) bitonic_cx(d, i, lane, stride, up);
+  }
+}
+
+// list (ascending, one key per lane) <- the 64 smallest keys of list U batch, ascending; batch is consumed
+__device__ __forceinline__ void bitonic_merge64(double& ld, int& li, double bd, int bi, int lane) {
+  const double rd = __shfl(bd, 63 - lane);
+  const int ri = __shfl(bi, 63 - lane);
+  if (key_less(rd, ri, ld, li)) {
+    ld = rd;
+    li = ri;
+  }
+#pragma unroll
+  for (int stride = 32; stride >= 1; stride >>= 1) bitonic_cx(ld, li, lane, stride, true);
 }
 
 template <int DIM>
@@ -124,9 +169,11 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
 // pays in Meshes/NearestNeighbors) and cut into batches of 64 consecutive points with bounding boxes.  One wave
 // owns one query: lane b first bounds the distance to batch b (min squared distance to its box, accumulated with
 // the same rounded operations as the point distance, hence never larger than the distance to any point inside);
-// batches are then visited nearest box first for the seed and in Morton order afterwards, and a batch whose bound
-// exceeds the current k-th distance is skipped.  Results are identical to the brute-force kernel: the ranking
-// key is still (d2, original index).
+// a second level of boxes covers groups of 64 batches.  Groups, and batches inside an opened group, are visited
+// nearest box first, and a box whose bound exceeds the current k-th distance is never opened.  A batch in which
+// many candidates beat the current k-th key is sorted and merged into the list with bitonic networks, otherwise
+// candidates are inserted one at a time.  Results are identical to the brute-force kernel: the ranking key is
+// still (d2, original index).
 // ---------------------------------------------------------------------------------------------
 static inline uint32_t spread_bits(uint32_t v, int dim) {
   // interleave the low 10 bits of v with dim-1 zero bits between consecutive bits
@@ -178,6 +225,25 @@ int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, h
       bhi[(size_t)b * dim + a] = h;
     }
   }
+  const int nb1 = (nb + 63) / 64;
+  std::vector<double> blo1((size_t)nb1 * dim), bhi1((size_t)nb1 * dim);
+  for (int g = 0; g < nb1; ++g) {
+    const int b0 = g * 64, b1 = b0 + 64 < nb ? b0 + 64 : nb;
+    for (int a = 0; a < dim; ++a) {
+      double l = blo[(size_t)b0 * dim + a], h = bhi[(size_t)b0 * dim + a];
+      for (int b = b0 + 1; b < b1; ++b) {
+        l = blo[(size_t)b * dim + a] < l ? blo[(size_t)b * dim + a] : l;
+        h = bhi[(size_t)b * dim + a] > h ? bhi[(size_t)b * dim + a] : h;
+      }
+      blo1[(size_t)g * dim + a] = l;
+      bhi1[(size_t)g * dim + a] = h;
+    }
+  }
+  GSS_TRY(ix->lo1.alloc(sizeof(double) * blo1.size()));
+  GSS_TRY(ix->hi1.alloc(sizeof(double) * bhi1.size()));
+  GSS_HIP(hipMemcpyAsync(ix->lo1.p, blo1.data(), sizeof(double) * blo1.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipMemcpyAsync(ix->hi1.p, bhi1.data(), sizeof(double) * bhi1.size(), hipMemcpyHostToDevice, s));
+  ix->nb1 = nb1;
   GSS_TRY(ix->xs.alloc(sizeof(double) * xs.size()));
   GSS_TRY(ix->perm.alloc(sizeof(int32_t) * perm.size()));
   GSS_TRY(ix->lo.alloc(sizeof(double) * blo.size()));
@@ -224,9 +290,11 @@ __device__ __forceinline__ double box_sqdist_nofma(const double* lo, const doubl
 template <int DIM, bool MASKED>
 __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restrict__ xs, const int* __restrict__ perm,
                                                          const double* __restrict__ blo, const double* __restrict__ bhi,
-                                                         int n, int nb, const double* __restrict__ centers, int64_t m,
-                                                         int k, double r2, int use_ball, int aniso, double ir0,
-                                                         double ir1, double ir2, const int* __restrict__ rank,
+                                                         const double* __restrict__ blo1,
+                                                         const double* __restrict__ bhi1, int n, int nb, int nb1,
+                                                         const double* __restrict__ centers, int64_t m, int k,
+                                                         double r2, int use_ball, int aniso, double ir0, double ir1,
+                                                         double ir2, const int* __restrict__ rank,
                                                          const int* __restrict__ qrank,
                                                          const int* __restrict__ bminrank, int* __restrict__ idx_out,
                                                          int* __restrict__ count_out) {
@@ -242,75 +310,88 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
   double ld = INF;   // lane l: l-th nearest so far (INF / INT_MAX = empty)
   int li = INT_MAX;
 
-  for (int c0 = 0; c0 < nb; c0 += 64) {
-    const int b = c0 + lane;
-    double dmin = INF;
-    if (b < nb) {
+  // two box levels: groups of 64 batches, then the batches of a group; both visited nearest box first, and a
+  // box whose bound exceeds the current k-th distance is never opened
+  for (int c1 = 0; c1 < nb1; c1 += 64) {
+    const int g = c1 + lane;
+    double d1 = INF;
+    if (g < nb1) {
       double lo[DIM], hi[DIM];
 #pragma unroll
       for (int a = 0; a < DIM; ++a) {
-        lo[a] = blo[b * DIM + a];
-        hi[a] = bhi[b * DIM + a];
+        lo[a] = blo1[g * DIM + a];
+        hi[a] = bhi1[g * DIM + a];
       }
-      dmin = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
+      d1 = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
     }
-    bool done = !(b < nb);
-    if (MASKED && !done && !(bminrank[b] < myrank)) done = true;
-    if (done) dmin = INF;
-    // seed: nearest box of this chunk first (ties: lowest lane), so that tau is tight before the sweep
-    double best = dmin;
-    int bl = lane;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double od = __shfl_xor(best, off);
-      const int ol = __shfl_xor(bl, off);
-      if (od < best || (od == best && ol < bl)) {
-        best = od;
-        bl = ol;
-      }
-    }
-    bool seeded = false;
+    bool done1 = !(g < nb1);
     while (true) {
-      // current k-th best key, re-read from the list (lane k - 1) whenever it may have changed
-      double tau_d = readlane_f64(ld, k - 1);
-      int tau_i = __builtin_amdgcn_readlane(li, k - 1);
-      const bool cand = !done && dmin <= tau_d && (!use_ball || dmin <= r2);
-      const unsigned long long mask = __ballot(cand);
-      if (!mask) break;
-      int pick = __builtin_ctzll(mask);
-      if (!seeded) {
-        seeded = true;
-        if ((mask >> bl) & 1ull) pick = bl;
-      }
-      if (lane == pick) done = true;
-      const int j = (c0 + pick) * 64 + lane;
-      const bool valid = j < n;
-      double c[DIM];
+      const double tau1 = readlane_f64(ld, k - 1);
+      const bool cand1 = !done1 && d1 <= tau1 && (!use_ball || d1 <= r2);
+      if (!__ballot(cand1)) break;
+      const double mn1 = wave_min_f64(cand1 ? d1 : INF);
+      const int pick1 = __builtin_ctzll(__ballot(cand1 && d1 == mn1));
+      if (lane == pick1) done1 = true;
+      const int b = (c1 + pick1) * 64 + lane;
+      double dmin = INF;
+      bool done = !(b < nb);
+      if (!done) {
+        double lo[DIM], hi[DIM];
 #pragma unroll
-      for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
-      const int oidx = valid ? perm[j] : INT_MAX;
-      const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);
-      bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
-      if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
-      unsigned long long qm = __ballot(qual);
-      while (qm) {
-        const int src = __builtin_ctzll(qm);
-        qm &= qm - 1;
-        const double cd = readlane_f64(d2, src);
-        const int ci = __builtin_amdgcn_readlane(oidx, src);
-        if (!key_less(cd, ci, tau_d, tau_i)) continue;
-        const int pos = __popcll(__ballot(key_less(ld, li, cd, ci)));
-        const double up_d = __shfl_up(ld, 1);
-        const int up_i = __shfl_up(li, 1);
-        if (lane > pos) {
-          ld = up_d;
-          li = up_i;
-        } else if (lane == pos) {
-          ld = cd;
-          li = ci;
+        for (int a = 0; a < DIM; ++a) {
+          lo[a] = blo[b * DIM + a];
+          hi[a] = bhi[b * DIM + a];
         }
-        tau_d = readlane_f64(ld, k - 1);
-        tau_i = __builtin_amdgcn_readlane(li, k - 1);
+        dmin = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
+        if (MASKED && !(bminrank[b] < myrank)) done = true;
+      }
+      while (true) {
+        // current k-th best key, re-read from the list (lane k - 1) whenever it may have changed
+        double tau_d = readlane_f64(ld, k - 1);
+        int tau_i = __builtin_amdgcn_readlane(li, k - 1);
+        const bool cand = !done && dmin <= tau_d && (!use_ball || dmin <= r2);
+        if (!__ballot(cand)) break;
+        const double mn = wave_min_f64(cand ? dmin : INF);
+        const int pick = __builtin_ctzll(__ballot(cand && dmin == mn));
+        if (lane == pick) done = true;
+        const int j = ((c1 + pick1) * 64 + pick) * 64 + lane;
+        const bool valid = j < n;
+        double c[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
+        const int oidx = valid ? perm[j] : INT_MAX;
+        const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);
+        bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
+        if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
+        unsigned long long qm = __ballot(qual);
+        if (k >= KNN_SORT_MIN_K && __popcll(qm) >= KNN_SORT_MIN) {
+          // many candidates beat the current k-th key (always true for the first batches): sort the batch and merge
+          // it into the list with bitonic networks instead of inserting one candidate at a time
+          double bd = qual ? d2 : INF;
+          int bi = qual ? oidx : INT_MAX;
+          bitonic_sort64(bd, bi, lane);
+          bitonic_merge64(ld, li, bd, bi, lane);
+          qm = 0;
+        }
+        while (qm) {
+          const int src = __builtin_ctzll(qm);
+          qm &= qm - 1;
+          const double cd = readlane_f64(d2, src);
+          const int ci = __builtin_amdgcn_readlane(oidx, src);
+          if (!key_less(cd, ci, tau_d, tau_i)) continue;
+          const int pos = __popcll(__ballot(key_less(ld, li, cd, ci)));
+          const double up_d = __shfl_up(ld, 1);
+          const int up_i = __shfl_up(li, 1);
+          if (lane > pos) {
+            ld = up_d;
+            li = up_i;
+          } else if (lane == pos) {
+            ld = cd;
+            li = ci;
+          }
+          tau_d = readlane_f64(ld, k - 1);
+          tau_i = __builtin_amdgcn_readlane(li, k - 1);
+        }
       }
     }
   }
@@ -333,7 +414,8 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
   if (aniso)
     for (int a = 0; a < ix.dim; ++a) ir[a] = inv_radii_host[a];
   dim3 grid((unsigned)((m + 3) / 4));
-#define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), (int)ix.n, ix.nb, \
+#define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), \
+                     ix.lo1.as<double>(), ix.hi1.as<double>(), (int)ix.n, ix.nb, ix.nb1, \
                      centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count
   if (rank) {
     GSS_REQUIRE(qrank && bminrank, "masked search needs query ranks and per-batch minimum ranks");
