@@ -183,6 +183,63 @@ __device__ __forceinline__ double cov_pair(const VgDev& v, const double* a, cons
   return c;
 }
 
+// Four covariances at once (same arithmetic as cov_pair).  The model switch is taken once and the four
+// evaluations sit in one basic block, so their sqrt / exp dependency chains overlap instead of running one after
+// the other -- what a kernel with few waves per SIMD needs (krig_local.hip).
+__device__ __forceinline__ void vg_shape4(int kind, const double* d2, double inv_range, double mscale, double pw,
+                                          double* g) {
+#define GSS_SHAPE4(EXPR)                                   \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {          \
+    const double q2 = d2[u];                               \
+    g[u] = (EXPR);                                         \
+  }
+  switch (kind) {
+    case GSS_VG_GAUSSIAN: GSS_SHAPE4(exp(-3.0 * (q2 * inv_range * inv_range))); break;
+    case GSS_VG_EXPONENTIAL: GSS_SHAPE4(exp(-3.0 * (sqrt(q2) * inv_range))); break;
+    case VG_MATERN12: GSS_SHAPE4(exp(-(mscale * (sqrt(q2) * inv_range)))); break;
+    case VG_MATERN32: {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double d = mscale * (sqrt(d2[u]) * inv_range);
+        g[u] = (1.0 + d) * exp(-d);
+      }
+      break;
+    }
+    case VG_MATERN52: {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double d = mscale * (sqrt(d2[u]) * inv_range);
+        g[u] = (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
+      }
+      break;
+    }
+    default: GSS_SHAPE4(vg_shape(kind, q2, inv_range, mscale, pw)); break;
+  }
+#undef GSS_SHAPE4
+}
+
+// out[u] = C(a_u, b) for four points a_u and one point b
+template <int DIM>
+__device__ __forceinline__ void cov_pair4(const VgDev& v, const double (*a)[DIM], const double* b, double* out) {
+  double d2[4], g[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) d2[u] = sqdist_nofma<DIM>(a[u], b, v.ir, v.aniso != 0);
+  vg_shape4(v.kind, d2, v.inv_range, v.mscale, v.pw, g);
+  double c[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) c[u] = v.cs * g[u];
+  for (int e = 0; e < v.nextra; ++e) {
+    double d2e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d2e[u] = sqdist_nofma<DIM>(a[u], b, v.ex[e].ir, v.ex[e].aniso != 0);
+    vg_shape4(v.ex[e].kind, d2e, v.ex[e].inv_range, v.ex[e].mscale, v.ex[e].pw, g);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] += v.ex[e].cs * g[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) out[u] = d2[u] <= 0.0 ? v.sill : c[u];
+}
+
 // ---------------------------------------------------------------------------------------------
 // dense FP64 toolkit (dense_la.hip, gemm_f64.hip)
 // ---------------------------------------------------------------------------------------------

@@ -269,6 +269,308 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// K5, MFMA-tiled variant (default).  Same mathematics as krig_local_kernel above, but the k x k system is held in
+// registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r <-> element
+// (row (l >> 4) + 4 r, column l & 15)) and factorised as A = U'U by tiles:
+//   diagonal tile   : through LDS into "lane = row" form, 16 x 16 Cholesky and triangular inverse V = U_kk^-1 with
+//                     v_readlane broadcasts, V back in tile layout (U_kk itself is never needed again)
+//   U_kj  = V' A_kj,  A_ij -= U_ki' U_kj,  right-hand sides  Y_k = V' B_k,  B_i -= U_ki' Y_k
+// Every product has the form X'Y with X and Y in tile layout, which is exactly what the MFMA consumes: register s
+// of X is the A operand of k-slice s (A[i][k] on lane i + 16 k) and register s of Y is its B operand, so no data
+// ever changes layout between products.  The right-hand sides [c0 | z | F] ride along as 16 columns, and one
+// last product G = Y'Y yields every dot product the block elimination needs (|y_c|^2, y_z.y_c, Y_F'Y_F, ...).
+// Rows beyond the neighbour count are padded with the identity.
+// ---------------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4_t xty(const d4_t& x, const d4_t& y, d4_t acc) {  // acc + X'Y
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s], y[s], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ double rl64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// t: symmetric positive definite 16 x 16 tile (tile layout).  Returns V = U^-1 (tile layout, upper triangular) for
+// t = U'U; *bad is set when a pivot is not positive.  S: 16 x 17 doubles of LDS owned by this wave.
+__device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int lane, bool* bad) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
+  __syncthreads();
+  const int i = c;  // lanes 16..63 shadow lanes 0..15
+  double row[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
+  __syncthreads();
+  // lower Cholesky t = L L', right-looking so that the updates of one step are independent of each other; lane i
+  // owns row i (its upper part holds don't-care values); the diagonal keeps 1 / L_jj
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double d = rl64(row[j], j);
+    if (!(d > 0.0)) {
+      *bad = true;
+      d = 1.0;
+    }
+    double y = __builtin_amdgcn_rsq(d);  // refined to full precision by two Newton steps
+    const double h = 0.5 * d;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    row[j] = (i == j) ? y : row[j] * y;
+#pragma unroll
+    for (int q = j + 1; q < 16; ++q) row[q] = fma(-row[j], rl64(row[j], q), row[q]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of later columns from being hoisted (SGPR pressure)
+  }
+  // W = L^-1 in place (unblocked trtri, last column first): lane i ends up with row i of W.  Column j of W is
+  // -W22 * L[j+1.., j] / L_jj with W22 the already inverted trailing block, whose row i is in lane i's registers.
+#pragma unroll
+  for (int q = 1; q < 16; ++q)
+    if (q > i) row[q] = 0.0;  // clear the don't-care upper part: W is lower triangular
+#pragma unroll
+  for (int j = 15; j >= 0; --j) {
+    const double dinv = rl64(row[j], j);  // 1 / L_jj (kept on the diagonal by the factorisation)
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = j + 1; q < 16; ++q) {
+      const double lqj = rl64(row[j], q);  // L[q][j]
+      if ((q - j) & 1) a0 = fma(row[q], lqj, a0);
+      else a1 = fma(row[q], lqj, a1);
+    }
+    row[j] = (i == j) ? dinv : (i > j ? -(a0 + a1) * dinv : 0.0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // V = W' back to tile layout: V[a][b] = W[b][a], lane b writes column b
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
+  __syncthreads();
+  d4_t v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = S[(g + 4 * r) * 17 + c];
+  __syncthreads();
+  return v;
+}
+
+constexpr int tile_id(int i, int j) { return i * 4 - (i * (i - 1)) / 2 + (j - i); }  // upper block triangle, i <= j
+
+template <int DIM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ drift_data,
+                                                             const double* __restrict__ x0,
+                                                             const double* __restrict__ drift_dom, int64_t m, int k,
+                                                             int minneighbors, const int* __restrict__ idx,
+                                                             const int* __restrict__ count,
+                                                             double* __restrict__ mean_out,
+                                                             double* __restrict__ var_out,
+                                                             uint8_t* __restrict__ status_out) {
+  __shared__ double nx[LMAX_K][3];
+  __shared__ double colv[2][LMAX_K];  // c0 column and data column, one entry per neighbour
+  __shared__ int nidx[LMAX_K];
+  __shared__ signed char se[LMAX_NC][4];
+  __shared__ double S[16 * 17];
+  __shared__ double G[16][17];
+
+  const int64_t p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int cnt = count[p];
+  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
+  if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
+    if (lane == 0) {
+      mean_out[p] = NaN;
+      var_out[p] = NaN;
+      status_out[p] = GSS_PT_MISSING;
+    }
+    return;
+  }
+  const int nc = sp.nc;
+  const int g = lane >> 4, c = lane & 15;
+  double c0[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
+  {
+    const bool act = lane < cnt;
+    const int nj = act ? idx[p * k + lane] : 0;
+    double xj[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
+      nx[lane][a] = xj[a];
+    }
+    nidx[lane] = nj;
+    double zz = act ? z[nj] : 0.0;
+    if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
+    colv[0][lane] = act ? cov_pair<DIM>(vg, xj, c0) : 0.0;
+    colv[1][lane] = act ? zz : 0.0;
+    if (lane == 0) {  // static indices only: a lane-indexed read would force the argument struct into scratch
+#pragma unroll
+      for (int cc = 0; cc < LMAX_NC; ++cc)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) se[cc][a] = sp.e[cc][a];
+    }
+  }
+  __syncthreads();
+  const int nt = (cnt + 15) >> 4;
+
+  // system matrix, upper block triangle, tile layout; the four rows a lane holds of a tile are evaluated together
+  d4_t T[10];
+#pragma unroll
+  for (int I = 0; I < 4; ++I) {
+    if (I < nt) {
+      double xr[4][DIM];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) xr[r][a] = nx[16 * I + g + 4 * r][a];
+#pragma unroll
+      for (int J = I; J < 4; ++J) {
+        if (J < nt) {
+          const int col = 16 * J + c;
+          double xcol[DIM], v[4];
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) xcol[a] = nx[col][a];
+          cov_pair4<DIM>(vg, xr, xcol, v);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + g + 4 * r;
+            T[tile_id(I, J)][r] = (row < cnt && col < cnt) ? v[r] : (row == col ? 1.0 : 0.0);
+          }
+        }
+      }
+    }
+  }
+  // right-hand sides: column 0 = c0, 1 = data, 2 + q = drift q
+  d4_t B[4];
+  const int q = c - 2;
+  int e0 = 0, e1 = 0, e2 = 0;
+  if (q >= 0 && q < nc) {
+    e0 = se[q][0];
+    e1 = se[q][1];
+    e2 = se[q][2];
+  }
+#pragma unroll
+  for (int K = 0; K < 4; ++K) {
+    if (K < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * K + g + 4 * r;
+        double v = 0.0;
+        if (row < cnt) {
+          if (c < 2) v = colv[c][row];
+          else if (q < nc) {
+            if (sp.variant == GSS_KRIG_UNIVERSAL) {
+              const int ee[3] = {e0, e1, e2};
+              v = 1.0;
+#pragma unroll
+              for (int a = 0; a < DIM; ++a) {
+                const double u = (nx[row][a] - c0[a]) * sp.inv_scale;
+                for (int w = 0; w < ee[a]; ++w) v *= u;
+              }
+            } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
+              v = drift_data[(int64_t)nidx[row] * nc + q];
+            } else {
+              v = 1.0;  // ordinary kriging: the constant drift
+            }
+          }
+        }
+        B[K][r] = v;
+      }
+    }
+  }
+
+  bool bad = false;
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    if (kk < nt) {
+      const d4_t V = potrf16_inverse(T[tile_id(kk, kk)], S, lane, &bad);
+#pragma unroll
+      for (int j = kk + 1; j < 4; ++j)
+        if (j < nt) T[tile_id(kk, j)] = xty(V, T[tile_id(kk, j)], zero4);
+      B[kk] = xty(V, B[kk], zero4);
+#pragma unroll
+      for (int i = kk + 1; i < 4; ++i) {
+        if (i < nt) {
+          const d4_t N = -T[tile_id(kk, i)];
+#pragma unroll
+          for (int j = i; j < 4; ++j)
+            if (j < nt) T[tile_id(i, j)] = xty(N, T[tile_id(kk, j)], T[tile_id(i, j)]);
+          B[i] = xty(N, B[kk], B[i]);
+        }
+      }
+    }
+  }
+  if (bad) {
+    if (lane == 0) {
+      mean_out[p] = NaN;
+      var_out[p] = NaN;
+      status_out[p] = GSS_PT_SINGULAR;
+    }
+    return;
+  }
+  d4_t Gt = zero4;
+#pragma unroll
+  for (int K = 0; K < 4; ++K)
+    if (K < nt) Gt = xty(B[K], B[K], Gt);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) G[g + 4 * r][c] = Gt[r];
+  __syncthreads();
+  // block elimination on the (2 + nc) x (2 + nc) Gram matrix, lane i = drift term i, everything in registers:
+  // S = Y_F'Y_F = L L', u = L^-1 (Y_F'y_c - f0), v = L^-1 Y_F'y_z, r'S^-1 r = |u|^2, t'S^-1 r = u.v
+  const double qf = G[0][0], af = G[1][0];
+  double rsr = 0.0, tsr = 0.0;
+  bool okS = true;
+  if (nc > 0) {
+    const int i = lane < LMAX_NC ? lane : LMAX_NC - 1;
+    double srow[LMAX_NC];
+#pragma unroll
+    for (int cc = 0; cc < LMAX_NC; ++cc) srow[cc] = G[2 + i][2 + cc];
+    double f0 = 1.0;
+    if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (se[i][0] + se[i][1] + se[i][2]) == 0 ? 1.0 : 0.0;
+    else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + (i < nc ? i : 0)];
+    double u = G[2 + i][0] - f0, v = G[2 + i][1];
+#pragma unroll
+    for (int j = 0; j < LMAX_NC; ++j) {
+      if (j < nc) {
+        double d = rl64(srow[j], j);
+        if (!(d > 0.0)) {
+          okS = false;
+          d = 1.0;
+        }
+        double y = __builtin_amdgcn_rsq(d);
+        const double h = 0.5 * d;
+        y = fma(y, fma(-h * y, y, 0.5), y);
+        y = fma(y, fma(-h * y, y, 0.5), y);
+        const double lij = srow[j] * y;  // L[i][j] for i > j
+#pragma unroll
+        for (int cc = j + 1; cc < LMAX_NC; ++cc) srow[cc] = fma(-lij, rl64(srow[j], cc) * y, srow[cc]);
+        const double uj = rl64(u, j) * y, vj = rl64(v, j) * y;
+        rsr = fma(uj, uj, rsr);
+        tsr = fma(uj, vj, tsr);
+        u = fma(-lij, uj, u);
+        v = fma(-lij, vj, v);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (!okS) {
+      mean_out[p] = NaN;
+      var_out[p] = NaN;
+      status_out[p] = GSS_PT_SINGULAR;
+    } else {
+      const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
+      const double vv = vg.sill - qf + rsr;
+      mean_out[p] = mu;
+      var_out[p] = vv > 0.0 ? vv : 0.0;
+      status_out[p] = GSS_PT_OK;
+    }
+  }
+}
+
 // Host driver: chunks the domain so that the neighbour-index scratch stays small, runs K4 then K5.
 int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const signed char* exps, double inv_scale,
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
@@ -292,6 +594,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
   const bool use_index = !(brute && brute[0] == '1');
+  const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
+  const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s, st_s;
   if (!idx_out) GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
@@ -309,6 +613,18 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     }
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
     ProfScope pl("krig_local", s);
+    if (use_mfma) {
+#define GSS_K5_ARGS vg, sp, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, \
+                    var + off, st
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((krig_local_mfma_kernel<1>), dim3((unsigned)mv), dim3(64), 0, s, GSS_K5_ARGS); break;
+        case 2: hipLaunchKernelGGL((krig_local_mfma_kernel<2>), dim3((unsigned)mv), dim3(64), 0, s, GSS_K5_ARGS); break;
+        default: hipLaunchKernelGGL((krig_local_mfma_kernel<3>), dim3((unsigned)mv), dim3(64), 0, s, GSS_K5_ARGS); break;
+      }
+#undef GSS_K5_ARGS
+      GSS_HIP(hipGetLastError());
+      continue;
+    }
     switch (dim) {
       case 1:
         hipLaunchKernelGGL((krig_local_kernel<1>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
