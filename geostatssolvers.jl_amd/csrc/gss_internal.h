@@ -133,6 +133,48 @@ __device__ __forceinline__ double sqdist_nofma(const double* a, const double* b,
   return acc;
 }
 
+// Ranking key of the neighbour search for the `distance` solver parameter (krig.jl:72, idw.jl:54, lwr.jl:57):
+// monotone in the distance, accumulated in dimension order with one rounding per operation.
+//   EUCLIDEAN: squared (Mahalanobis) distance; CITYBLOCK: sum |t|; CHEBYSHEV: max |t|;
+//   HAVERSINE: sin^2(dlat/2) + cos(lat1) cos(lat2) sin^2(dlon/2) for (lon, lat) in degrees ([DEP] Distances.jl)
+template <int DIM, int METRIC>
+__device__ __forceinline__ double metric_key(const double* a, const double* b, const double* ir, bool aniso) {
+#pragma clang fp contract(off)
+  if (METRIC == GSS_METRIC_CITYBLOCK) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) acc = acc + fabs(a[k] - b[k]);
+    return acc;
+  } else if (METRIC == GSS_METRIC_CHEBYSHEV) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const double t = fabs(a[k] - b[k]);
+      acc = t > acc ? t : acc;
+    }
+    return acc;
+  } else if (METRIC == GSS_METRIC_HAVERSINE) {
+    const double D = 0.017453292519943295;  // pi / 180
+    const double s1 = sin(((b[DIM > 1 ? 1 : 0] - a[DIM > 1 ? 1 : 0]) * 0.5) * D);
+    const double s2 = sin(((b[0] - a[0]) * 0.5) * D);
+    const double cc = cos(a[DIM > 1 ? 1 : 0] * D) * cos(b[DIM > 1 ? 1 : 0] * D);
+    const double t1 = s1 * s1, t2 = cc * (s2 * s2);
+    return t1 + t2;
+  } else {
+    return sqdist_nofma<DIM>(a, b, ir, aniso);
+  }
+}
+
+// distance from the ranking key
+__device__ __forceinline__ double metric_dist(int metric, double key, double param) {
+  if (metric == GSS_METRIC_EUCLIDEAN) return sqrt(key);
+  if (metric == GSS_METRIC_HAVERSINE) {
+    const double r = sqrt(key);
+    return 2.0 * param * asin(r < 1.0 ? r : 1.0);
+  }
+  return key;
+}
+
 // g(h) = 1 - f(h / range): normalised covariance shape of one structure, from the squared distance (d2 > 0)
 __device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range, double mscale, double pw) {
   switch (kind) {
@@ -286,8 +328,11 @@ int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnI
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s,
                            const int* rank = nullptr, const int* qrank = nullptr, const int* bminrank = nullptr);
+// metric != GSS_METRIC_EUCLIDEAN: exhaustive kernel (no box bounds for those keys), balls not allowed
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
-                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s);
+                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
+                       int metric = 0);
+int32_t check_metric(int metric, double metric_param, int dim, double radius, const double* inv_radii);
 
 // ---------------------------------------------------------------------------------------------
 // noise (noise.hip)

@@ -22,7 +22,20 @@ struct EstSpec {
   int wkind;        // GSS_WEIGHT_*
   double exponent;  // IDW
   double wa, wp;    // LWR weight parameters
+  int metric;       // GSS_METRIC_* of the search (distances entering the weights use it too)
+  double mparam;
 };
+
+// ranking key of the search for a runtime metric
+template <int DIM>
+__device__ __forceinline__ double est_key(int metric, const double* a, const double* b, const double* ir, bool aniso) {
+  switch (metric) {
+    case GSS_METRIC_CITYBLOCK: return metric_key<DIM, GSS_METRIC_CITYBLOCK>(a, b, ir, aniso);
+    case GSS_METRIC_CHEBYSHEV: return metric_key<DIM, GSS_METRIC_CHEBYSHEV>(a, b, ir, aniso);
+    case GSS_METRIC_HAVERSINE: return metric_key<DIM, GSS_METRIC_HAVERSINE>(a, b, ir, aniso);
+    default: return sqdist_nofma<DIM>(a, b, ir, aniso);
+  }
+}
 
 __device__ __forceinline__ double idw_weight(double d, double d2, double e) {
   if (e == 1.0) return 1.0 / d;
@@ -168,8 +181,8 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
 #pragma unroll
   for (int a = 0; a < DIM; ++a) c[a] = xdata[(int64_t)i * DIM + a];
   const double zi = z[i];
-  const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);  // the distance the search ranked by
-  const double d = sqrt(d2);
+  const double d2 = est_key<DIM>(sp.metric, c, qc, ir, aniso != 0);  // the key the search ranked by
+  const double d = metric_dist(sp.metric, d2, sp.mparam);
 
   if (sp.method == 0) {
     const unsigned long long zero = __ballot(act && d2 == 0.0);
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
       }
       return;
     }
-    const double w = act ? idw_weight(d, d2, sp.exponent) : 0.0;
+    const double w = act ? idw_weight(d, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : d * d, sp.exponent) : 0.0;
     const double sw = wave_sum(w);
     const double swz = wave_sum(w * zi);
     const double dmin = wave_min(act ? d : __builtin_huge_val());
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
     for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
     __syncthreads();
     for (int j = 0; j < tn; ++j) {
-      const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+      const double d2 = est_key<DIM>(sp.metric, &sx[j * DIM], qc, ir, aniso != 0);
       if (use_ball && !(d2 <= r2)) continue;
       ++cnt;
       dmax2 = d2 > dmax2 ? d2 : dmax2;
@@ -267,7 +280,8 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
           if (!haszero) zzero = sz[j];
           haszero = true;
         } else {
-          const double w = idw_weight(sqrt(d2), d2, sp.exponent);
+          const double dd = metric_dist(sp.metric, d2, sp.mparam);
+          const double w = idw_weight(dd, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : dd * dd, sp.exponent);
           sw += w;
           swz += w * sz[j];
         }
@@ -287,13 +301,13 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
       status_out[p] = GSS_PT_OK;
     } else {
       mean_out[p] = swz / sw;
-      aux_out[p] = sqrt(dmin2);
+      aux_out[p] = metric_dist(sp.metric, dmin2, sp.mparam);
       status_out[p] = GSS_PT_OK;
     }
     return;
   }
   // sweep 2 (LWR): moments with delta = d / dmax
-  const double dmax = sqrt(dmax2);
+  const double dmax = metric_dist(sp.metric, dmax2, sp.mparam);
   double S1[NT], S2[NT], b[NP];
 #pragma unroll
   for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
@@ -306,9 +320,9 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
     for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
     __syncthreads();
     for (int j = 0; j < tn; ++j) {
-      const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+      const double d2 = est_key<DIM>(sp.metric, &sx[j * DIM], qc, ir, aniso != 0);
       if (use_ball && !(d2 <= r2)) continue;
-      const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, sqrt(d2) / dmax);
+      const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
       double u[NP];
       u[0] = 1.0;
 #pragma unroll
@@ -371,8 +385,9 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   }
 
   const int64_t chunk = 1 << 20;
-  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
-  GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
+  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call (Euclidean / Mahalanobis search only)
+  const bool use_index = sp.metric == GSS_METRIC_EUCLIDEAN;
+  if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s;
   GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
   GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
@@ -380,8 +395,12 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
     const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
     {
       ProfScope ps("knn", s);
-      GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
-                                 cnt_s.as<int>(), s));
+      if (use_index)
+        GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                                   cnt_s.as<int>(), s));
+      else
+        GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                               cnt_s.as<int>(), s, sp.metric));
     }
     ProfScope pl(pname, s);
     dim3 grid((unsigned)((mv + 3) / 4));
@@ -408,6 +427,7 @@ static int32_t est_predict(const EstSpec& sp, const double* xdata, const double*
   GSS_REQUIRE(k >= 1 && k <= n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
               (long long)n);
   GSS_REQUIRE(minneighbors <= k, "invalid min/max number of neighbors");  // idw.jl:97, lwr.jl:99
+  GSS_TRY(check_metric(sp.metric, sp.mparam, dim, radius, inv_radii));
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdata && z && xdom && mean && aux)), "NULL array");
   if (m == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
@@ -442,21 +462,24 @@ using namespace gss;
 extern "C" {
 
 int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
-                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, double exponent,
-                        double* mean, double* dist, uint8_t* status, int32_t mem, void* stream) {
+                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
+                        double metric_param, double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
+                        void* stream) {
   GSS_REQUIRE(exponent > 0.0, "exponent must be positive");  // idw.jl:96
   EstSpec sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.method = 0;
   sp.exponent = exponent;
+  sp.metric = metric;
+  sp.mparam = metric_param;
   return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, dist, status, mem,
                      stream);
 }
 
 int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
-                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t weight_kind,
-                        double weight_a, double weight_p, double* mean, double* var, uint8_t* status, int32_t mem,
-                        void* stream) {
+                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
+                        double metric_param, int32_t weight_kind, double weight_a, double weight_p, double* mean,
+                        double* var, uint8_t* status, int32_t mem, void* stream) {
   GSS_REQUIRE(weight_kind == GSS_WEIGHT_EXP || weight_kind == GSS_WEIGHT_TRICUBE, "unknown weight function %d",
               weight_kind);
   GSS_REQUIRE(weight_kind != GSS_WEIGHT_EXP || weight_p > 0.0, "weight exponent must be positive");
@@ -466,6 +489,8 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
   sp.wkind = weight_kind;
   sp.wa = weight_a;
   sp.wp = weight_p;
+  sp.metric = metric;
+  sp.mparam = metric_param;
   return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, var, status, mem,
                      stream);
 }

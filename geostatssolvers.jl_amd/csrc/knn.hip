@@ -79,7 +79,7 @@ __device__ __forceinline__ void bitonic_merge64(double& ld, int& li, double bd, 
   for (int stride = 32; stride >= 1; stride >>= 1) bitonic_cx(ld, li, lane, stride, true);
 }
 
-template <int DIM>
+template <int DIM, int METRIC>
 __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xdata, int n,
                                                   const double* __restrict__ centers, int64_t m, int k, double r2,
                                                   int use_ball, int aniso, double ir0, double ir1, double ir2,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
       const int gidx = t0 + j;
 #pragma unroll
       for (int q = 0; q < KNN_Q; ++q) {
-        const double d2 = sqdist_nofma<DIM>(c, qc[q], ir, aniso != 0);
+        const double d2 = metric_key<DIM, METRIC>(c, qc[q], ir, aniso != 0);
         const bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, gidx, tau_d[q], tau_i[q]);
         unsigned long long mask = __ballot(qual);
         while (mask) {
@@ -436,15 +436,54 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
   return GSS_OK;
 }
 
-// brute-force reference path (GSS_KNN_BRUTE=1), kept for A/B checks
+int32_t check_metric(int metric, double metric_param, int dim, double radius, const double* inv_radii) {
+  GSS_REQUIRE(metric >= GSS_METRIC_EUCLIDEAN && metric <= GSS_METRIC_HAVERSINE, "unknown search metric %d", metric);
+  if (metric == GSS_METRIC_EUCLIDEAN) return GSS_OK;
+  // searcher_ui (ui.jl:25-31): a neighbourhood replaces the metric search, the two are never combined
+  GSS_REQUIRE(radius < 0.0 && inv_radii == nullptr, "a search ball cannot be combined with a non-Euclidean distance");
+  if (metric == GSS_METRIC_HAVERSINE) {
+    GSS_REQUIRE(dim == 2, "the haversine distance needs (longitude, latitude) points, got %d-D", dim);
+    GSS_REQUIRE(metric_param > 0.0, "the haversine distance needs a positive sphere radius");
+  }
+  return GSS_OK;
+}
+
+template <int DIM, int METRIC>
+static void launch_brute(dim3 grid, hipStream_t s, const double* xdata, int n, const double* centers, int64_t m, int k,
+                         double r2, int use_ball, int aniso, const double* ir, int* idx, int* count) {
+  hipLaunchKernelGGL((knn_kernel<DIM, METRIC>), grid, dim3(256), 0, s, xdata, n, centers, m, k, r2, use_ball, aniso,
+                     ir[0], ir[1], ir[2], idx, count);
+}
+
+template <int DIM>
+static void launch_brute_metric(int metric, dim3 grid, hipStream_t s, const double* xdata, int n,
+                                const double* centers, int64_t m, int k, double r2, int use_ball, int aniso,
+                                const double* ir, int* idx, int* count) {
+  switch (metric) {
+    case GSS_METRIC_CITYBLOCK:
+      launch_brute<DIM, GSS_METRIC_CITYBLOCK>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      break;
+    case GSS_METRIC_CHEBYSHEV:
+      launch_brute<DIM, GSS_METRIC_CHEBYSHEV>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      break;
+    case GSS_METRIC_HAVERSINE:
+      launch_brute<DIM, GSS_METRIC_HAVERSINE>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      break;
+    default:
+      launch_brute<DIM, GSS_METRIC_EUCLIDEAN>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      break;
+  }
+}
+
+// Euclidean: pruned search (exhaustive kernel with GSS_KNN_BRUTE=1, kept for A/B checks); other metrics: exhaustive
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
-                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s) {
+                       double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s, int metric) {
   GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
                                  "(use the global neighbourhood beyond that)", k);
   GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3, "knn: bad sizes");
   if (m <= 0) return GSS_OK;
   const char* e = std::getenv("GSS_KNN_BRUTE");
-  if (!(e && e[0] == '1')) {
+  if (metric == GSS_METRIC_EUCLIDEAN && !(e && e[0] == '1')) {
     KnnIndex ix;
     GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
     GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s));
@@ -459,18 +498,9 @@ int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* ce
     for (int a = 0; a < dim; ++a) ir[a] = inv_radii_host[a];
   dim3 grid((unsigned)((m + 4 * KNN_Q - 1) / (4 * KNN_Q)));
   switch (dim) {
-    case 1:
-      hipLaunchKernelGGL((knn_kernel<1>), grid, dim3(256), 0, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso,
-                         ir[0], ir[1], ir[2], idx, count);
-      break;
-    case 2:
-      hipLaunchKernelGGL((knn_kernel<2>), grid, dim3(256), 0, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso,
-                         ir[0], ir[1], ir[2], idx, count);
-      break;
-    default:
-      hipLaunchKernelGGL((knn_kernel<3>), grid, dim3(256), 0, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso,
-                         ir[0], ir[1], ir[2], idx, count);
-      break;
+    case 1: launch_brute_metric<1>(metric, grid, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso, ir, idx, count); break;
+    case 2: launch_brute_metric<2>(metric, grid, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso, ir, idx, count); break;
+    default: launch_brute_metric<3>(metric, grid, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso, ir, idx, count); break;
   }
   GSS_HIP(hipGetLastError());
   return GSS_OK;
@@ -481,10 +511,11 @@ int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* ce
 using namespace gss;
 
 extern "C" int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double* centers, int64_t m,
-                                  int32_t k, double radius, const double* inv_radii, int32_t* idx, int32_t* count,
-                                  int32_t mem, void* stream) {
+                                  int32_t k, double radius, const double* inv_radii, int32_t metric,
+                                  double metric_param, int32_t* idx, int32_t* count, int32_t mem, void* stream) {
   GSS_REQUIRE(xdata && centers && idx, "gss_knn_search: NULL array");
   GSS_REQUIRE(k >= 1 && k <= n, "gss_knn_search: k = %d outside 1..n = %lld", k, (long long)n);
+  GSS_TRY(check_metric(metric, metric_param, dim, radius, inv_radii));
   hipStream_t s = to_stream(stream);
   Staged sx, sc, si, sn;
   GSS_TRY(sx.in(xdata, sizeof(double) * (size_t)(n * dim), mem, s));
@@ -492,7 +523,7 @@ extern "C" int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, c
   GSS_TRY(si.out(idx, sizeof(int32_t) * (size_t)(m * k), mem));
   GSS_TRY(sn.out(count, sizeof(int32_t) * (size_t)m, mem));
   GSS_TRY(knn_search_dev(sx.as<double>(), n, dim, sc.as<double>(), m, k, radius, inv_radii, si.as<int>(),
-                         sn.as<int>(), s));
+                         sn.as<int>(), s, metric));
   GSS_TRY(si.back(idx, sizeof(int32_t) * (size_t)(m * k), mem, s));
   GSS_TRY(sn.back(count, sizeof(int32_t) * (size_t)m, mem, s));
   return GSS_OK;

@@ -351,7 +351,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s);
+                       int* count_out, hipStream_t s, int metric);
 }
 
 static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
@@ -789,9 +789,11 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
 
 
 int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m, int32_t k,
-                             int32_t minneighbors, double radius, const double* inv_radii, double* mean, double* var,
-                             uint8_t* status, int32_t* idx_out, int32_t* count_out, int32_t mem, void* stream) {
+                             int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
+                             double metric_param, double* mean, double* var, uint8_t* status, int32_t* idx_out,
+                             int32_t* count_out, int32_t mem, void* stream) {
   GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_TRY(check_metric(metric, metric_param, h->dim, radius, inv_radii));
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_knn: NULL array");
   GSS_REQUIRE(k >= 1 && k <= h->n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
               (long long)h->n);
@@ -810,7 +812,7 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
   GSS_TRY(krig_local_dev(h->vg, h->variant, h->nc, dim, &h->ds.e[0][0], h->ds.inv_scale[0], h->sk_mean,
                          h->xdata.as<double>(), h->z.as<double>(), h->drift_data.as<double>(), h->n,
                          sx.as<double>(), sd.as<double>(), m, k, minneighbors, radius, inv_radii, smean.as<double>(),
-                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s));
+                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s, metric));
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
   GSS_TRY(sstat.back(status, (size_t)m, mem, s));

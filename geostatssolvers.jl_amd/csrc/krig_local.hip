@@ -576,7 +576,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s) {
+                       int* count_out, hipStream_t s, int metric) {
   GSS_REQUIRE(nc <= LMAX_NC, "moving-neighbourhood kriging supports at most %d drift terms (got %d)", LMAX_NC, nc);
   GSS_REQUIRE(k >= 1 && k <= LMAX_K, "maxneighbors = %d: the moving-neighbourhood kernels hold at most %d "
                                      "neighbours (use the global neighbourhood beyond that)", k, LMAX_K);
@@ -593,7 +593,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   const int64_t chunk = 1 << 20;
   KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
-  const bool use_index = !(brute && brute[0] == '1');
+  const bool use_index = metric == GSS_METRIC_EUCLIDEAN && !(brute && brute[0] == '1');
   const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
   const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
@@ -609,7 +609,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     {
       ProfScope ps("knn", s);
       if (use_index) GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
-      else GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
+      else GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, metric));
     }
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
     ProfScope pl("krig_local", s);

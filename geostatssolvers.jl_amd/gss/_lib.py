@@ -59,17 +59,18 @@ SIGNATURES = {
     "gss_profile_reset": [],
     "gss_profile_read": [C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)],
     "gss_cov_pairwise": [_VG, _p, _i64, _p, _i64, _p, _i64, _i32, _p],
-    "gss_knn_search": [_p, _i64, _i32, _p, _i64, _i32, _f64, _p, _p, _p, _i32, _p],
+    "gss_knn_search": [_p, _i64, _i32, _p, _i64, _i32, _f64, _p, _i32, _f64, _p, _p, _i32, _p],
     "gss_krig_create": [C.POINTER(_p), _VG, _i32, _f64, _i32, _i32, _p, _p, _p, _i64, _i32, _p],
     "gss_krig_destroy": [_p],
     "gss_krig_info": [_p, C.POINTER(_i64), C.POINTER(_i32)],
     "gss_krig_factor_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "gss_krig_adopt_factor": [_p],
     "gss_krig_predict_global": [_p, _p, _p, _i64, _p, _p, _p, _i32, _p],
-    "gss_krig_predict_knn": [_p, _p, _p, _i64, _i32, _i32, _f64, _p, _p, _p, _p, _p, _p, _i32, _p],
+    "gss_krig_predict_knn": [_p, _p, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _p, _p, _p, _p, _p, _i32, _p],
     "gss_krig_predict_global_batch": [_p, _p, _i64, _p, _i64, _p, _i32, _p],
-    "gss_idw_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _f64, _p, _p, _p, _i32, _p],
-    "gss_lwr_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _f64, _p, _p, _p, _i32, _p],
+    "gss_idw_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _f64, _p, _p, _p, _i32, _p],
+    "gss_lwr_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _i32, _f64, _f64, _p, _p, _p, _i32,
+                        _p],
     "gss_sgs_create": [C.POINTER(_p), _VG, _f64, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _f64, _p, _i32, _p],
     "gss_sgs_destroy": [_p],
     "gss_sgs_weights": [_p, _p, _p, _p, _p, _i32, _p],
@@ -198,6 +199,25 @@ def make_variogram(kind: str, dim: int, sill=1.0, nugget=0.0, range=1.0, nu=1.0,
             for k, r in enumerate(eradii):
                 x.inv_radii[k] = 1.0 / float(r)
     return v
+
+
+METRICS = {"euclidean": 0, "cityblock": 1, "chebyshev": 2, "haversine": 3}
+
+
+def metric_spec(distance):
+    """Solver parameter `distance` -> (GSS_METRIC_*, parameter).  Accepts None / "euclidean" / "cityblock" /
+    "chebyshev" / ("haversine", radius) (the Distances.jl objects Euclidean(), Cityblock(), Chebyshev(), Haversine(r))."""
+    if distance is None:
+        return 0, 0.0
+    if isinstance(distance, str):
+        name, par = distance.lower(), 0.0
+    else:
+        name, par = str(distance[0]).lower(), float(distance[1])
+    if name not in METRICS:
+        raise NotImplementedError(f"search distance {distance!r}: euclidean, cityblock, chebyshev or ('haversine', r)")
+    if name == "haversine" and not par > 0.0:
+        raise ValueError("('haversine', radius) needs a positive radius")
+    return METRICS[name], par
 
 
 def profile_enable(on: bool = True):

@@ -126,7 +126,8 @@ class KrigHandle:
                                               mem, current_stream()))
         return mean, var, status
 
-    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False):
+    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False,
+                    distance=None):
         xdom = _prep_in(xdom)
         m = xdom.shape[0]
         mem = _space(xdom)
@@ -138,8 +139,9 @@ class KrigHandle:
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
         dd = _prep_in(drift_dom)
+        met, mpar = _lib.metric_spec(distance)
         check(self._l.gss_krig_predict_knn(self._h, ptr(xdom), ptr(dd), m, int(k), int(minneighbors), r, ptr(ir),
-                                           ptr(mean), ptr(var), ptr(status), ptr(idx), ptr(cnt), mem,
+                                           met, mpar, ptr(mean), ptr(var), ptr(status), ptr(idx), ptr(cnt), mem,
                                            current_stream()))
         if return_idx:
             return mean, var, status, idx, cnt
@@ -329,8 +331,9 @@ class HipEngine:
         return out
 
     @staticmethod
-    def knn_search(xdata, centers, k, radius=None, radii=None):
+    def knn_search(xdata, centers, k, radius=None, radii=None, distance=None):
         l = _lib.lib()
+        met, mpar = _lib.metric_spec(distance)
         x = np.ascontiguousarray(xdata, dtype=np.float64)
         if x.ndim == 1:
             x = x[:, None]
@@ -340,12 +343,12 @@ class HipEngine:
         cnt = np.empty(m, dtype=np.int32)
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
-        check(l.gss_knn_search(ptr(x), x.shape[0], x.shape[1], ptr(c), m, int(k), r, ptr(ir), ptr(idx), ptr(cnt),
-                               MEM_HOST, current_stream()))
+        check(l.gss_knn_search(ptr(x), x.shape[0], x.shape[1], ptr(c), m, int(k), r, ptr(ir), met, mpar, ptr(idx),
+                               ptr(cnt), MEM_HOST, current_stream()))
         return idx, cnt
 
     @staticmethod
-    def _estimate(fn_name, extra, xdata, z, xdom, k, minneighbors, radius, radii):
+    def _estimate(fn_name, extra, xdata, z, xdom, k, minneighbors, radius, radii, distance=None):
         """Host arrays in -> host arrays out; if `xdom` is a CUDA tensor everything stays in HBM."""
         l = _lib.lib()
         dev = is_torch(xdom) and xdom.is_cuda
@@ -369,23 +372,24 @@ class HipEngine:
             mean, aux, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
+        met, mpar = _lib.metric_spec(distance)
         check(getattr(l, fn_name)(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k), int(minneighbors), r,
-                                  ptr(ir), *extra, ptr(mean), ptr(aux), ptr(st), MEM_DEVICE if dev else MEM_HOST,
+                                  ptr(ir), met, mpar, *extra, ptr(mean), ptr(aux), ptr(st), MEM_DEVICE if dev else MEM_HOST,
                                   current_stream()))
         return mean, aux, st
 
     @staticmethod
-    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None):
+    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None, distance=None):
         """gss_idw_predict (idw.jl:111-142) -> mean, distance to the nearest sample, status."""
         return HipEngine._estimate("gss_idw_predict", (float(exponent),), xdata, z, xdom, k, minneighbors, radius,
-                                   radii)
+                                   radii, distance)
 
     @staticmethod
-    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None):
+    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None, distance=None):
         """gss_lwr_predict (lwr.jl:114-147); weight = (kind, a, p) -> mean, norm(r), status."""
         kind, a, p = weight
         return HipEngine._estimate("gss_lwr_predict", (int(kind), float(a), float(p)), xdata, z, xdom, k,
-                                   minneighbors, radius, radii)
+                                   minneighbors, radius, radii, distance)
 
 
 def default_engine():

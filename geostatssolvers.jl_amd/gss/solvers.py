@@ -88,6 +88,14 @@ def _seed_from(rng) -> int:
     return int(rng.integers(0, 2 ** 63 - 1))
 
 
+def _distance(p):
+    """The search metric only matters without a neighbourhood (searcher_ui, ui.jl:25-31)."""
+    from ._lib import metric_spec
+    d = p["distance"]
+    metric_spec(d)                       # validates / raises NotImplementedError for unknown metrics
+    return None if p["neighborhood"] is not None else d
+
+
 def _ball(neighborhood):
     if neighborhood is None:
         return None, None
@@ -143,8 +151,7 @@ class KrigingSolver(_Solver):
             inds = np.flatnonzero(~np.isnan(z))                       # krig.jl:97
             if inds.size == 0:
                 raise AssertionError(f"all samples of {var} are missing, aborting...")   # krig.jl:100-102
-            if p["distance"] not in ("euclidean", None):
-                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            _distance(p)
             if p["path"] not in ("linear", None):
                 raise NotImplementedError("only LinearPath is available (results are per-point independent)")
             vdom = PointSet(coords[inds])
@@ -180,7 +187,8 @@ class KrigingSolver(_Solver):
                         mu, var_, st = h.predict_global(xdom, drift_dom)                 # krig.jl:166-186
                     else:
                         radius, radii = _ball(p["neighborhood"])
-                        mu, var_, st = h.predict_knn(xdom, q["nmax"], q["minneighbors"], radius, radii, drift_dom)
+                        mu, var_, st = h.predict_knn(xdom, q["nmax"], q["minneighbors"], radius, radii, drift_dom,
+                                                     distance=_distance(p))
                 else:
                     mu, var_, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
             finally:
@@ -245,8 +253,7 @@ class _NeighborEstimator(_Solver):
             inds = np.flatnonzero(~np.isnan(zall))                       # idw.jl:77, lwr.jl:80
             n = inds.size
             assert n > 0, "estimation requires data"                      # idw.jl:95
-            if p["distance"] not in ("euclidean", None):
-                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            _distance(p)
             if p["path"] not in ("linear", None):
                 raise NotImplementedError("only LinearPath is available (results are per-point independent)")
             nmin = p["minneighbors"]
@@ -285,7 +292,7 @@ class IDWSolver(_NeighborEstimator):
         assert p["exponent"] > 0, "exponent must be positive"                                  # idw.jl:96
 
     def _estimate(self, p, x, z, xdom, k, nmin, radius, radii):
-        return self.engine.idw(x, z, xdom, k, nmin, float(p["exponent"]), radius, radii)
+        return self.engine.idw(x, z, xdom, k, nmin, float(p["exponent"]), radius, radii, distance=_distance(p))
 
 
 class LWRSolver(_NeighborEstimator):
@@ -298,7 +305,7 @@ class LWRSolver(_NeighborEstimator):
         if not hasattr(wf, "spec"):
             raise NotImplementedError("weightfun must be ExpWeight(a, p) or TricubeWeight(): the weights are "
                                       "evaluated inside the device kernel, arbitrary callables cannot cross the C-ABI")
-        return self.engine.lwr(x, z, xdom, k, nmin, wf.spec(), radius, radii)
+        return self.engine.lwr(x, z, xdom, k, nmin, wf.spec(), radius, radii, distance=_distance(p))
 
 
 # ------------------------------------------------------------------------------------------

@@ -110,6 +110,15 @@ function cvariogram(γ, dim; extent=nothing)
                (NOEXTRA, NOEXTRA, NOEXTRA))
 end
 
+# solver parameter `distance` (krig.jl:72, idw.jl:54, lwr.jl:57) -> (GSS_METRIC_*, parameter); a neighbourhood
+# overrides it exactly as searcher_ui does (ui.jl:25-31)
+metricspec(::Euclidean) = (Int32(0), 0.0)
+metricspec(::Cityblock) = (Int32(1), 0.0)
+metricspec(::Chebyshev) = (Int32(2), 0.0)
+metricspec(d::Haversine) = (Int32(3), Float64(d.radius))
+metricspec(d) = throw(ArgumentError("search distance $d is not available on the device"))
+searchmetric(p) = isnothing(p.neighborhood) ? metricspec(p.distance) : (Int32(0), 0.0)
+
 # point-major coordinates: a d x n Julia matrix is already in the layout the C-ABI wants
 coordmatrix(dom) = reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(dom, i)))) for i in 1:nelements(dom)])
 
@@ -181,11 +190,12 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
             rs = ustrip.(radii(p.neighborhood))
             length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
           end
+          met, mpar = searchmetric(p)
           check(ccall((:gss_krig_predict_knn, libgss), Int32,
-                      (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
-                       Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Cvoid}),
-                      h[], X0, F0, m, Int32(k), Int32(p.minneighbors), radius, ir, μ, σ², status, C_NULL, C_NULL,
-                      GSS_MEM_HOST, C_NULL))
+                      (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64}, Int32,
+                       Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Cvoid}),
+                      h[], X0, F0, m, Int32(k), Int32(p.minneighbors), radius, ir, met, mpar, μ, σ², status, C_NULL,
+                      C_NULL, GSS_MEM_HOST, C_NULL))
         end
       finally
         ccall((:gss_krig_destroy, libgss), Int32, (Ptr{Cvoid},), h[])
@@ -267,20 +277,22 @@ end
 solve(problem::EstimationProblem, solver::IDWSolverHIP) =
   neighbor_estimate(problem, solver, "_distance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
     @assert p.exponent > 0 "exponent must be positive"                   # idw.jl:96
+    met, mpar = searchmetric(p)
     ccall((:gss_idw_predict, libgss), Int32,
           (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
-           Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
-          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, Float64(p.exponent), μ, aux, status,
-          GSS_MEM_HOST, C_NULL)
+           Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, Float64(p.exponent), μ, aux,
+          status, GSS_MEM_HOST, C_NULL)
   end)
 
 solve(problem::EstimationProblem, solver::LWRSolverHIP) =
   neighbor_estimate(problem, solver, "_variance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
     wk, wa, wp = weightspec(p.weightfun)
+    met, mpar = searchmetric(p)
     ccall((:gss_lwr_predict, libgss), Int32,
           (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
-           Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
-          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, wk, wa, wp, μ, aux, status,
+           Int32, Float64, Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, wk, wa, wp, μ, aux, status,
           GSS_MEM_HOST, C_NULL)
   end)
 

@@ -125,9 +125,16 @@ int32_t gss_cov_pairwise(const gss_variogram_t* vg, const double* a, int64_t na,
  *      ascending (FP64 squared distance accumulated in dimension order without FMA, index).
  *      radius < 0: plain k-NN.  radius >= 0: only neighbours with d^2 <= radius^2 (isotropic) or
  *      Mahalanobis d^2 <= 1 when inv_radii != NULL.  idx is m x k (int32, -1 padded). ---------- */
+enum {                        /* solver parameter `distance` (krig.jl:72, idw.jl:54, lwr.jl:57), [DEP] Distances.jl */
+  GSS_METRIC_EUCLIDEAN = 0,   /* default; with inv_radii: Mahalanobis ball                                       */
+  GSS_METRIC_CITYBLOCK = 1,
+  GSS_METRIC_CHEBYSHEV = 2,
+  GSS_METRIC_HAVERSINE = 3    /* points are (longitude, latitude) in degrees, metric_param = sphere radius       */
+};
+/* metric != EUCLIDEAN cannot be combined with a ball (searcher_ui uses either the ball or the metric, ui.jl:25-31). */
 int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double* centers, int64_t m,
-                       int32_t k, double radius, const double* inv_radii, int32_t* idx, int32_t* count,
-                       int32_t mem, void* stream);
+                       int32_t k, double radius, const double* inv_radii, int32_t metric, double metric_param,
+                       int32_t* idx, int32_t* count, int32_t mem, void* stream);
 
 /* ---- KrigingSolver ------------------------------------------------------------------------
  * gss_krig_create replaces preprocess (krig.jl:76-128) + GeoStatsModels.fit of exactsolve
@@ -157,12 +164,13 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
                                 double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
 
 /* moving neighbourhood: replaces approxsolve krig.jl:188-234 (search + fit + predictprob per point).
- * k = maxneighbors (already clamped by searcher_ui), radius/inv_radii as gss_knn_search.
+ * k = maxneighbors (already clamped by searcher_ui), radius / inv_radii / metric as gss_knn_search
+ * (the metric only ranks neighbours; covariances keep the variogram's own distance).
  * idx_out (m x k int32) and count_out (m) may be NULL. */
 int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
                              int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
-                             double* mean, double* var, uint8_t* status, int32_t* idx_out,
-                             int32_t* count_out, int32_t mem, void* stream);
+                             int32_t metric, double metric_param, double* mean, double* var, uint8_t* status,
+                             int32_t* idx_out, int32_t* count_out, int32_t mem, void* stream);
 
 /* re-use a factorised handle with new data values (same locations): the conditional-FFTGS
  * pattern fft.jl:176-188 where one kriging system serves every realisation.
@@ -180,7 +188,8 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
  *   weight(h) = exp(-weight_a * h^weight_p) for GSS_WEIGHT_EXP (reference default a = 3, p = 2,
  *   lwr.jl:58) or (1 - h^3)^3 for GSS_WEIGHT_TRICUBE.
  * k = number of neighbours the searcher returns (ui.jl:16-23): 1..64, or k == n for
- * `maxneighbors = nothing` (every sample, no search).  radius / inv_radii as gss_knn_search.
+ * `maxneighbors = nothing` (every sample, no search).  radius / inv_radii / metric as gss_knn_search;
+ * the weights use the distances of that metric (searchdists!, idw.jl:120).
  * status: GSS_PT_MISSING when fewer than minneighbors were found (idw.jl:123, lwr.jl:126),
  * GSS_PT_SINGULAR when the LWR normal equations are not positive definite (the reference throws).
  * xdata n x d and xdom m x d point-major; status may be NULL. */
@@ -188,12 +197,12 @@ enum { GSS_WEIGHT_EXP = 0, GSS_WEIGHT_TRICUBE = 1 };
 
 int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom,
                         int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
-                        double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
-                        void* stream);
+                        int32_t metric, double metric_param, double exponent, double* mean, double* dist,
+                        uint8_t* status, int32_t mem, void* stream);
 int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom,
                         int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
-                        int32_t weight_kind, double weight_a, double weight_p, double* mean, double* var,
-                        uint8_t* status, int32_t mem, void* stream);
+                        int32_t metric, double metric_param, int32_t weight_kind, double weight_a,
+                        double weight_p, double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
 
 /* ---- FFTGS ------------------------------------------------------------------------------
  * gss_fftgs_create replaces preprocess fft.jl:62-103 (unconditional part): covariance to the

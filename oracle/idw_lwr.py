@@ -15,10 +15,10 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
-from .kriging import sqdist
+from .kriging import metric_dist, metric_key
 
 
-def _neighbours(x, center, k, radius, radii):
+def _neighbours(x, center, k, radius, radii, distance=None):
     """searchdists!(neighbors, distances, center, searcher) — idw.jl:120, lwr.jl:123.
     Ascending (d2, index); with a ball only d2 <= r2 (Mahalanobis for an anisotropic ball)."""
     inv = None
@@ -28,15 +28,16 @@ def _neighbours(x, center, k, radius, radii):
         r2 = 1.0
     elif radius is not None:
         r2 = float(radius) ** 2
-    d2 = sqdist(x, center, inv)
+    d2 = metric_key(x, center, distance, inv)
     order = np.argsort(d2, kind="stable")[:k]
     if r2 is not None:
         order = order[d2[order] <= r2]
-    return order, np.sqrt(d2[order])
+    return order, metric_dist(d2[order], distance)
 
 
 def idw(x: np.ndarray, z: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[int] = None, minneighbors: int = 1,
-        exponent: float = 1.0, radius: Optional[float] = None, radii: Optional[Sequence[float]] = None):
+        exponent: float = 1.0, radius: Optional[float] = None, radii: Optional[Sequence[float]] = None,
+        distance=None):
     """idw.jl:111-142.  Returns (mu, dist, status): status 1 = fewer than `minneighbors` neighbours (`missing`)."""
     x = np.atleast_2d(np.asarray(x, dtype=np.float64))
     z = np.asarray(z, dtype=np.float64)
@@ -51,7 +52,7 @@ def idw(x: np.ndarray, z: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[i
     sd = np.full(m, np.nan)
     st = np.zeros(m, dtype=np.uint8)
     for p in range(m):
-        is_, ds = _neighbours(x, xdom[p], nmax, radius, radii)
+        is_, ds = _neighbours(x, xdom[p], nmax, radius, radii, distance)
         if is_.size < minneighbors:                                       # idw.jl:123-124
             st[p] = 1
             continue
@@ -84,7 +85,7 @@ def exp_weight(a: float, p: float) -> Callable:
 
 def lwr(x: np.ndarray, z: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[int] = None, minneighbors: int = 1,
         weightfun: Callable = default_weightfun, radius: Optional[float] = None,
-        radii: Optional[Sequence[float]] = None):
+        radii: Optional[Sequence[float]] = None, distance=None):
     """lwr.jl:114-147.  Returns (mu, var, status); `var` is norm(r) exactly as the reference stores it
     under `<var>_variance` (lwr.jl:141-142,154).  status 1 = too few neighbours, 2 = singular normal equations
     (the reference's `\\` would throw a SingularException there)."""
@@ -100,7 +101,7 @@ def lwr(x: np.ndarray, z: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[i
     var = np.full(m, np.nan)
     st = np.zeros(m, dtype=np.uint8)
     for p in range(m):
-        is_, ds = _neighbours(x, xdom[p], nmax, radius, radii)
+        is_, ds = _neighbours(x, xdom[p], nmax, radius, radii, distance)
         if is_.size < minneighbors or is_.size == 0:                      # lwr.jl:126-127
             st[p] = 1
             continue

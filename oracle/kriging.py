@@ -173,8 +173,46 @@ def sqdist(x: np.ndarray, c: np.ndarray, inv_radii: Optional[np.ndarray] = None)
     return acc
 
 
+def metric_key(x: np.ndarray, c: np.ndarray, distance=None, inv_radii: Optional[np.ndarray] = None) -> np.ndarray:
+    """Ranking key of the search for the solver parameter `distance` (krig.jl:72; [DEP] Distances.jl):
+    Euclidean -> squared distance (sqdist), "cityblock" -> sum |t|, "chebyshev" -> max |t|,
+    ("haversine", r) -> sin^2(dlat/2) + cos(lat1) cos(lat2) sin^2(dlon/2) for (lon, lat) in degrees."""
+    name = "euclidean" if distance is None else (distance if isinstance(distance, str) else distance[0])
+    if name == "euclidean":
+        return sqdist(x, c, inv_radii)
+    x = np.asarray(x, dtype=np.float64)
+    c = np.asarray(c, dtype=np.float64)
+    if name == "cityblock":
+        acc = np.zeros(x.shape[0])
+        for k in range(x.shape[1]):
+            acc = acc + np.abs(x[:, k] - c[k])
+        return acc
+    if name == "chebyshev":
+        acc = np.zeros(x.shape[0])
+        for k in range(x.shape[1]):
+            acc = np.maximum(acc, np.abs(x[:, k] - c[k]))
+        return acc
+    if name == "haversine":
+        D = 0.017453292519943295
+        s1 = np.sin(((c[1] - x[:, 1]) * 0.5) * D)
+        s2 = np.sin(((c[0] - x[:, 0]) * 0.5) * D)
+        cc = np.cos(x[:, 1] * D) * np.cos(c[1] * D)
+        return s1 * s1 + cc * (s2 * s2)
+    raise ValueError(distance)
+
+
+def metric_dist(key: np.ndarray, distance=None) -> np.ndarray:
+    """Distance from the ranking key."""
+    name = "euclidean" if distance is None else (distance if isinstance(distance, str) else distance[0])
+    if name == "euclidean":
+        return np.sqrt(key)
+    if name == "haversine":
+        return 2.0 * float(distance[1]) * np.arcsin(np.minimum(np.sqrt(key), 1.0))
+    return key
+
+
 def knn_search(x: np.ndarray, centers: np.ndarray, k: int, radius: Optional[float] = None,
-               radii: Optional[Sequence[float]] = None):
+               radii: Optional[Sequence[float]] = None, distance=None):
     """Exact k nearest neighbours of each centre among rows of x.
 
     Returns (idx [m x k] int32, 0-based, -1 padded; count [m]).  With a ball only
@@ -194,8 +232,8 @@ def knn_search(x: np.ndarray, centers: np.ndarray, k: int, radius: Optional[floa
     idx = np.full((m, k), -1, dtype=np.int32)
     cnt = np.zeros(m, dtype=np.int32)
     for p in range(m):
-        d2 = sqdist(x, centers[p], inv)
-        order = np.argsort(d2, kind="stable")[:k]          # (d2, index) ascending
+        d2 = metric_key(x, centers[p], distance, inv)
+        order = np.argsort(d2, kind="stable")[:k]          # (key, index) ascending
         if r2 is not None:
             order = order[d2[order] <= r2]
         idx[p, :order.size] = order
@@ -213,13 +251,13 @@ def exactsolve(variant, vg, x, z, xdom, mean=0.0, degree=None, drift_data=None, 
 
 
 def approxsolve(variant, vg, x, z, xdom, maxneighbors, minneighbors=1, mean=0.0, degree=None,
-                drift_data=None, drift_dom=None, radius=None, radii=None, return_idx=False):
+                drift_data=None, drift_dom=None, radius=None, radii=None, return_idx=False, distance=None):
     """krig.jl:188-234: per point k-NN, fit on the neighbours, predict; too few -> missing (NaN)."""
     x = np.atleast_2d(np.asarray(x, dtype=np.float64))
     xdom = np.atleast_2d(np.asarray(xdom, dtype=np.float64))
     z = np.asarray(z, dtype=np.float64)
     m = xdom.shape[0]
-    idx, cnt = knn_search(x, xdom, maxneighbors, radius, radii)
+    idx, cnt = knn_search(x, xdom, maxneighbors, radius, radii, distance)
     mu = np.full(m, np.nan)
     var = np.full(m, np.nan)
     status = np.zeros(m, dtype=np.uint8)

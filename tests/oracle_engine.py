@@ -30,10 +30,11 @@ class _Krig:
                                  drift_data=self.drift_data, drift_dom=drift_dom)
         return mu, var, np.zeros(len(mu), dtype=np.uint8)
 
-    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False):
+    def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False,
+                    distance=None):
         return OK_.approxsolve(self.variant, self.vg, self.x, self.z, xdom, k, minneighbors, mean=self.mean,
                                degree=self.degree, drift_data=self.drift_data, drift_dom=drift_dom, radius=radius,
-                               radii=radii, return_idx=return_idx)
+                               radii=radii, return_idx=return_idx, distance=distance)
 
     def predict_global_batch(self, xdom, zbatch):
         return np.stack([OK_.exactsolve(self.variant, self.vg, self.x, zb, xdom, mean=self.mean)[0] for zb in zbatch])
@@ -100,17 +101,17 @@ class OracleEngine:
         return cov_pairwise(_ovg(vg), a, b)
 
     @staticmethod
-    def knn_search(xdata, centers, k, radius=None, radii=None):
-        return OK_.knn_search(xdata, centers, k, radius, radii)
+    def knn_search(xdata, centers, k, radius=None, radii=None, distance=None):
+        return OK_.knn_search(xdata, centers, k, radius, radii, distance)
 
     @staticmethod
-    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None):
+    def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None, distance=None):
         from oracle import idw_lwr
-        return idw_lwr.idw(xdata, z, xdom, k, minneighbors, exponent, radius, radii)
+        return idw_lwr.idw(xdata, z, xdom, k, minneighbors, exponent, radius, radii, distance)
 
     @staticmethod
-    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None):
+    def lwr(xdata, z, xdom, k, minneighbors=1, weight=(0, 3.0, 2.0), radius=None, radii=None, distance=None):
         from oracle import idw_lwr
         kind, a, p = weight
         wf = idw_lwr.tricube if kind == 1 else idw_lwr.exp_weight(a, p)
-        return idw_lwr.lwr(xdata, z, xdom, k, minneighbors, wf, radius, radii)
+        return idw_lwr.lwr(xdata, z, xdom, k, minneighbors, wf, radius, radii, distance)

@@ -111,3 +111,68 @@ def test_solvers_through_solve_and_argument_errors():
         HipEngine.idw(rng.uniform(size=(200, 2)), rng.uniform(size=200), grid, 100)
     with pytest.raises(_lib.GSSError, match="exponent must be positive"):
         HipEngine.idw(xs[keep], zs[keep], grid, 5, 1, 0.0)
+
+
+METRICS = ["cityblock", "chebyshev", ("haversine", 6371.0)]
+
+
+@pytest.mark.parametrize("distance", METRICS)
+def test_search_metrics_indices_and_estimators(distance):
+    """`distance` parameter (krig.jl:72, idw.jl:54, lwr.jl:57): neighbour indices bit-exact under the metric's key,
+    IDW / LWR / moving-neighbourhood kriging on those neighbours within the usual tolerances."""
+    from gss.engine import HipEngine, KrigHandle, OK
+    import gss
+    from oracle import kriging as K
+    from oracle.variogram import Variogram
+    rng = np.random.default_rng(21)
+    if distance[0] == "haversine":
+        x = np.c_[rng.uniform(-180, 180, 700), rng.uniform(-80, 80, 700)]
+        c = np.c_[rng.uniform(-180, 180, 400), rng.uniform(-85, 85, 400)]
+    else:
+        x = rng.uniform(0, 100, (700, 3))
+        c = rng.uniform(0, 100, (400, 3))
+    c[:3] = x[:3]
+    z = np.sin(x[:, 0] / 20.0) + 0.01 * x[:, 1]
+    for k in (1, 7, 64):
+        idx, cnt = HipEngine.knn_search(x, c, k, distance=distance)
+        ridx, rcnt = K.knn_search(x, c, k, distance=distance)
+        assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+    for k in (9, None):
+        kk = 700 if k is None else k
+        mu, sd, st = HipEngine.idw(x, z, c, kk, 1, 2.0, distance=distance)
+        rmu, rsd, rst = E.idw(x, z, c, k, 1, 2.0, distance=distance)
+        assert np.array_equal(st, rst) and _close(mu, rmu) and _close(sd, rsd, 1e-9)
+        mu, var, st = HipEngine.lwr(x, z, c, kk, 1, (0, 3.0, 2.0), distance=distance)
+        rmu, rvar, rst = E.lwr(x, z, c, k, 1, E.default_weightfun, distance=distance)
+        assert np.array_equal(st, rst) and _close(mu, rmu, 1e-8) and _close(var, rvar, 1e-8)
+    if distance[0] != "haversine":
+        h = KrigHandle(gss.ExponentialVariogram(range=30.0), OK, x, z, factor=False)
+        mu, var, st, idx, cnt = h.predict_knn(c, 12, return_idx=True, distance=distance)
+        r = K.approxsolve(K.OK, Variogram("exponential", range=30.0), x, z, c, 12, return_idx=True, distance=distance)
+        assert np.array_equal(idx, r[3]) and _close(mu, r[0], 1e-9) and _close(var, r[1], 1e-9)
+
+
+def test_reference_haversine_cases_and_metric_errors():
+    """test/estimation/idw.jl:23-29 (Haversine(1.0), 3 data on a lon/lat grid) through solve; a ball cannot be
+    combined with a metric at the C-ABI (searcher_ui never does, ui.jl:25-31)."""
+    import gss
+    from gss import _lib
+    from gss.engine import HipEngine
+    xs = np.array([(50.0, -30.0), (100.0, 30.0), (200.0, 10.0)])
+    zs = np.array([4.0, -1.0, 3.0])
+    dom = gss.CartesianGrid((200, 100), (1.0, -89.0), (358.0 / 200, 178.0 / 100))
+    prob = gss.EstimationProblem(gss.georef(dict(z=zs), xs), dom, "z")
+    sol = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=3, distance=("haversine", 1.0)))))
+    mu, sd, _ = E.idw(xs, zs, dom.centroids()[::37], 3, distance=("haversine", 1.0))
+    assert _close(sol["z"][::37], mu) and _close(sol["z_distance"][::37], sd, 1e-9)
+    sol = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=3, distance=("haversine", 6371.0)))))
+    assert np.isfinite(sol["z"]).sum() > 0.9 * sol["z"].size
+    with pytest.raises(_lib.GSSError, match="cannot be combined"):
+        l = _lib.lib()
+        from gss.engine import ptr, check, MEM_HOST, current_stream
+        idx = np.empty((3, 2), dtype=np.int32)
+        cnt = np.empty(3, dtype=np.int32)
+        check(l.gss_knn_search(ptr(xs), 3, 2, ptr(xs), 3, 2, 5.0, None, 1, 0.0, ptr(idx), ptr(cnt), MEM_HOST,
+                               current_stream()))
+    with pytest.raises(_lib.GSSError, match="longitude"):
+        HipEngine.knn_search(np.zeros((4, 3)), np.zeros((2, 3)), 2, distance=("haversine", 1.0))

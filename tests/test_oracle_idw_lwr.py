@@ -122,8 +122,40 @@ def test_idw_lwr_parameter_errors():
     with pytest.raises(NotImplementedError):
         gss.solve(prob, gss.LWRSolver(("z", dict(weightfun=lambda h: 1 - h)), engine=OracleEngine))
     with pytest.raises(NotImplementedError):
+        gss.solve(prob, gss.IDWSolver(("z", dict(distance="minkowski")), engine=OracleEngine))
+    with pytest.raises(ValueError, match="positive radius"):
         gss.solve(prob, gss.IDWSolver(("z", dict(distance="haversine")), engine=OracleEngine))
     with pytest.raises(ValueError):
         gss.IDWSolver(("z", dict(variogram=None)))
     with pytest.warns(UserWarning, match="Invalid maximum number of neighbors"):
         gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=10 ** 6)), engine=OracleEngine))
+
+
+def test_search_distances_of_the_reference_tests():
+    """`distance` (idw.jl:54, lwr.jl:57; test/estimation/idw.jl:23-29 uses Haversine(1.0)): closed forms of the
+    metric keys and the solvers running on a longitude / latitude grid through the stand-in engine."""
+    from oracle.kriging import knn_search, metric_dist, metric_key
+    pts = np.array([[0.0, 0.0], [90.0, 0.0], [0.0, 90.0], [180.0, 0.0], [10.0, -20.0]])
+    key = metric_key(pts, pts[0], ("haversine", 2.0))
+    d = metric_dist(key, ("haversine", 2.0))
+    assert np.allclose(d[:4], [0.0, np.pi, np.pi, 2 * np.pi], atol=1e-12)         # quarter / half great circles, r = 2
+    assert np.allclose(metric_key(pts, pts[4], "cityblock"), [30, 100, 120, 190, 0])
+    assert np.allclose(metric_key(pts, pts[4], "chebyshev"), [20, 80, 110, 170, 0])
+    # the three metrics rank differently
+    q = np.array([[50.0, 40.0]])
+    ranks = {m: tuple(knn_search(pts, q, 5, distance=m)[0][0]) for m in (None, "cityblock", "chebyshev", ("haversine", 1.0))}
+    assert len(set(ranks.values())) >= 2
+    data = gss.georef(dict(z=[4.0, -1.0, 3.0]), [(50.0, -30.0), (100.0, 30.0), (200.0, 10.0)])
+    dom = gss.CartesianGrid((60, 30), (1.0, -89.0), (358.0 / 60, 178.0 / 30))
+    prob = gss.EstimationProblem(data, dom, "z")
+    sol = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=3, distance=("haversine", 1.0))), engine=OracleEngine))
+    mu, sd, _ = E.idw(np.array([(50.0, -30.0), (100.0, 30.0), (200.0, 10.0)]), np.array([4.0, -1.0, 3.0]),
+                      dom.centroids(), 3, distance=("haversine", 1.0))
+    assert np.allclose(sol["z"], mu) and np.allclose(sol["z_distance"], sd)
+    assert sol["z"].min() >= -1.0 and sol["z"].max() <= 4.0 and sd.max() <= np.pi
+    # a neighbourhood overrides the metric (searcher_ui, ui.jl:25-31)
+    sol2 = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=3, distance="chebyshev",
+                                                     neighborhood=gss.MetricBall(500.0))), engine=OracleEngine))
+    ref = E.lwr(np.array([(50.0, -30.0), (100.0, 30.0), (200.0, 10.0)]), np.array([4.0, -1.0, 3.0]), dom.centroids(), 3,
+                radius=500.0)
+    assert np.allclose(sol2["z"], ref[0], equal_nan=True)
