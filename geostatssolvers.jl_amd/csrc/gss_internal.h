@@ -317,7 +317,7 @@ int32_t cov_pairwise_dev(const VgDev& vg, const double* a, int64_t na, const dou
 // neighbour search (knn.hip)
 // ---------------------------------------------------------------------------------------------
 struct KnnIndex {
-  DevBuf xs, perm, lo, hi;  // Morton-sorted coordinates (n x dim), original indices, batch box corners (nb x dim)
+  DevBuf xs, perm, lo, hi;  // k-d ordered coordinates (n x dim), original indices, batch box corners (nb x dim)
   DevBuf lo1, hi1;          // boxes of groups of 64 consecutive batches (nb1 x dim)
   int64_t n = 0;
   int nb = 0, nb1 = 0, dim = 0;

@@ -4,7 +4,7 @@
 //   gss_lwr_predict  <- /root/reference/src/estimation/lwr.jl:114-147
 //
 // Two device paths, chosen by the neighbour count the searcher would return (ui.jl:16-23):
-//   * k <= 64     : K4 (Morton-ordered exact k-NN) then one wave per estimation point, lane = neighbour;
+//   * k <= 64     : K4 (k-d ordered exact k-NN) then one wave per estimation point, lane = neighbour;
 //   * k == n > 64 : "all samples" (maxneighbors = nothing): no search at all, one thread per estimation
 //                   point sweeping the samples staged through LDS (broadcast reads).
 // LWR solves its (d+1) x (d+1) normal equations about the estimation point (same predictor, better conditioned
@@ -385,7 +385,7 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   }
 
   const int64_t chunk = 1 << 20;
-  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call (Euclidean / Mahalanobis search only)
+  KnnIndex ix;  // k-d ordered batches + boxes, built once per call (Euclidean / Mahalanobis search only)
   const bool use_index = sp.metric == GSS_METRIC_EUCLIDEAN;
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s;

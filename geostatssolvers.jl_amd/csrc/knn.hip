@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pruned search.  The data are put in Morton order once (host, O(n log n), like the KD-tree build the reference
-// pays in Meshes/NearestNeighbors) and cut into batches of 64 consecutive points with bounding boxes.  One wave
+// Pruned search.  The data are put in a balanced k-d order once (host, O(n log n), like the KD-tree build the
+// reference pays in Meshes/NearestNeighbors) and cut into batches of 64 consecutive points with bounding boxes.  One wave
 // owns one query: lane b first bounds the distance to batch b (min squared distance to its box, accumulated with
 // the same rounded operations as the point distance, hence never larger than the distance to any point inside);
 // a second level of boxes covers groups of 64 batches.  Groups, and batches inside an opened group, are visited
@@ -175,40 +175,45 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
 // candidates are inserted one at a time.  Results are identical to the brute-force kernel: the ranking key is
 // still (d2, original index).
 // ---------------------------------------------------------------------------------------------
-static inline uint32_t spread_bits(uint32_t v, int dim) {
-  // interleave the low 10 bits of v with dim-1 zero bits between consecutive bits
-  uint32_t r = 0;
-  for (int b = 0; b < 10; ++b) r |= ((v >> b) & 1u) << (b * dim);
-  return r;
+// Balanced k-d ordering: the index range [lo, hi) of `perm` is split at a multiple of `unit` points (4096 while a
+// range holds more than one group of 64 batches, 64 below) by the median along the widest axis of its bounding
+// box, recursively, so that every batch of 64 consecutive points -- and every group of 64 consecutive batches -- is
+// a subtree: compact, nearly cubic, non-overlapping boxes.  (A Morton sort leaves batches that straddle the
+// curve's jumps and therefore have large boxes: 16 batches were opened per query at k = 16 instead of 6-7.)
+static void kd_order(const double* x, int dim, int32_t* perm, int64_t lo, int64_t hi) {
+  const int64_t count = hi - lo;
+  if (count <= 64) return;
+  const int64_t unit = count > 4096 ? 4096 : 64;
+  const int64_t units = (count + unit - 1) / unit;
+  const int64_t left = unit * ((units + 1) / 2);
+  double bl[3], bh[3];
+  for (int a = 0; a < dim; ++a) bl[a] = bh[a] = x[(int64_t)perm[lo] * dim + a];
+  for (int64_t i = lo + 1; i < hi; ++i)
+    for (int a = 0; a < dim; ++a) {
+      const double v = x[(int64_t)perm[i] * dim + a];
+      bl[a] = v < bl[a] ? v : bl[a];
+      bh[a] = v > bh[a] ? v : bh[a];
+    }
+  int axis = 0;
+  for (int a = 1; a < dim; ++a)
+    if (bh[a] - bl[a] > bh[axis] - bl[axis]) axis = a;
+  std::nth_element(perm + lo, perm + lo + left, perm + hi, [&](int32_t p, int32_t q) {
+    const double vp = x[(int64_t)p * dim + axis], vq = x[(int64_t)q * dim + axis];
+    return vp < vq || (vp == vq && p < q);
+  });
+  kd_order(x, dim, perm, lo, lo + left);
+  kd_order(x, dim, perm, lo + left, hi);
 }
 
 int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, hipStream_t s) {
-  std::vector<double> lo(dim, 0.0), hi(dim, 0.0);
-  for (int a = 0; a < dim; ++a) lo[a] = hi[a] = xhost[a];
-  for (int64_t i = 1; i < n; ++i)
-    for (int a = 0; a < dim; ++a) {
-      const double v = xhost[i * dim + a];
-      lo[a] = v < lo[a] ? v : lo[a];
-      hi[a] = v > hi[a] ? v : hi[a];
-    }
-  std::vector<std::pair<uint32_t, int32_t>> key((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    uint32_t code = 0;
-    for (int a = 0; a < dim; ++a) {
-      const double ext = hi[a] - lo[a];
-      const double u = ext > 0.0 ? (xhost[i * dim + a] - lo[a]) / ext : 0.0;
-      uint32_t q = (uint32_t)(u * 1023.0);
-      if (q > 1023u) q = 1023u;
-      code |= spread_bits(q, dim) << a;
-    }
-    key[(size_t)i] = {code, (int32_t)i};
-  }
-  std::sort(key.begin(), key.end());
+  std::vector<int32_t> key((size_t)n);
+  for (int64_t i = 0; i < n; ++i) key[(size_t)i] = (int32_t)i;
+  kd_order(xhost, dim, key.data(), 0, n);
   const int nb = (int)((n + 63) / 64);
   std::vector<double> xs((size_t)(n * dim)), blo((size_t)nb * dim), bhi((size_t)nb * dim);
   std::vector<int32_t> perm((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
-    const int32_t o = key[(size_t)i].second;
+    const int32_t o = key[(size_t)i];
     perm[(size_t)i] = o;
     for (int a = 0; a < dim; ++a) xs[(size_t)(i * dim + a)] = xhost[(int64_t)o * dim + a];
   }

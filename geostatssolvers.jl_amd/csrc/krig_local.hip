@@ -591,7 +591,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   sp.sk_mean = sk_mean;
 
   const int64_t chunk = 1 << 20;
-  KnnIndex ix;  // Morton-ordered batches + boxes, built once per call
+  KnnIndex ix;  // k-d ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
   const bool use_index = metric == GSS_METRIC_EUCLIDEAN && !(brute && brute[0] == '1');
   const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles

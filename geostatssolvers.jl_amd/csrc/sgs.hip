@@ -36,7 +36,7 @@ __device__ __forceinline__ double sgs_wave_sum(double v) {
   return v;
 }
 
-// lowest visiting rank inside each Morton batch of the search index
+// lowest visiting rank inside each batch of the search index
 __global__ __launch_bounds__(256) void sgs_batch_minrank_kernel(const int* __restrict__ perm,
                                                                 const int* __restrict__ rank, int n, int nb,
                                                                 int* __restrict__ bmin) {
