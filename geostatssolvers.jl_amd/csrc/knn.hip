@@ -14,6 +14,7 @@
 #include "gss_internal.h"
 
 #include <algorithm>
+#include <future>
 #include <climits>
 #include <cstdlib>
 #include <utility>
@@ -180,42 +181,54 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
 // box, recursively, so that every batch of 64 consecutive points -- and every group of 64 consecutive batches -- is
 // a subtree: compact, nearly cubic, non-overlapping boxes.  (A Morton sort leaves batches that straddle the
 // curve's jumps and therefore have large boxes: 16 batches were opened per query at k = 16 instead of 6-7.)
-static void kd_order(const double* x, int dim, int32_t* perm, int64_t lo, int64_t hi) {
+struct KdPoint {
+  double c[3];
+  int32_t idx;
+};
+
+static void kd_order(KdPoint* pts, int dim, int64_t lo, int64_t hi, int depth) {
   const int64_t count = hi - lo;
   if (count <= 64) return;
   const int64_t unit = count > 4096 ? 4096 : 64;
   const int64_t units = (count + unit - 1) / unit;
   const int64_t left = unit * ((units + 1) / 2);
   double bl[3], bh[3];
-  for (int a = 0; a < dim; ++a) bl[a] = bh[a] = x[(int64_t)perm[lo] * dim + a];
+  for (int a = 0; a < dim; ++a) bl[a] = bh[a] = pts[lo].c[a];
   for (int64_t i = lo + 1; i < hi; ++i)
     for (int a = 0; a < dim; ++a) {
-      const double v = x[(int64_t)perm[i] * dim + a];
+      const double v = pts[i].c[a];
       bl[a] = v < bl[a] ? v : bl[a];
       bh[a] = v > bh[a] ? v : bh[a];
     }
   int axis = 0;
   for (int a = 1; a < dim; ++a)
     if (bh[a] - bl[a] > bh[axis] - bl[axis]) axis = a;
-  std::nth_element(perm + lo, perm + lo + left, perm + hi, [&](int32_t p, int32_t q) {
-    const double vp = x[(int64_t)p * dim + axis], vq = x[(int64_t)q * dim + axis];
-    return vp < vq || (vp == vq && p < q);
+  std::nth_element(pts + lo, pts + lo + left, pts + hi, [axis](const KdPoint& p, const KdPoint& q) {
+    return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.idx < q.idx);
   });
-  kd_order(x, dim, perm, lo, lo + left);
-  kd_order(x, dim, perm, lo + left, hi);
+  if (depth < 3 && count > 16384) {  // the two halves are independent: up to 8 host threads on large inputs
+    auto fut = std::async(std::launch::async, kd_order, pts, dim, lo, lo + left, depth + 1);
+    kd_order(pts, dim, lo + left, hi, depth + 1);
+    fut.get();
+  } else {
+    kd_order(pts, dim, lo, lo + left, depth + 1);
+    kd_order(pts, dim, lo + left, hi, depth + 1);
+  }
 }
 
 int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, hipStream_t s) {
-  std::vector<int32_t> key((size_t)n);
-  for (int64_t i = 0; i < n; ++i) key[(size_t)i] = (int32_t)i;
-  kd_order(xhost, dim, key.data(), 0, n);
+  std::vector<KdPoint> pts((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    for (int a = 0; a < 3; ++a) pts[(size_t)i].c[a] = a < dim ? xhost[i * dim + a] : 0.0;
+    pts[(size_t)i].idx = (int32_t)i;
+  }
+  kd_order(pts.data(), dim, 0, n, 0);
   const int nb = (int)((n + 63) / 64);
   std::vector<double> xs((size_t)(n * dim)), blo((size_t)nb * dim), bhi((size_t)nb * dim);
   std::vector<int32_t> perm((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
-    const int32_t o = key[(size_t)i];
-    perm[(size_t)i] = o;
-    for (int a = 0; a < dim; ++a) xs[(size_t)(i * dim + a)] = xhost[(int64_t)o * dim + a];
+    perm[(size_t)i] = pts[(size_t)i].idx;
+    for (int a = 0; a < dim; ++a) xs[(size_t)(i * dim + a)] = pts[(size_t)i].c[a];
   }
   for (int b = 0; b < nb; ++b) {
     const int64_t j0 = (int64_t)b * 64, j1 = j0 + 64 < n ? j0 + 64 : n;
