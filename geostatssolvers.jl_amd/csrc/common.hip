@@ -183,6 +183,34 @@ static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
   }
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, size_t nwords) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void copy_f64_kernel(double* __restrict__ dst, const double* __restrict__ src,
+                                                       int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+int32_t dev_zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return GSS_OK;
+  const size_t nwords = bytes / 4;
+  size_t blocks = (nwords + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), nwords);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+int32_t dev_copy_f64(double* dst, const double* src, int64_t n, hipStream_t s) {
+  if (n <= 0) return GSS_OK;
+  hipLaunchKernelGGL(copy_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
 int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
   GSS_REQUIRE(vg != nullptr, "variogram is NULL");
   GSS_REQUIRE(vg->dim >= 1 && vg->dim <= 3, "variogram dim %d outside 1..3", vg->dim);

@@ -439,7 +439,7 @@ int64_t potrf_dinv_doubles(int64_t n) { return ((n + LEAF - 1) / LEAF) * LEAF * 
 // dinv: caller workspace of potrf_dinv_doubles(n) doubles receiving the inverses of the diagonal leaf blocks
 // (they are needed by the panel solves anyway); asynchronous on s, *d_info is zeroed first.
 int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s) {
-  GSS_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
+  GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
   return potrf_rec(A, n, lda, 0, d_info, dinv, s);
 }
 

@@ -306,6 +306,12 @@ int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ld
 int32_t trsm_right_lt_f64(double* X, int64_t m, int64_t n, int64_t ldx, const double* L, int64_t ldl,
                           double* scratch, const double* dinv, hipStream_t s);
 
+// Fill / copy kernels used instead of hipMemsetAsync / hipMemcpyAsync inside sequences that may be captured into a
+// hipGraph: with ROCm 7.2 a graph's memset nodes running next to plain memsets of another stream were observed to
+// write a stale fill pattern (0x24242424 into a word that was cleared with 0).
+int32_t dev_zero_bytes(void* p, size_t bytes, hipStream_t s);             // p 4-byte aligned, bytes multiple of 4
+int32_t dev_copy_f64(double* dst, const double* src, int64_t n, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // covariance assembly (cov_kernels.hip)
 // ---------------------------------------------------------------------------------------------

@@ -38,20 +38,18 @@ struct DriftSpec {
   double inv_scale[3];
 };
 
-// out[c * ld + p] = f_c(x_p) for c < nc, zero rows up to nrows; optionally dotted with wd into mean_part
+// out[c * ld + p] = f_c(x_p) for c < nc, zero rows up to nrows
 template <int DIM>
 __global__ __launch_bounds__(256) void drift_rows_kernel(DriftSpec ds, const double* __restrict__ x,
                                                          const double* __restrict__ drift_vals, int64_t npts,
                                                          int64_t ncols_pad, double* __restrict__ out, int64_t ld,
-                                                         int nrows, const double* __restrict__ wd,
-                                                         double* __restrict__ mean_part) {
+                                                         int nrows) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= ncols_pad) return;
   const int64_t pc = p < npts ? p : npts - 1;
   double xs[DIM];
 #pragma unroll
   for (int k = 0; k < DIM; ++k) xs[k] = (x[pc * DIM + k] - ds.center[k]) * ds.inv_scale[k];
-  double acc = 0.0;
   for (int c = 0; c < nrows; ++c) {
     double f = 0.0;
     if (c < ds.nc) {
@@ -65,39 +63,37 @@ __global__ __launch_bounds__(256) void drift_rows_kernel(DriftSpec ds, const dou
       } else {
         f = drift_vals[pc * ds.nc + c];
       }
-      if (wd) acc = fma(wd[c], f, acc);
     }
     out[(int64_t)c * ld + p] = f;
   }
-  if (mean_part) mean_part[p] = acc;
 }
 
-// R[j * ldr + p] = C(x_j, x0_p) for the j rows of segment blockIdx.y; mean_part[seg][p] = sum wd_j C
+// R[j * ldr + p] = C(x_j, x0_p) for the j rows of segment blockIdx.y
 template <int DIM>
 __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* __restrict__ xd, int n,
                                                        const double* __restrict__ x0, int64_t m_valid,
-                                                       const double* __restrict__ wd, double* __restrict__ R,
-                                                       int64_t ldr, double* __restrict__ mean_part, int seg_len) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t pc = p < m_valid ? p : m_valid - 1;
-  double c[DIM];
+                                                       double* __restrict__ R, int64_t ldr, int seg_len,
+                                                       int nblk) {
+  // units = (point block, row segment), walked with a grid stride
+  for (int unit = blockIdx.x; unit < nblk * NSEG; unit += gridDim.x) {
+    const int seg = unit % NSEG;
+    const int64_t p = (int64_t)(unit / NSEG) * 256 + threadIdx.x;
+    const int64_t pc = p < m_valid ? p : m_valid - 1;
+    double c[DIM];
 #pragma unroll
-  for (int k = 0; k < DIM; ++k) c[k] = x0[pc * DIM + k];
-  const int j0 = blockIdx.y * seg_len;
-  const int j1 = j0 + seg_len < n ? j0 + seg_len : n;
-  double acc = 0.0;
-  double* rp = R + (int64_t)j0 * ldr + p;
+    for (int k = 0; k < DIM; ++k) c[k] = x0[pc * DIM + k];
+    const int j0 = seg * seg_len;
+    const int j1 = j0 + seg_len < n ? j0 + seg_len : n;
+    double* rp = R + (int64_t)j0 * ldr + p;
 #pragma unroll 4
-  for (int j = j0; j < j1; ++j) {
-    double x[DIM];
+    for (int j = j0; j < j1; ++j) {
+      double x[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
-    const double cv = cov_pair<DIM>(vg, x, c);
-    *rp = cv;
-    rp += ldr;
-    acc = fma(wd[j], cv, acc);
+      for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
+      *rp = cov_pair<DIM>(vg, x, c);
+      rp += ldr;
+    }
   }
-  mean_part[(int64_t)blockIdx.y * ldr + p] = acc;
 }
 
 // K3.  One workgroup owns a strip of BN = 128 points and walks the row blocks I of W' (lower
@@ -113,7 +109,7 @@ constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 template <bool W14, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
-    int64_t ldr, const double* __restrict__ mean_part, int nparts, double sill, double mean0, int64_t m_valid,
+    int64_t ldr, double sill, double mean0, int64_t m_valid,
     double* __restrict__ mean_out, double* __restrict__ var_out, uint8_t* __restrict__ status_out,
     double* __restrict__ qpart, int strip0, int nstrips) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -125,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int nI = (N1 + BM - 1) / BM;
+  const int nI = (N1 + BM) / BM;  // rows 0..N1: the system plus the dual-weight row N1 (the mean)
   int64_t strip = blockIdx.x;  // strips strip0 .. strip0 + nstrips - 1 belong to this launch
   int Ibeg = 0, Iend = nI;
   if (SPLIT) {
@@ -143,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int kq = tid >> 6;
 
   double qacc[4] = {0.0, 0.0, 0.0, 0.0};
+  double macc[4] = {0.0, 0.0, 0.0, 0.0};  // row N1 of the product: wd . rhs
 
   for (int I = Ibeg; I < Iend; ++I) {
     const int i0 = I * BM;
@@ -224,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
             const int row = i0 + tm * 16 + lk + 4 * r;
             const double v = accw[tm][tn][r];
             const double vv = v * v;
-            s += (row < n) ? vv : -vv;
+            s += (row < n) ? vv : (row < N1 ? -vv : 0.0);
+            if (row == N1) macc[tn] += v;
           }
         qacc[tn] += s;
       }
@@ -239,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
             const int row = i0 + wm * 64 + tm * 16 + lk + 4 * r;
             const double v = acc[tm][tn][r];
             const double vv = v * v;
-            s += (row < n) ? vv : -vv;
+            s += (row < n) ? vv : (row < N1 ? -vv : 0.0);
+            if (row == N1) macc[tn] += v;
           }
         qacc[tn] += s;
       }
@@ -251,31 +250,44 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   for (int tn = 0; tn < 4; ++tn) {
     qacc[tn] += __shfl_xor(qacc[tn], 16);
     qacc[tn] += __shfl_xor(qacc[tn], 32);
+    macc[tn] += __shfl_xor(macc[tn], 16);
+    macc[tn] += __shfl_xor(macc[tn], 32);
   }
   __syncthreads();
-  double* red = smem;  // [2][BN]
+  double* red = smem;            // [2][BN] signed squares
+  double* redm = smem + 2 * BN;  // [2][BN] mean row
   if (lk == 0) {
     if (W14) {
       red[wave * 32 + lr] = qacc[0];
       red[wave * 32 + 16 + lr] = qacc[1];
       red[BN + wave * 32 + lr] = 0.0;
       red[BN + wave * 32 + 16 + lr] = 0.0;
+      redm[wave * 32 + lr] = macc[0];
+      redm[wave * 32 + 16 + lr] = macc[1];
+      redm[BN + wave * 32 + lr] = 0.0;
+      redm[BN + wave * 32 + 16 + lr] = 0.0;
     } else {
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
+      for (int tn = 0; tn < 4; ++tn) {
+        red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
+        redm[wm * BN + wn * 64 + tn * 16 + lr] = macc[tn];
+      }
     }
   }
   __syncthreads();
   if (SPLIT) {
-    if (tid < BN) qpart[(int64_t)Ibeg * ldr + p0 + tid] = red[tid] + red[BN + tid];
+    if (tid < BN) {
+      qpart[(int64_t)Ibeg * ldr + p0 + tid] = red[tid] + red[BN + tid];
+      // the unit that owns the row block of row N1 delivers the mean
+      if (Ibeg == N1 / BM && p0 + tid < m_valid) mean_out[p0 + tid] = mean0 + (redm[tid] + redm[BN + tid]);
+    }
     return;
   }
   if (tid < BN) {
     const int64_t p = p0 + tid;
     if (p < m_valid) {
       const double q = red[tid] + red[BN + tid];
-      double mu = mean0;
-      for (int s = 0; s < nparts; ++s) mu += mean_part[(int64_t)s * ldr + p];
+      const double mu = mean0 + (redm[tid] + redm[BN + tid]);
       const double v = sill - q;
       mean_out[p] = mu;
       var_out[p] = v > 0.0 ? v : 0.0;
@@ -284,20 +296,16 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   }
 }
 
-// mean / variance from the per-row-block partial sums of the SPLIT quadratic form (fixed summation order)
-__global__ __launch_bounds__(256) void krig_finish_kernel(const double* __restrict__ qpart, int nI,
-                                                          const double* __restrict__ mean_part, int nparts,
-                                                          int64_t ldr, double sill, double mean0, int64_t m_valid,
-                                                          double* __restrict__ mean_out, double* __restrict__ var_out,
+// variance from the per-row-block partial sums of the SPLIT quadratic form (fixed summation order); the mean is
+// written by the unit that owns row N1
+__global__ __launch_bounds__(256) void krig_finish_kernel(const double* __restrict__ qpart, int nI, int64_t ldr,
+                                                          double sill, int64_t m_valid, double* __restrict__ var_out,
                                                           uint8_t* __restrict__ status_out) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= m_valid) return;
   double q = 0.0;
   for (int I = 0; I < nI; ++I) q += qpart[(int64_t)I * ldr + p];
-  double mu = mean0;
-  for (int s = 0; s < nparts; ++s) mu += mean_part[(int64_t)s * ldr + p];
   const double v = sill - q;
-  mean_out[p] = mu;
   var_out[p] = v > 0.0 ? v : 0.0;
   if (status_out) status_out[p] = GSS_PT_OK;
 }
@@ -341,6 +349,15 @@ struct gss_krig {
   DriftSpec ds;
   DevBuf xdata, z, drift_data;
   DevBuf factor;  // W' (ldw x N1pad, column-major) followed by wd (N1pad)
+  // fit in flight: workspace, completion event and status words (joined by krig_fit_wait)
+  DevBuf fit_ws;
+  hipEvent_t fit_done = nullptr;
+  bool fit_pending = false;
+  int* fit_info = nullptr;
+  ~gss_krig() {
+    if (fit_pending && fit_done) (void)hipEventSynchronize(fit_done);
+    if (fit_done) (void)hipEventDestroy(fit_done);
+  }
   bool factored = false;
   double* Wp() const { return factor.as<double>(); }
   double* wd() const { return factor.as<double>() + ldw * N1pad; }
@@ -423,21 +440,20 @@ static int32_t krig_workspace(int64_t N1pad, int64_t mc, hipStream_t s, double**
 }
 
 static int32_t launch_drift_rows(const gss_krig* h, const double* x, const double* drift_vals, int64_t npts,
-                                 int64_t ncols_pad, double* out, int64_t ld, int nrows, const double* wd,
-                                 double* mean_part, hipStream_t s) {
+                                 int64_t ncols_pad, double* out, int64_t ld, int nrows, hipStream_t s) {
   dim3 grid((unsigned)((ncols_pad + 255) / 256));
   switch (h->dim) {
     case 1:
       hipLaunchKernelGGL((drift_rows_kernel<1>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
-                         ld, nrows, wd, mean_part);
+                         ld, nrows);
       break;
     case 2:
       hipLaunchKernelGGL((drift_rows_kernel<2>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
-                         ld, nrows, wd, mean_part);
+                         ld, nrows);
       break;
     default:
       hipLaunchKernelGGL((drift_rows_kernel<3>), grid, dim3(256), 0, s, h->ds, x, drift_vals, npts, ncols_pad, out,
-                         ld, nrows, wd, mean_part);
+                         ld, nrows);
       break;
   }
   GSS_HIP(hipGetLastError());
@@ -471,11 +487,22 @@ __global__ void constraint_rows_kernel(const double* __restrict__ WS, int64_t ld
   }
 }
 
+__global__ __launch_bounds__(256) void wd_row_kernel(const double* __restrict__ wd, int64_t N1,
+                                                     double* __restrict__ row, int64_t ldw) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < N1) row[k * ldw] = wd[k];
+}
+
 // Factorisation of the kriging system on the device (GeoStatsModels.fit, krig.jl:176).  One workspace
-// allocation, no host synchronisation until the final status read.
-static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
-  const int64_t n = h->n, N1 = h->N1, N1pad = h->N1pad, ldw = h->ldw;
-  const int nc = h->nc;
+// allocation; everything is enqueued on `s` without host synchronisation (krig_fit_wait joins).
+struct FitPlan {
+  double *M, *T, *Dinv, *Fd, *Bm, *S, *SDinv, *gwork, *zz, *u;
+  int *info, *info2;
+  int64_t szM, szS;
+};
+
+static int32_t krig_fit_plan(gss_krig* h, FitPlan* fp) {
+  const int64_t n = h->n, N1pad = h->N1pad, ldw = h->ldw;
   const int64_t hh = n / 2 + 64;
   const int64_t szM = ldw * N1pad;
   const int64_t szT = hh * hh > (int64_t)MAX_NC * n ? hh * hh : (int64_t)MAX_NC * n;
@@ -485,34 +512,45 @@ static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
   int64_t szGemv = gemv_work_doubles(false, ldw, ldw);
   if (gemv_work_doubles(true, ldw, ldw) > szGemv) szGemv = gemv_work_doubles(true, ldw, ldw);
   const int64_t szVec = 2 * ldw;
-  DevBuf ws;
+  DevBuf& ws = h->fit_ws;
   GSS_TRY(ws.alloc(sizeof(double) * (size_t)(szM + szT + szDinv + szFd + szBm + szS + szGemv + szVec) + 64));
-  double* M = ws.as<double>();
-  double* T = M + szM;
-  double* Dinv = T + szT;
-  double* Fd = Dinv + szDinv;
-  double* Bm = Fd + szFd;
-  double* S = Bm + szBm;            // S (MAX_NC^2), then its leaf inverse scratch (64 x 64)
-  double* SDinv = S + MAX_NC * MAX_NC;
-  double* gwork = S + szS;
-  double* zz = gwork + szGemv;
-  double* u = zz + ldw;
-  int* info = reinterpret_cast<int*>(u + ldw);
-  int* info2 = info + 1;
+  fp->M = ws.as<double>();
+  fp->T = fp->M + szM;
+  fp->Dinv = fp->T + szT;
+  fp->Fd = fp->Dinv + szDinv;
+  fp->Bm = fp->Fd + szFd;
+  fp->S = fp->Bm + szBm;            // S (MAX_NC^2), then its leaf inverse scratch (64 x 64)
+  fp->SDinv = fp->S + MAX_NC * MAX_NC;
+  fp->gwork = fp->S + szS;
+  fp->zz = fp->gwork + szGemv;
+  fp->u = fp->zz + ldw;
+  fp->info = reinterpret_cast<int*>(fp->u + ldw);
+  fp->info2 = fp->info + 1;
+  fp->szM = szM;
+  fp->szS = szS;
+  return GSS_OK;
+}
 
-  GSS_HIP(hipMemsetAsync(M, 0, sizeof(double) * (size_t)szM, s));
-  GSS_HIP(hipMemsetAsync(h->factor.p, 0, h->factor.bytes, s));
-  GSS_HIP(hipMemsetAsync(info2, 0, sizeof(int), s));
+// pure enqueue (fills, copies, kernels), about 140 launches: roughly 2 ms of host time
+static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
+  const int64_t n = h->n, N1 = h->N1, ldw = h->ldw;
+  const int nc = h->nc;
+  double *M = fp.M, *T = fp.T, *Dinv = fp.Dinv, *Fd = fp.Fd, *Bm = fp.Bm, *S = fp.S, *SDinv = fp.SDinv;
+  double *gwork = fp.gwork, *zz = fp.zz, *u = fp.u;
+  int *info = fp.info, *info2 = fp.info2;
+  const int64_t szM = fp.szM, szS = fp.szS;
+  GSS_TRY(dev_zero_bytes(M, sizeof(double) * (size_t)szM, s));
+  GSS_TRY(dev_zero_bytes(h->factor.p, h->factor.bytes, s));
+  GSS_TRY(dev_zero_bytes(info2, sizeof(int), s));
   GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M, ldw, s));
   GSS_TRY(potrf_f64(M, n, ldw, info, Dinv, s));
   double* Wp = h->Wp();
   GSS_TRY(trtri_f64(M, n, ldw, Wp, ldw, T, Dinv, s));
 
   if (nc > 0) {
-    GSS_HIP(hipMemsetAsync(S, 0, sizeof(double) * (size_t)szS, s));
+    GSS_TRY(dev_zero_bytes(S, sizeof(double) * (size_t)szS, s));
     // Fd (n x nc, column-major): drift functions at the data locations
-    GSS_TRY(launch_drift_rows(h, h->xdata.as<double>(), h->drift_data.as<double>(), n, n, Fd, n, nc, nullptr,
-                              nullptr, s));
+    GSS_TRY(launch_drift_rows(h, h->xdata.as<double>(), h->drift_data.as<double>(), n, n, Fd, n, nc, s));
     // Bm[c] = W F[:, c]   (row c of B = (L^-1 F)')
     for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(false, n, n, Wp, ldw, Fd + (int64_t)c * n, Bm + (int64_t)c * n, gwork, s));
     hipLaunchKernelGGL(small_gram_kernel, dim3(nc, nc), dim3(64), 0, s, Bm, nc, n, S, MAX_NC);
@@ -529,28 +567,52 @@ static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
   }
 
   // dual weights wd = W'' D W' [z - mean; 0]
-  GSS_HIP(hipMemsetAsync(zz, 0, sizeof(double) * (size_t)(2 * ldw), s));
-  GSS_HIP(hipMemcpyAsync(zz, h->z.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  GSS_TRY(dev_zero_bytes(zz, sizeof(double) * (size_t)(2 * ldw), s));
+  GSS_TRY(dev_copy_f64(zz, h->z.as<double>(), n, s));
   if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
     hipLaunchKernelGGL(sub_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, zz, n, h->sk_mean);
   }
   GSS_TRY(gemv_f64(false, N1, N1, Wp, ldw, zz, u, gwork, s));
   if (nc > 0) hipLaunchKernelGGL(flip_tail_kernel, dim3(1), dim3(256), 0, s, u, n, N1);
   GSS_TRY(gemv_f64(true, N1, N1, Wp, ldw, u, h->wd(), gwork, s));
+  // row N1 of W' <- wd: the mean then comes out of K3's product as row N1 of W' R
+  hipLaunchKernelGGL(wd_row_kernel, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, s, h->wd(), N1, Wp + N1, ldw);
   GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
+  FitPlan fp;
+  GSS_TRY(krig_fit_plan(h, &fp));
+  GSS_TRY(krig_fit_enqueue(h, fp, s));
+  h->fit_info = fp.info;
+  if (!h->fit_done) GSS_HIP(hipEventCreateWithFlags(&h->fit_done, hipEventDisableTiming));
+  GSS_HIP(hipEventRecord(h->fit_done, s));
+  h->fit_pending = true;
+  h->factored = true;
+  return GSS_OK;
+}
+
+// Joins a pending fit: waits for it, reads the two status words, releases the workspace.
+static int32_t krig_fit_wait(gss_krig* h) {
+  if (!h->fit_pending) return GSS_OK;
+  h->fit_pending = false;
+  GSS_HIP(hipEventSynchronize(h->fit_done));
   int hinfo[2] = {0, 0};
-  GSS_HIP(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  GSS_HIP(hipStreamSynchronize(s));
+  GSS_HIP(hipMemcpy(hinfo, h->fit_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  h->fit_ws.release();
+  h->fit_info = nullptr;
   if (hinfo[0] != 0) {
+    h->factored = false;
     set_error("kriging covariance matrix is not positive definite (pivot %d of %lld); add a nugget or remove "
-              "duplicate samples", hinfo[0] - 1, (long long)n);
+              "duplicate samples", hinfo[0] - 1, (long long)h->n);
     return GSS_ERR_NOT_POSDEF;
   }
   if (hinfo[1] != 0) {
+    h->factored = false;
     set_error("drift functions are linearly dependent on the sample locations (constraint %d)", hinfo[1] - 1);
     return GSS_ERR_NOT_POSDEF;
   }
-  h->factored = true;
   return GSS_OK;
 }
 
@@ -625,8 +687,10 @@ int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t var
     GSS_REQUIRE(n + h->nc >= 1 && n >= h->nc, "fewer samples (%lld) than drift constraints (%d)", (long long)n,
                 h->nc);
   h->N1 = n + h->nc;
-  h->N1pad = round_up(h->N1, BK);
-  h->ldw = round_up(h->N1, BM);
+  // one spare row below the system: row N1 of W' holds the dual weights wd, so that the mean wd . rhs falls out of
+  // the same MFMA product as the quadratic form (and K1 no longer depends on the fit)
+  h->N1pad = round_up(h->N1 + 1, BK);
+  h->ldw = round_up(h->N1 + 1, BM);
 
   hipStream_t s = to_stream(stream);
   GSS_TRY(h->xdata.alloc(sizeof(double) * (size_t)(n * h->dim)));
@@ -640,7 +704,10 @@ int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t var
   GSS_HIP(hipStreamSynchronize(s));
   // the factor buffer always exists so that a broadcast can land in it
   GSS_TRY(h->factor.alloc(sizeof(double) * (size_t)(h->ldw * h->N1pad + h->N1pad)));
-  if ((flags & GSS_KRIG_NO_FACTOR) == 0) GSS_TRY(krig_factorize(h, s));
+  if ((flags & GSS_KRIG_NO_FACTOR) == 0) {
+    GSS_TRY(krig_factorize(h, s));
+    GSS_TRY(krig_fit_wait(h));
+  }
   guard.h = nullptr;
   *out = h;
   return GSS_OK;
@@ -715,42 +782,41 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
     const int64_t mv = (m - off) < mc ? (m - off) : mc;
     const int64_t cols = round_up(mv, 256);  // multiple of BN as well
     const double* x0 = sx.as<double>() + off * dim;
-    dim3 g1((unsigned)(cols / 256), NSEG);
+    const int nblk = (int)(cols / 256);
+    dim3 g1((unsigned)(nblk * NSEG));
     const int nrows = (int)(h->N1pad - h->n);
     {
       ProfScope ps("krig_rhs", s);
       switch (dim) {
       case 1:
         hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), Rws, ldr, mpart, seg_len);
+                           mv, Rws, ldr, seg_len, nblk);
         break;
       case 2:
         hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), Rws, ldr, mpart, seg_len);
+                           mv, Rws, ldr, seg_len, nblk);
         break;
       default:
         hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, h->wd(), Rws, ldr, mpart, seg_len);
+                           mv, Rws, ldr, seg_len, nblk);
         break;
     }
     GSS_HIP(hipGetLastError());
     // drift rows n..N1-1 and zero rows up to N1pad, plus their share of the mean
     if (nrows > 0) {
       const double* dv = h->variant == GSS_KRIG_EXTDRIFT ? sd.as<double>() + off * h->ndrift : nullptr;
-      GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, Rws + h->n * ldr, ldr, nrows, h->wd() + h->n,
-                                mpart + (int64_t)NSEG * ldr, s));
+      GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, Rws + h->n * ldr, ldr, nrows, s));
     }
     }
-    const int nparts = nrows > 0 ? NSEG + 1 : NSEG;
     ProfScope pq("krig_quadform", s);
     {
       const int nstrips = (int)(cols / BN);
-      const int nI = (int)((h->N1 + BM - 1) / BM);
-      double* qpart = mpart + (int64_t)(NSEG + 1) * ldr;
+      const int nI = (int)((h->N1 + BM) / BM);  // row blocks of rows 0..N1 (row N1 = dual weights)
+      double* qpart = mpart;
       const double mean0 = h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0;
       uint8_t* stp = status ? sstat.as<uint8_t>() + off : nullptr;
-#define GSS_K3_ARGS(S0, NS) h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, mpart, nparts, h->vg.sill, \
-                            mean0, mv, smean.as<double>() + off, svar.as<double>() + off, stp, qpart, (S0), (NS)
+#define GSS_K3_ARGS(S0, NS) h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, h->vg.sill, mean0, mv, \
+                            smean.as<double>() + off, svar.as<double>() + off, stp, qpart, (S0), (NS)
       // Whole rounds of 512 resident workgroups (2 per CU) run one workgroup per strip; the remainder strips
       // would occupy a full extra round, so they run as (strip, row block) units, which pack ~3x tighter.
       const int nmain = split ? 0 : (nstrips / 512) * 512;
@@ -774,8 +840,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
         const int64_t pbeg = (int64_t)nmain * BN;
         if (mv > pbeg)
           hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv - pbeg + 255) / 256)), dim3(256), 0, s, qpart + pbeg,
-                             nI, mpart + pbeg, nparts, ldr, h->vg.sill, mean0, mv - pbeg, smean.as<double>() + off + pbeg,
-                             svar.as<double>() + off + pbeg, stp ? stp + pbeg : nullptr);
+                             nI, ldr, h->vg.sill, mv - pbeg, svar.as<double>() + off + pbeg, stp ? stp + pbeg : nullptr);
       }
 #undef GSS_K3_ARGS
     }
@@ -874,26 +939,26 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
     const int64_t mv = (m - off) < mc ? (m - off) : mc;
     const int64_t cols = round_up(mv, 256);
     const double* x0 = sx.as<double>() + off * dim;
-    dim3 g1((unsigned)(cols / 256), NSEG);
+    const int nblk = (int)(cols / 256);
+    dim3 g1((unsigned)(nblk * NSEG));
     switch (dim) {
       case 1:
         hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), Rws, ldr, mpart, seg_len);
+                           Rws, ldr, seg_len, nblk);
         break;
       case 2:
         hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), Rws, ldr, mpart, seg_len);
+                           Rws, ldr, seg_len, nblk);
         break;
       default:
         hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           h->wd(), Rws, ldr, mpart, seg_len);
+                           Rws, ldr, seg_len, nblk);
         break;
     }
     GSS_HIP(hipGetLastError());
     const int nrows = (int)(h->N1pad - n);
     if (nrows > 0)
-      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, Rws + n * ldr, ldr, nrows, h->wd() + n,
-                                mpart + (int64_t)NSEG * ldr, s));
+      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, Rws + n * ldr, ldr, nrows, s));
     // out(b, off + p) = sum_k WD(k, b) R(k, p)
     GSS_TRY(gemm_f64(nbatch, mv, N1, 1.0, WD.as<double>(), ldw, 1, Rws, ldr, 1, 0.0,
                      so.as<double>() + off, m, 1, false, s));

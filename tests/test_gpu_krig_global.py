@@ -233,3 +233,4 @@ def test_nested_variograms_all_paths():
     p = OL.preprocess(o, cent, cent[[3, 40]], [0.5, -0.5])
     L22, d2 = lh.factor()
     assert np.max(np.abs(L22 - p.L22)) < 1e-9 and np.max(np.abs(d2 - p.d2)) < 1e-9
+
