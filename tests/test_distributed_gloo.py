@@ -63,6 +63,14 @@ def _worker(rank, world, port, q):
         s2 = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
                        gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine))
         out["lu"] = np.stack(s2["z"])
+        # IDW / LWR shard estimation points, SGS shards realisations (section 8f rows)
+        si = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=6, exponent=2)), engine=OracleEngine))
+        sl = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9)), engine=OracleEngine))
+        out["idw"], out["lwr"] = np.c_[si["z"], si["z_distance"]], np.c_[sl["z"], sl["z_variance"]]
+        s3 = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
+                       gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0), maxneighbors=5)), rng=9,
+                               engine=OracleEngine))
+        out["sgs"] = np.stack(s3["z"])
         # factor broadcast plumbing
         t = torch.arange(1000, dtype=torch.float64) * (1.0 if rank == 0 else -1.0)
         parallel.broadcast_(t, src=0)
@@ -115,8 +123,16 @@ def test_two_ranks_reproduce_single_process_results():
     S = gss.georef({"z": [0.0, 1.0]}, np.array([[2.0], [20.0]]))
     l = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
                   gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine))
+    ri = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=6, exponent=2)), engine=OracleEngine))
+    rl = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9)), engine=OracleEngine))
+    rs = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
+                   gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0), maxneighbors=5)), rng=9,
+                           engine=OracleEngine))
     for rank in (0, 1):
         out = results[rank]
+        assert np.array_equal(out["idw"], np.c_[ri["z"], ri["z_distance"]])
+        assert np.array_equal(out["lwr"], np.c_[rl["z"], rl["z_variance"]])
+        assert np.array_equal(out["sgs"], np.stack(rs["z"]))
         assert np.array_equal(out["krig_mu"], ref["z"]) and np.array_equal(out["krig_var"], ref["z_variance"])
         assert out["local_len"][0] == out["local_len"][1]
         assert np.array_equal(out["fft"], np.stack(f["z"])) and np.array_equal(out["lu"], np.stack(l["z"]))
