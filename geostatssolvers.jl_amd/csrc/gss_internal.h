@@ -175,36 +175,109 @@ __device__ __forceinline__ double metric_dist(int metric, double key, double par
   return key;
 }
 
+// exp and sqrt for the covariance kernels.  The libm versions cost 26 and 19 FP64 instructions; the covariance
+// assembly (K1: 10^9 evaluations per 10^6 points, K5: 2 144 per point) is bound by exactly those.
+//   gss_exp : x = n ln2/64 + r, exp(x) = 2^(n>>6) * T[n&63] * (1 + r + ... + r^5/120); Cody-Waite reduction with a
+//             26-bit high part (n L_HI exact for |x| < 745); 64-entry table of correctly rounded 2^(j/64).
+//             Max relative error 2.2e-16 on 10^6 arguments in [-745, -1e-8] (tools/probe_fastmath.hip).
+//   gss_sqrt: v_rsq_f64 seed + two Goldschmidt steps; bit-identical to libm sqrt on the same sample.
+static __device__ const double GSS_EXP2_TAB[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951,
+};
+
+__device__ __forceinline__ double gss_exp(double x) {
+  x = x < -800.0 ? -800.0 : x;                             // exp underflows to 0 from -745.2 on; keeps n in int range
+  const double n = __builtin_rint(x * 92.33248261689366);  // 64 / ln 2
+  double r = fma(-n, 0.010830424493178725, x);             // ln2/64, 27 trailing bits cleared
+  r = fma(-n, 2.030704202170295e-10, r);                    // ln2/64 - high part
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = p * r;  // exp(r) - 1
+  const int ni = (int)n;
+  const double t = GSS_EXP2_TAB[ni & 63];
+  return __builtin_amdgcn_ldexp(fma(t, p, t), ni >> 6);
+}
+
+// Table-free form for kernels that run few waves per SIMD (K5, SGS weights): a degree-13 polynomial costs four more
+// FMAs than the table lookup but no memory round trip.  Same 2.2e-16 maximum relative error.
+__device__ __forceinline__ double gss_exp_poly(double x) {
+  x = x < -800.0 ? -800.0 : x;
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double gss_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double s = x * y;
+  const double h = 0.5 * y;
+  s = fma(fma(-s, s, x), h, s);
+  s = fma(fma(-s, s, x), h, s);
+  return x > 0.0 ? s : 0.0;
+}
+
 // g(h) = 1 - f(h / range): normalised covariance shape of one structure, from the squared distance (d2 > 0)
 __device__ __forceinline__ double vg_shape(int kind, double d2, double inv_range, double mscale, double pw) {
   switch (kind) {
-    case GSS_VG_GAUSSIAN: return exp(-3.0 * (d2 * inv_range * inv_range));
-    case GSS_VG_EXPONENTIAL: return exp(-3.0 * (sqrt(d2) * inv_range));
+    case GSS_VG_GAUSSIAN: return gss_exp(-3.0 * (d2 * inv_range * inv_range));
+    case GSS_VG_EXPONENTIAL: return gss_exp(-3.0 * (gss_sqrt(d2) * inv_range));
     case GSS_VG_SPHERICAL: {
-      const double x = sqrt(d2) * inv_range;
+      const double x = gss_sqrt(d2) * inv_range;
       return x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
     }
-    case VG_MATERN12: return exp(-(mscale * (sqrt(d2) * inv_range)));
+    case VG_MATERN12: return gss_exp(-(mscale * (gss_sqrt(d2) * inv_range)));
     case VG_MATERN32: {
-      const double d = mscale * (sqrt(d2) * inv_range);
-      return (1.0 + d) * exp(-d);
+      const double d = mscale * (gss_sqrt(d2) * inv_range);
+      return (1.0 + d) * gss_exp(-d);
     }
     case VG_MATERN52: {
-      const double d = mscale * (sqrt(d2) * inv_range);
-      return (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
+      const double d = mscale * (gss_sqrt(d2) * inv_range);
+      return (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp(-d);
     }
     case GSS_VG_CUBIC: {
-      const double x = sqrt(d2) * inv_range;
+      const double x = gss_sqrt(d2) * inv_range;
       const double x2 = x * x, x3 = x2 * x;
       return x < 1.0 ? 1.0 - (7.0 * x2 - 8.75 * x3 + 3.5 * x3 * x2 - 0.75 * x3 * x3 * x) : 0.0;
     }
     case GSS_VG_SINEHOLE: {
-      const double t = 3.14159265358979323846 * (sqrt(d2) * inv_range);
+      const double t = 3.14159265358979323846 * (gss_sqrt(d2) * inv_range);
       return sin(t) / t;
     }
     case GSS_VG_POWER: return 1.0 - mscale * pow(d2, pw);  // pseudo-covariance A - gamma(h), see gss.h
     default: {  // GSS_VG_PENTASPHERICAL
-      const double x = sqrt(d2) * inv_range;
+      const double x = gss_sqrt(d2) * inv_range;
       const double x2 = x * x, x3 = x2 * x;
       return x < 1.0 ? 1.0 - (1.875 * x - 1.25 * x3 + 0.375 * x3 * x2) : 0.0;
     }
@@ -225,6 +298,14 @@ __device__ __forceinline__ double cov_pair(const VgDev& v, const double* a, cons
   return c;
 }
 
+// Out-of-line evaluation of the less common models (spherical family, sine hole, power): sin / pow / long polynomials
+// would otherwise be inlined four times per call site of cov_pair4, and the moving-neighbourhood kernel has eleven
+// such sites -- its code then no longer fits the instruction cache.
+__device__ __attribute__((noinline)) static double vg_shape_call(int kind, double d2, double inv_range, double mscale,
+                                                                 double pw) {
+  return vg_shape(kind, d2, inv_range, mscale, pw);
+}
+
 // Four covariances at once (same arithmetic as cov_pair).  The model switch is taken once and the four
 // evaluations sit in one basic block, so their sqrt / exp dependency chains overlap instead of running one after
 // the other -- what a kernel with few waves per SIMD needs (krig_local.hip).
@@ -236,26 +317,26 @@ __device__ __forceinline__ void vg_shape4(int kind, const double* d2, double inv
     g[u] = (EXPR);                                         \
   }
   switch (kind) {
-    case GSS_VG_GAUSSIAN: GSS_SHAPE4(exp(-3.0 * (q2 * inv_range * inv_range))); break;
-    case GSS_VG_EXPONENTIAL: GSS_SHAPE4(exp(-3.0 * (sqrt(q2) * inv_range))); break;
-    case VG_MATERN12: GSS_SHAPE4(exp(-(mscale * (sqrt(q2) * inv_range)))); break;
+    case GSS_VG_GAUSSIAN: GSS_SHAPE4(gss_exp_poly(-3.0 * (q2 * inv_range * inv_range))); break;
+    case GSS_VG_EXPONENTIAL: GSS_SHAPE4(gss_exp_poly(-3.0 * (gss_sqrt(q2) * inv_range))); break;
+    case VG_MATERN12: GSS_SHAPE4(gss_exp_poly(-(mscale * (gss_sqrt(q2) * inv_range)))); break;
     case VG_MATERN32: {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double d = mscale * (sqrt(d2[u]) * inv_range);
-        g[u] = (1.0 + d) * exp(-d);
+        const double d = mscale * (gss_sqrt(d2[u]) * inv_range);
+        g[u] = (1.0 + d) * gss_exp_poly(-d);
       }
       break;
     }
     case VG_MATERN52: {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double d = mscale * (sqrt(d2[u]) * inv_range);
-        g[u] = (1.0 + d + d * d * (1.0 / 3.0)) * exp(-d);
+        const double d = mscale * (gss_sqrt(d2[u]) * inv_range);
+        g[u] = (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp_poly(-d);
       }
       break;
     }
-    default: GSS_SHAPE4(vg_shape(kind, q2, inv_range, mscale, pw)); break;
+    default: GSS_SHAPE4(vg_shape_call(kind, q2, inv_range, mscale, pw)); break;
   }
 #undef GSS_SHAPE4
 }
