@@ -13,6 +13,7 @@
 // Universal-kriging monomials are taken about the estimation point (the polynomial space is
 // translation invariant), so f0 = (1, 0, ..., 0).
 #include "gss_internal.h"
+#include "tile16.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -282,80 +283,6 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
 // last product G = Y'Y yields every dot product the block elimination needs (|y_c|^2, y_z.y_c, Y_F'Y_F, ...).
 // Rows beyond the neighbour count are padded with the identity.
 // ---------------------------------------------------------------------------------------------
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ d4_t xty(const d4_t& x, const d4_t& y, d4_t acc) {  // acc + X'Y
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s], y[s], acc, 0, 0, 0);
-  return acc;
-}
-
-__device__ __forceinline__ double rl64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// t: symmetric positive definite 16 x 16 tile (tile layout).  Returns V = U^-1 (tile layout, upper triangular) for
-// t = U'U; *bad is set when a pivot is not positive.  S: 16 x 17 doubles of LDS owned by this wave.
-__device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int lane, bool* bad) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
-  __syncthreads();
-  const int i = c;  // lanes 16..63 shadow lanes 0..15
-  double row[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
-  __syncthreads();
-  // lower Cholesky t = L L', right-looking so that the updates of one step are independent of each other; lane i
-  // owns row i (its upper part holds don't-care values); the diagonal keeps 1 / L_jj
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double d = rl64(row[j], j);
-    if (!(d > 0.0)) {
-      *bad = true;
-      d = 1.0;
-    }
-    double y = __builtin_amdgcn_rsq(d);  // refined to full precision by two Newton steps
-    const double h = 0.5 * d;
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    row[j] = (i == j) ? y : row[j] * y;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) row[q] = fma(-row[j], rl64(row[j], q), row[q]);
-    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of later columns from being hoisted (SGPR pressure)
-  }
-  // W = L^-1 in place (unblocked trtri, last column first): lane i ends up with row i of W.  Column j of W is
-  // -W22 * L[j+1.., j] / L_jj with W22 the already inverted trailing block, whose row i is in lane i's registers.
-#pragma unroll
-  for (int q = 1; q < 16; ++q)
-    if (q > i) row[q] = 0.0;  // clear the don't-care upper part: W is lower triangular
-#pragma unroll
-  for (int j = 15; j >= 0; --j) {
-    const double dinv = rl64(row[j], j);  // 1 / L_jj (kept on the diagonal by the factorisation)
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) {
-      const double lqj = rl64(row[j], q);  // L[q][j]
-      if ((q - j) & 1) a0 = fma(row[q], lqj, a0);
-      else a1 = fma(row[q], lqj, a1);
-    }
-    row[j] = (i == j) ? dinv : (i > j ? -(a0 + a1) * dinv : 0.0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // V = W' back to tile layout: V[a][b] = W[b][a], lane b writes column b
-#pragma unroll
-  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
-  __syncthreads();
-  d4_t v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = S[(g + 4 * r) * 17 + c];
-  __syncthreads();
-  return v;
-}
-
-constexpr int tile_id(int i, int j) { return i * 4 - (i * (i - 1)) / 2 + (j - i); }  // upper block triangle, i <= j
 
 template <int DIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
