@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void potrf_inv_leaf_kernel(double* __restrict__
 // 22 us instead of 51 us for the register/readlane leaf above (kept for A/B: GSS_LEAF_VARIANT=0).
 __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restrict__ A, int n, int64_t lda,
                                                                  int row_offset, int* __restrict__ info,
-                                                                 double* __restrict__ dinv) {
+                                                                 double* __restrict__ dinv, int64_t ldd, int full64) {
   __shared__ double S[16 * 17];
   __shared__ double S2[16 * 17];
   const int lane = threadIdx.x;
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restr
       Wt[tile_id(I, J)] = w;
     }
   }
-  // dinv is 64 x 64 column-major, zero outside the n x n block and above the diagonal
+  // dinv (column-major, leading dimension ldd): zero above the diagonal; full64: the whole 64 x 64 block is written
+  // (zero outside n x n), otherwise only the n x n block
 #pragma unroll
   for (int I = 0; I < 4; ++I)
 #pragma unroll
@@ -430,9 +431,10 @@ __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int wrow = 16 * J + g + 4 * r, wcol = 16 * I + c;
+        const bool inside = wrow < n && wcol < n;
         double v = 0.0;
-        if (J >= I && wrow < n && wcol < n) v = Wt[tile_id(I, J >= I ? J : I)][r];
-        dinv[wrow + wcol * LEAF] = v;
+        if (J >= I && inside) v = Wt[tile_id(I, J >= I ? J : I)][r];
+        if (full64 || inside) dinv[wrow + (int64_t)wcol * ldd] = v;
       }
 }
 
@@ -534,7 +536,7 @@ static int32_t potrf_rec(double* A, int64_t n, int64_t lda, int64_t row_offset, 
     }
     if (leaf_variant == 1)
       hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info,
-                         dinv);
+                         dinv, (int64_t)LEAF, 1);
     else
       hipLaunchKernelGGL(potrf_inv_leaf_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, dinv);
     GSS_HIP(hipGetLastError());
@@ -558,6 +560,42 @@ int64_t potrf_dinv_doubles(int64_t n) { return ((n + LEAF - 1) / LEAF) * LEAF * 
 int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
   return potrf_rec(A, n, lda, 0, d_info, dinv, s);
+}
+
+// Cholesky factor and its inverse in one recursion: the inverse of the leading block turns the panel solve into one
+// GEMM, so an internal node costs four GEMMs (L21 = A21 W11', A22 -= L21 L21', T = L21 W11, W21 = -W22 T) instead of the
+// ~9 launches of separate potrf / trsm / trtri recursions.  W (n x n, ldw, strict upper triangle zero on entry)
+// receives inv(L); A is destroyed (only its diagonal leaf blocks end up holding L).  scr: n * n doubles.
+static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw, int64_t n, int64_t row_offset,
+                                 int* d_info, double* scr, hipStream_t s) {
+  if (n <= 0) return GSS_OK;
+  if (n <= LEAF) {
+    hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, W,
+                       ldw, 0);
+    GSS_HIP(hipGetLastError());
+    return GSS_OK;
+  }
+  const int64_t n1 = split_point(n), n2 = n - n1;
+  double* A21 = A + n1;
+  double* A22 = A + n1 + n1 * lda;
+  double* W21 = W + n1;
+  double* W22 = W + n1 + n1 * ldw;
+  GSS_TRY(potrf_inverse_rec(A, lda, W, ldw, n1, row_offset, d_info, scr, s));
+  double* L21 = scr;            // n2 x n1, column-major, ld n2
+  double* T2 = scr + n1 * n2;   // n2 x n1
+  double* rest = T2 + n1 * n2;
+  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, A21, 1, lda, W, ldw, 1, 0.0, L21, 1, n2, false, s));
+  GSS_TRY(gemm_f64(n2, n2, n1, -1.0, L21, 1, n2, L21, n2, 1, 1.0, A22, 1, lda, true, s));
+  GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, s));
+  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, n2, W, 1, ldw, 0.0, T2, 1, n2, false, s));
+  GSS_TRY(gemm_f64(n2, n1, n2, -1.0, W22, 1, ldw, T2, 1, n2, 0.0, W21, 1, ldw, false, s));
+  return GSS_OK;
+}
+
+int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,
+                          hipStream_t s) {
+  GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
+  return potrf_inverse_rec(A, lda, W, ldw, n, 0, d_info, scr, s);
 }
 
 }  // namespace gss

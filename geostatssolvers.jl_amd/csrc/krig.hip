@@ -503,10 +503,9 @@ struct FitPlan {
 
 static int32_t krig_fit_plan(gss_krig* h, FitPlan* fp) {
   const int64_t n = h->n, N1pad = h->N1pad, ldw = h->ldw;
-  const int64_t hh = n / 2 + 64;
   const int64_t szM = ldw * N1pad;
-  const int64_t szT = hh * hh > (int64_t)MAX_NC * n ? hh * hh : (int64_t)MAX_NC * n;
-  const int64_t szDinv = potrf_dinv_doubles(n) + 64 * 64;
+  const int64_t szT = n * n > (int64_t)MAX_NC * n ? n * n : (int64_t)MAX_NC * n;  // potrf_inverse_f64 scratch
+  const int64_t szDinv = 64 * 64;  // scratch of the constraint-block leaf
   const int64_t szFd = (int64_t)MAX_NC * n, szBm = (int64_t)MAX_NC * n;
   const int64_t szS = 2 * MAX_NC * MAX_NC + 64 * 64;
   int64_t szGemv = gemv_work_doubles(false, ldw, ldw);
@@ -535,7 +534,7 @@ static int32_t krig_fit_plan(gss_krig* h, FitPlan* fp) {
 static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
   const int64_t n = h->n, N1 = h->N1, ldw = h->ldw;
   const int nc = h->nc;
-  double *M = fp.M, *T = fp.T, *Dinv = fp.Dinv, *Fd = fp.Fd, *Bm = fp.Bm, *S = fp.S, *SDinv = fp.SDinv;
+  double *M = fp.M, *T = fp.T, *Fd = fp.Fd, *Bm = fp.Bm, *S = fp.S, *SDinv = fp.SDinv;
   double *gwork = fp.gwork, *zz = fp.zz, *u = fp.u;
   int *info = fp.info, *info2 = fp.info2;
   const int64_t szM = fp.szM, szS = fp.szS;
@@ -543,9 +542,8 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(h->factor.p, h->factor.bytes, s));
   GSS_TRY(dev_zero_bytes(info2, sizeof(int), s));
   GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M, ldw, s));
-  GSS_TRY(potrf_f64(M, n, ldw, info, Dinv, s));
   double* Wp = h->Wp();
-  GSS_TRY(trtri_f64(M, n, ldw, Wp, ldw, T, Dinv, s));
+  GSS_TRY(potrf_inverse_f64(M, n, ldw, Wp, ldw, T, info, s));
 
   if (nc > 0) {
     GSS_TRY(dev_zero_bytes(S, sizeof(double) * (size_t)szS, s));
@@ -555,13 +553,12 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
     for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(false, n, n, Wp, ldw, Fd + (int64_t)c * n, Bm + (int64_t)c * n, gwork, s));
     hipLaunchKernelGGL(small_gram_kernel, dim3(nc, nc), dim3(64), 0, s, Bm, nc, n, S, MAX_NC);
     GSS_HIP(hipGetLastError());
-    GSS_TRY(potrf_f64(S, nc, MAX_NC, info2, SDinv, s));
-    // W'[n:, n:] = inv(L_S)
-    GSS_TRY(trtri_f64(S, nc, MAX_NC, Wp + n + n * ldw, ldw, T, SDinv, s));
+    // W'[n:, n:] = inv(L_S)  (nc <= 64: one leaf)
+    GSS_TRY(potrf_inverse_f64(S, nc, MAX_NC, Wp + n + n * ldw, ldw, SDinv, info2, s));
     // T[c] = W' Bm[c]  (row c of B W)
     for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(true, n, n, Wp, ldw, Bm + (int64_t)c * n, T + (int64_t)c * n, gwork, s));
     // W'[n:, 0:n] = -inv(L_S) * T
-    hipLaunchKernelGGL(constraint_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, SDinv, (int64_t)64, T,
+    hipLaunchKernelGGL(constraint_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wp + n + n * ldw, ldw, T,
                        nc, n, Wp + n, ldw);
     GSS_HIP(hipGetLastError());
   }
