@@ -566,8 +566,25 @@ int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, 
 // GEMM, so an internal node costs four GEMMs (L21 = A21 W11', A22 -= L21 L21', T = L21 W11, W21 = -W22 T) instead of the
 // ~9 launches of separate potrf / trsm / trtri recursions.  W (n x n, ldw, strict upper triangle zero on entry)
 // receives inv(L); A is destroyed (only its diagonal leaf blocks end up holding L).  scr: n * n doubles.
+// dst (m x n, ldd) <- src (m x n, lds), column-major
+__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ src, int64_t lds, int64_t m,
+                                                         int64_t n, double* __restrict__ dst, int64_t ldd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = blockIdx.y;
+  if (i < m && j < n) dst[i + j * ldd] = src[i + j * lds];
+}
+
+static int32_t copy_block(const double* src, int64_t lds, int64_t m, int64_t n, double* dst, int64_t ldd,
+                          hipStream_t s) {
+  if (m <= 0 || n <= 0) return GSS_OK;
+  hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)n), dim3(256), 0, s, src, lds, m, n,
+                     dst, ldd);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
 static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw, int64_t n, int64_t row_offset,
-                                 int* d_info, double* scr, hipStream_t s) {
+                                 int* d_info, double* scr, bool keep_L, hipStream_t s) {
   if (n <= 0) return GSS_OK;
   if (n <= LEAF) {
     hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, W,
@@ -580,22 +597,57 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
   double* A22 = A + n1 + n1 * lda;
   double* W21 = W + n1;
   double* W22 = W + n1 + n1 * ldw;
-  GSS_TRY(potrf_inverse_rec(A, lda, W, ldw, n1, row_offset, d_info, scr, s));
+  GSS_TRY(potrf_inverse_rec(A, lda, W, ldw, n1, row_offset, d_info, scr, keep_L, s));
   double* L21 = scr;            // n2 x n1, column-major, ld n2
   double* T2 = scr + n1 * n2;   // n2 x n1
   double* rest = T2 + n1 * n2;
   GSS_TRY(gemm_f64(n2, n1, n1, 1.0, A21, 1, lda, W, ldw, 1, 0.0, L21, 1, n2, false, s));
+  if (keep_L) GSS_TRY(copy_block(L21, n2, n2, n1, A21, lda, s));
   GSS_TRY(gemm_f64(n2, n2, n1, -1.0, L21, 1, n2, L21, n2, 1, 1.0, A22, 1, lda, true, s));
-  GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, s));
+  GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, keep_L, s));
   GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, n2, W, 1, ldw, 0.0, T2, 1, n2, false, s));
   GSS_TRY(gemm_f64(n2, n1, n2, -1.0, W22, 1, ldw, T2, 1, n2, 0.0, W21, 1, ldw, false, s));
   return GSS_OK;
 }
 
 int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,
-                          hipStream_t s) {
+                          bool keep_L, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
-  return potrf_inverse_rec(A, lda, W, ldw, n, 0, d_info, scr, s);
+  return potrf_inverse_rec(A, lda, W, ldw, n, 0, d_info, scr, keep_L, s);
+}
+
+// Right-looking Cholesky by panels of POTRF_PANEL columns for large blocks whose inverse is not wanted (LUGS): the
+// diagonal block of a panel is factorised together with its inverse (potrf_inverse_rec), which makes the rows below
+// one GEMM (L_ik = A_ik W_kk'), followed by one trailing update per panel.  About 95 launches per panel instead of
+// ~370 with the fully recursive potrf_f64.  A holds L in its lower triangle on return.
+constexpr int64_t POTRF_PANEL = 1024;
+
+int64_t potrf_blocked_work_doubles(int64_t n) {
+  const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
+  return 2 * B * B + n * B;
+}
+
+int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s) {
+  GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
+  const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
+  double* Wk = work;           // B x B inverse of the diagonal block
+  double* scr = Wk + B * B;    // B x B scratch of the recursion
+  double* P = scr + B * B;     // (n - k0 - nb) x nb panel
+  for (int64_t k0 = 0; k0 < n; k0 += B) {
+    const int64_t nb = (n - k0) < B ? (n - k0) : B;
+    const int64_t m2 = n - k0 - nb;
+    double* Akk = A + k0 + k0 * lda;
+    GSS_TRY(dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s));
+    GSS_TRY(potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s));
+    if (m2 > 0) {
+      double* Ap = Akk + nb;                 // rows below the diagonal block
+      double* A22 = Akk + nb + nb * lda;
+      GSS_TRY(gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s));
+      GSS_TRY(copy_block(P, m2, m2, nb, Ap, lda, s));
+      GSS_TRY(gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s));
+    }
+  }
+  return GSS_OK;
 }
 
 }  // namespace gss

@@ -379,10 +379,14 @@ int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda,
 // Asynchronous on s.
 int64_t potrf_dinv_doubles(int64_t n);
 int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s);
-// Factor and inverse together (A = L L', W = inv(L)); A is destroyed, W's strict upper triangle must be zero on
-// entry, scr holds n * n doubles.  *d_info as potrf_f64.  Asynchronous on s.
+// Factor and inverse together (A = L L', W = inv(L)); W's strict upper triangle must be zero on entry, scr holds
+// n * n doubles.  *d_info as potrf_f64.  Asynchronous on s.
+// keep_L: also leave the complete factor L in the lower triangle of A (otherwise only its diagonal leaf blocks).
 int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,
-                          hipStream_t s);
+                          bool keep_L, hipStream_t s);
+// Cholesky of a large block without its inverse, by panels (work: potrf_blocked_work_doubles(n) doubles).
+int64_t potrf_blocked_work_doubles(int64_t n);
+int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s);
 // W = inv(L), lower, column-major; W's strict upper triangle must be zero on entry; T is scratch of
 // at least (n/2+64)^2 doubles; dinv (nullable) = cached leaf inverses from potrf_f64
 int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, const double* dinv,

@@ -543,7 +543,7 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(info2, sizeof(int), s));
   GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M, ldw, s));
   double* Wp = h->Wp();
-  GSS_TRY(potrf_inverse_f64(M, n, ldw, Wp, ldw, T, info, s));
+  GSS_TRY(potrf_inverse_f64(M, n, ldw, Wp, ldw, T, info, false, s));
 
   if (nc > 0) {
     GSS_TRY(dev_zero_bytes(S, sizeof(double) * (size_t)szS, s));
@@ -554,7 +554,7 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
     hipLaunchKernelGGL(small_gram_kernel, dim3(nc, nc), dim3(64), 0, s, Bm, nc, n, S, MAX_NC);
     GSS_HIP(hipGetLastError());
     // W'[n:, n:] = inv(L_S)  (nc <= 64: one leaf)
-    GSS_TRY(potrf_inverse_f64(S, nc, MAX_NC, Wp + n + n * ldw, ldw, SDinv, info2, s));
+    GSS_TRY(potrf_inverse_f64(S, nc, MAX_NC, Wp + n + n * ldw, ldw, SDinv, info2, false, s));
     // T[c] = W' Bm[c]  (row c of B W)
     for (int c = 0; c < nc; ++c) GSS_TRY(gemv_f64(true, n, n, Wp, ldw, Bm + (int64_t)c * n, T + (int64_t)c * n, gwork, s));
     // W'[n:, 0:n] = -inv(L_S) * T

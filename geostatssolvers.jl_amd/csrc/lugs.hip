@@ -4,10 +4,10 @@
 // (lu.jl:171-196) and passes w1 back in for the second variable.
 //
 //   lu.jl:124      C22 = sill - pairwise(g, Ds)                   cov_pairwise (K1)
-//   lu.jl:128      L22 = cholesky(C22).L          (unconditional)  potrf_f64 (FP64 MFMA GEMM recursion)
+//   lu.jl:128      L22 = cholesky(C22).L          (unconditional)  potrf_blocked_f64 (panels of 1024, FP64 MFMA GEMMs)
 //   lu.jl:131-132  C11, C12
 //   lu.jl:134      L11 = cholesky(C11).L
-//   lu.jl:135      B12 = L11 \ C12     -> stored transposed: A21 = C21 * inv(L11)'   (trsm_right_lt_f64)
+//   lu.jl:135      B12 = L11 \ C12     -> stored transposed: A21 = C21 * inv(L11)'   (one GEMM with W11 = inv(L11))
 //   lu.jl:136-138  d2  = A21 * (L11 \ z1)
 //   lu.jl:139      L22 = cholesky(C22 - A21 * B12).L               (lower-tile SYRK + potrf)
 //   lu.jl:209-213  y2  = d2 + L22 * w          for all realisations at once: one GEMM L22 * W
@@ -144,29 +144,37 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
     double* C22 = h->L22();
     GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
     if (nd > 0) {
-      DevBuf C11, A21, w, dinv, gwork;
+      DevBuf C11, W11, C21, A21, w, scr, gwork;
       GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
+      GSS_TRY(W11.alloc(sizeof(double) * (size_t)(nd * nd)));
+      GSS_TRY(scr.alloc(sizeof(double) * (size_t)(nd * nd)));
+      GSS_TRY(C21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(A21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));
-      GSS_TRY(dinv.alloc(sizeof(double) * (size_t)potrf_dinv_doubles(nd)));
-      GSS_TRY(gwork.alloc(sizeof(double) * (size_t)gemv_work_doubles(false, ns, nd)));
+      int64_t gw = gemv_work_doubles(false, ns, nd);
+      if (gemv_work_doubles(false, nd, nd) > gw) gw = gemv_work_doubles(false, nd, nd);
+      GSS_TRY(gwork.alloc(sizeof(double) * (size_t)gw));
       GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxd.as<double>(), nd, C11.as<double>(), nd, s));  // :131
-      // row-major nd x ns == column-major ns x nd: A21 <- C21                                             // :132
-      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, A21.as<double>(), ns, s));
-      GSS_TRY(potrf_f64(C11.as<double>(), nd, nd, info.as<int>(), dinv.as<double>(), s));                  // :134
+      // row-major nd x ns == column-major ns x nd: C21                                                    // :132
+      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, C21.as<double>(), ns, s));
+      // L11 and W11 = inv(L11) together (lu.jl:134): the two solves below become products with W11
+      GSS_TRY(dev_zero_bytes(W11.p, W11.bytes, s));
+      GSS_TRY(potrf_inverse_f64(C11.as<double>(), nd, nd, W11.as<double>(), nd, scr.as<double>(), info.as<int>(), false,
+                                s));
       GSS_TRY(check_info(info, "data covariance C11", s));
-      GSS_TRY(trsm_right_lt_f64(A21.as<double>(), ns, nd, ns, C11.as<double>(), nd, nullptr, dinv.as<double>(), s));  // :135
-      // w' = z1' * inv(L11)'  i.e. w = L11 \ z1                                                           // :138
-      GSS_HIP(hipMemcpyAsync(w.p, h->z1.p, sizeof(double) * (size_t)nd, hipMemcpyDeviceToDevice, s));
-      GSS_TRY(trsm_right_lt_f64(w.as<double>(), 1, nd, 1, C11.as<double>(), nd, nullptr, dinv.as<double>(), s));
-      GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), gwork.as<double>(), s));  // :138
+      // A21 = C21 * inv(L11)'  (= B12', lu.jl:135)
+      GSS_TRY(gemm_f64(ns, nd, nd, 1.0, C21.as<double>(), 1, ns, W11.as<double>(), nd, 1, 0.0, A21.as<double>(), 1, ns,
+                       false, s));
+      // w = L11 \ z1 = W11 z1,  d2 = A21 w                                                               // :138
+      GSS_TRY(gemv_f64(false, nd, nd, W11.as<double>(), nd, h->z1.as<double>(), w.as<double>(), gwork.as<double>(), s));
+      GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), gwork.as<double>(), s));
       // C22 -= A21 * A21'  (lower tiles)                                                                  // :139
       GSS_TRY(gemm_f64(ns, ns, nd, -1.0, A21.as<double>(), 1, ns, A21.as<double>(), ns, 1, 1.0, C22, 1, ns, true, s));
       GSS_HIP(hipStreamSynchronize(s));
     }
-    DevBuf dinv22;
-    GSS_TRY(dinv22.alloc(sizeof(double) * (size_t)potrf_dinv_doubles(ns)));
-    GSS_TRY(potrf_f64(C22, ns, ns, info.as<int>(), dinv22.as<double>(), s));                                // :128/:139
+    DevBuf work22;
+    GSS_TRY(work22.alloc(sizeof(double) * (size_t)potrf_blocked_work_doubles(ns)));
+    GSS_TRY(potrf_blocked_f64(C22, ns, ns, info.as<int>(), work22.as<double>(), s));                        // :128/:139
     GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22", s));
     hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)ns), dim3(256), 0, s, C22, ns,
                        ns);
