@@ -27,6 +27,8 @@ struct GemmArgs {
   double* D;
   int64_t sd_i, sd_j;
   int lower_only;
+  int vec;  // both operands contiguous along their tile edge, 16-byte aligned, K a multiple of BK: interior tiles may
+            // stage with 16-byte loads
 };
 
 // Register-staged, LDS double-buffered pipeline (one barrier per BK stage), bounds-checked scalar loads that
@@ -78,7 +80,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
     }
   }
   double ra[G::NLOAD], rb[G::NLOAD];
+  // interior tiles of aligned, edge-contiguous operands: 16-byte loads without bounds checks (K3's staging map:
+  // thread = 2 consecutive elements of k-row kq + RPP * pass); everything else: bounds-checked scalar loads
+  constexpr int RPP = 512 / T;  // k-rows covered per pass of the 256 threads
+  const bool fastp = A_ICONTIG && B_JCONTIG && g.vec && (i0 + T <= g.M) && (j0 + T <= g.N);
+  const int e2 = (tid % (T / 2)) * 2, kq = tid / (T / 2);
   auto load_stage = [&](int64_t k0) {
+    if (fastp) {
+#pragma unroll
+      for (int r = 0; r < G::NLOAD / 2; ++r) {
+        const int64_t kr = k0 + kq + RPP * r;
+        const d2v va = *reinterpret_cast<const d2v*>(g.A + (i0 + e2) + kr * g.sa_k);
+        const d2v vb = *reinterpret_cast<const d2v*>(g.B + kr * g.sb_k + (j0 + e2));
+        ra[2 * r] = va.x;
+        ra[2 * r + 1] = va.y;
+        rb[2 * r] = vb.x;
+        rb[2 * r + 1] = vb.y;
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < G::NLOAD; ++r) {
       const int64_t gi = i0 + ai[r], gka = k0 + ak[r];
@@ -90,6 +110,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
   auto store_stage = [&](int buf) {
     double* a = As + buf * G::STAGE;
     double* b = Bs + buf * G::STAGE;
+    if (fastp) {
+#pragma unroll
+      for (int r = 0; r < G::NLOAD / 2; ++r) {
+        *reinterpret_cast<d2v*>(a + (kq + RPP * r) * G::LD + e2) = d2v{ra[2 * r], ra[2 * r + 1]};
+        *reinterpret_cast<d2v*>(b + (kq + RPP * r) * G::LD + e2) = d2v{rb[2 * r], rb[2 * r + 1]};
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < G::NLOAD; ++r) {
       a[ak[r] * G::LD + ai[r]] = ra[r];
@@ -178,7 +206,11 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                  const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
                  int64_t sd_j, bool lower_only, hipStream_t s) {
   if (M <= 0 || N <= 0) return GSS_OK;
-  GemmArgs g{M, N, K, alpha, beta, A, sa_i, sa_k, B, sb_k, sb_j, D, sd_i, sd_j, lower_only ? 1 : 0};
+  GemmArgs g{M, N, K, alpha, beta, A, sa_i, sa_k, B, sb_k, sb_j, D, sd_i, sd_j, lower_only ? 1 : 0, 0};
+  g.vec = (sa_i == 1 && sb_j == 1 && K % BK == 0 && sa_k % 2 == 0 && sb_k % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0)
+              ? 1
+              : 0;
   const bool ai = (sa_i == 1) || (sa_k != 1);
   const bool bj = (sb_j == 1) || (sb_k != 1);
   // 128-tiles only when they can fill at least half of the 256 CUs; otherwise 64-tiles (4x the workgroups)
