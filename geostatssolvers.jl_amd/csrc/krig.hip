@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const int i0 = I * BM;
     const int kend = (i0 + BM < N1pad) ? i0 + BM : N1pad;
     const int ntile = kend / BK;
+    // rows i0 .. N1 of this block carry data (row N1 = dual weights); 16-row tiles beyond them are zero padding
+    const int tm_max = (N1 + 1 - i0 + 15) / 16 < 8 ? (N1 + 1 - i0 + 15) / 16 : 8;
 
     d4 acc[4][4];
     d4 accw[8][2];
@@ -186,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
       }
       if (W14) {
         // stages inside the diagonal block (k > i0) only touch row tiles tm >= (k - i0) / 16
-        mma_stage_w14<GUARD>(As + cur * TILE_LDS, Bs + cur * TILE_LDS, accw, wave, lane, (t * BK - i0) >> 4);
+        const int tmn = (t * BK - i0) >> 4;
+        mma_stage_w14<GUARD>(As + cur * TILE_LDS, Bs + cur * TILE_LDS, accw, wave, lane, tmn > 0 ? tmn : 0, tm_max);
       } else {
         mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
       }
@@ -203,8 +206,12 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     };
     if (W14) {
       const int tdiag = (i0 / BK + 1) < ntile ? (i0 / BK + 1) : ntile;
-      for (int t = 0; t < tdiag; ++t) stage(t, std::false_type{});
-      for (int t = tdiag; t < ntile; ++t) stage(t, std::true_type{});
+      if (tm_max < 8) {  // last row block: its bottom row tiles are padding, every stage is guarded
+        for (int t = 0; t < ntile; ++t) stage(t, std::true_type{});
+      } else {
+        for (int t = 0; t < tdiag; ++t) stage(t, std::false_type{});
+        for (int t = tdiag; t < ntile; ++t) stage(t, std::true_type{});
+      }
     } else {
       for (int t = 0; t < ntile; ++t) stage(t, std::false_type{});
     }

@@ -52,9 +52,10 @@ __device__ __forceinline__ void mma_stage(const double* __restrict__ As, const d
 // Measured alternative, kept out of the build: the 4-block form v_mfma_f64_4x4x4_4b_f64 (lane maps
 // A = 16k + 4b + i, B = 16k + 4b + j, D = 16i + 4b + j, tools/probe_mfma4x4.hip) runs this kernel at the same
 // rate as the 16x16x4 form although it is 1.5x faster in a register-only loop (tools/probe_f64.hip).
+// tm_max < 8: row tiles tm >= tm_max lie entirely in the zero padding below the last row of the operand.
 template <bool GUARD>
 __device__ __forceinline__ void mma_stage_w14(const double* __restrict__ As, const double* __restrict__ Bs,
-                                              d4 (&acc)[8][2], int wave, int lane, int tm_min) {
+                                              d4 (&acc)[8][2], int wave, int lane, int tm_min, int tm_max = 8) {
   const int lr = lane & 15;
   const int lk = lane >> 4;
 #pragma unroll
@@ -67,7 +68,7 @@ __device__ __forceinline__ void mma_stage_w14(const double* __restrict__ As, con
     for (int tm = 0; tm < 8; ++tm) a[tm] = ap[tm * 16];
 #pragma unroll
     for (int tm = 0; tm < 8; ++tm) {
-      if (!GUARD || tm >= tm_min) {
+      if (!GUARD || (tm >= tm_min && tm < tm_max)) {
         acc[tm][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b0, acc[tm][0], 0, 0, 0);
         acc[tm][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b1, acc[tm][1], 0, 0, 0);
       }
