@@ -341,6 +341,33 @@ __device__ __forceinline__ void vg_shape4(int kind, const double* d2, double inv
 #undef GSS_SHAPE4
 }
 
+// Single-structure models fixed at compile time (KIND = device kind): the moving-neighbourhood kernel is instantiated
+// per model so that each of its covariance call sites carries one formula instead of all of them (instruction cache).
+template <int KIND>
+__device__ __forceinline__ double vg_shape_k(double d2, double inv_range, double mscale, double pw) {
+  if (KIND == GSS_VG_GAUSSIAN) return gss_exp_poly(-3.0 * (d2 * inv_range * inv_range));
+  if (KIND == GSS_VG_EXPONENTIAL) return gss_exp_poly(-3.0 * (gss_sqrt(d2) * inv_range));
+  if (KIND == VG_MATERN12) return gss_exp_poly(-(mscale * (gss_sqrt(d2) * inv_range)));
+  if (KIND == VG_MATERN32) {
+    const double d = mscale * (gss_sqrt(d2) * inv_range);
+    return (1.0 + d) * gss_exp_poly(-d);
+  }
+  if (KIND == VG_MATERN52) {
+    const double d = mscale * (gss_sqrt(d2) * inv_range);
+    return (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp_poly(-d);
+  }
+  if (KIND == GSS_VG_SPHERICAL) {
+    const double x = gss_sqrt(d2) * inv_range;
+    return x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
+  }
+  return vg_shape(KIND, d2, inv_range, mscale, pw);
+}
+
+template <int DIM, int KIND>
+__device__ __forceinline__ double cov_pair_k(const VgDev& v, const double* a, const double* b);
+template <int DIM, int KIND>
+__device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DIM], const double* b, double* out);
+
 // out[u] = C(a_u, b) for four points a_u and one point b
 template <int DIM>
 __device__ __forceinline__ void cov_pair4(const VgDev& v, const double (*a)[DIM], const double* b, double* out) {
@@ -361,6 +388,31 @@ __device__ __forceinline__ void cov_pair4(const VgDev& v, const double (*a)[DIM]
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) out[u] = d2[u] <= 0.0 ? v.sill : c[u];
+}
+
+// KIND < 0: any model (the general functions above); otherwise one structure of device kind KIND, v.nextra == 0
+template <int DIM, int KIND>
+__device__ __forceinline__ double cov_pair_k(const VgDev& v, const double* a, const double* b) {
+  if (KIND < 0) return cov_pair<DIM>(v, a, b);
+  const double d2 = sqdist_nofma<DIM>(a, b, v.ir, v.aniso != 0);
+  const double g = vg_shape_k<(KIND < 0 ? 0 : KIND)>(d2, v.inv_range, v.mscale, v.pw);
+  return d2 <= 0.0 ? v.sill : v.cs * g;
+}
+
+template <int DIM, int KIND>
+__device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DIM], const double* b, double* out) {
+  if (KIND < 0) {
+    cov_pair4<DIM>(v, a, b, out);
+    return;
+  }
+  double d2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) d2[u] = sqdist_nofma<DIM>(a[u], b, v.ir, v.aniso != 0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const double g = vg_shape_k<(KIND < 0 ? 0 : KIND)>(d2[u], v.inv_range, v.mscale, v.pw);
+    out[u] = d2[u] <= 0.0 ? v.sill : v.cs * g;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
