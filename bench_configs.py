@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs] [--quick]
+    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs,est_all] [--quick]
 """
 import argparse
 import json
@@ -194,6 +194,37 @@ def _est(a, gss, _lib, which):
                              "sample": "oracle.idw_lwr.%s, %d points in %.1f s" % (which, ns, cdt)}}
 
 
+def cfg_est_all(a, gss, _lib):
+    """Section 8f.3, the reference's DEFAULT configuration (maxneighbors = nothing, idw.jl:93): every sample is a
+    neighbour of every point -- no search, est_all_kernel sweeps the samples from LDS.  5 000 samples, 1.25e6 points."""
+    from gss.engine import HipEngine
+    n = 5000
+    m = 100_000 if a.quick else 1_250_000
+    x = np.random.default_rng(16).uniform(0, 100, (n, 3))
+    z = np.sin(x[:, 0] / 9.0) + 0.01 * x[:, 1]
+    x0 = np.random.default_rng(17).uniform(0, 100, (m, 3))
+    xd, zd, x0d = (torch.as_tensor(v, device="cuda") for v in (x, z, x0))
+    out = {}
+    for which, run in (("idw", lambda q: HipEngine.idw(xd, zd, q, n, 1, 1.0)), ("lwr", lambda q: HipEngine.lwr(xd, zd, q, n))):
+        run(x0d[:20000])
+        sync()
+        _lib.profile_reset(); _lib.profile_enable(True)
+        t0 = time.perf_counter()
+        mu, aux, st = run(x0d)
+        sync()
+        dt = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        out[which] = {"points_per_s": round(m / dt, 1), "kernel_ms": round(_lib.profile_read(which)[0], 2),
+                      "pairs_per_s": round(n * m / dt, 1)}
+    from oracle import idw_lwr as E
+    ns = 200
+    r = E.idw(x, z, x0[:ns])
+    err = float(np.max(np.abs(mu[:ns].cpu().numpy() - E.lwr(x, z, x0[:ns])[0])))
+    return {"config": "8f.3 IDW / LWR with all %d samples per point (reference default), %d points" % (n, m),
+            "metric": "estimated points/s", "value": out["idw"]["points_per_s"], "unit": "points/s", "idw": out["idw"],
+            "lwr": out["lwr"], "lwr_parity_max_abs_err_first_%d" % ns: err}
+
+
 def cfg_idw(a, gss, _lib):
     return _est(a, gss, _lib, "idw")
 
@@ -264,7 +295,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs}
+    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -49,7 +49,7 @@ __device__ __forceinline__ double lwr_weight(int kind, double a, double p, doubl
     return t * t * t;
   }
   const double hp = (p == 2.0) ? h * h : (p == 1.0 ? h : pow(h, p));
-  return exp(-a * hp);
+  return gss_exp(-a * hp);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -269,6 +269,46 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
     for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
     for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
     __syncthreads();
+    if (sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && (sp.exponent == 1.0 || sp.exponent == 2.0)) {
+      // the reference's default (all samples, exponent 1) and its square: branch-free, 1 / d from v_rsq_f64 and
+      // 1 / d^2 from v_rcp_f64 (two Newton steps each), four samples in flight
+      const bool e1 = sp.exponent == 1.0;
+#pragma unroll 4
+      for (int j = 0; j < tn; ++j) {
+        const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+        const bool in = !use_ball || d2 <= r2;
+        const bool zero = in && d2 == 0.0;
+        cnt += in ? 1 : 0;
+        dmin2 = (in && d2 < dmin2) ? d2 : dmin2;
+        zzero = (zero && !haszero) ? sz[j] : zzero;
+        haszero = haszero || zero;
+        double y;
+        if (e1) {
+          y = __builtin_amdgcn_rsq(d2);
+          const double hh = 0.5 * d2;
+          y = fma(y, fma(-hh * y, y, 0.5), y);
+          y = fma(y, fma(-hh * y, y, 0.5), y);
+        } else {
+          y = __builtin_amdgcn_rcp(d2);
+          y = fma(y, fma(-d2, y, 1.0), y);
+          y = fma(y, fma(-d2, y, 1.0), y);
+        }
+        const double w = (in && !zero) ? y : 0.0;
+        sw += w;
+        swz = fma(w, sz[j], swz);
+      }
+      continue;
+    }
+    if (sp.method == 1 && sp.metric == GSS_METRIC_EUCLIDEAN) {  // LWR, first sweep: farthest neighbour and count
+#pragma unroll 4
+      for (int j = 0; j < tn; ++j) {
+        const double d2 = sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0);
+        const bool in = !use_ball || d2 <= r2;
+        cnt += in ? 1 : 0;
+        dmax2 = (in && d2 > dmax2) ? d2 : dmax2;
+      }
+      continue;
+    }
     for (int j = 0; j < tn; ++j) {
       const double d2 = est_key<DIM>(sp.metric, &sx[j * DIM], qc, ir, aniso != 0);
       if (use_ball && !(d2 <= r2)) continue;
@@ -319,10 +359,17 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
     for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
     for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
     __syncthreads();
+    const bool euclid = sp.metric == GSS_METRIC_EUCLIDEAN;
+    const bool gauss_w = sp.wkind == GSS_WEIGHT_EXP && sp.wp == 2.0;  // exp(-a delta^2): no square root needed
+    const double inv_dmax2 = 1.0 / dmax2;
     for (int j = 0; j < tn; ++j) {
-      const double d2 = est_key<DIM>(sp.metric, &sx[j * DIM], qc, ir, aniso != 0);
+      const double d2 = euclid ? sqdist_nofma<DIM>(&sx[j * DIM], qc, ir, aniso != 0)
+                               : est_key<DIM>(sp.metric, &sx[j * DIM], qc, ir, aniso != 0);
       if (use_ball && !(d2 <= r2)) continue;
-      const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
+      double w;
+      if (euclid && gauss_w) w = gss_exp(-sp.wa * (d2 * inv_dmax2));
+      else if (euclid) w = lwr_weight(sp.wkind, sp.wa, sp.wp, gss_sqrt(d2 * inv_dmax2));
+      else w = lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
       double u[NP];
       u[0] = 1.0;
 #pragma unroll
