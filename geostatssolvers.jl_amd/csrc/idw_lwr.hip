@@ -52,28 +52,6 @@ __device__ __forceinline__ double lwr_weight(int kind, double a, double p, doubl
   return gss_exp(-a * hp);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(v, off);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-
 // Weighted least squares about the estimation point.  S1 = X'WX, S2 = X'W^2 X (packed lower triangles, NP = DIM+1,
 // u_0 = 1, u_a = x_a - x0_a), b = X'Wz.  mean = theta_0 with S1 theta = b; "variance" = |W X S1^-1 e_1| =
 // sqrt(a' S2 a) with S1 a = e_1 (lwr.jl:139-145).  Returns false when S1 is not positive definite.
@@ -151,7 +129,34 @@ __device__ __forceinline__ bool lwr_solve(const double* S1, const double* S2, co
 // ---------------------------------------------------------------------------------------------
 // k <= 64: one wave per estimation point on the neighbour lists written by K4
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
+// GW = lanes per estimation point: 64 (one wave per point) or 16 when k <= 16 (four points per wave: the reductions
+// are four shuffle steps instead of six and are shared by four points)
+template <int GW>
+__device__ __forceinline__ double grp_sum(double v) {
+#pragma unroll
+  for (int off = GW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <int GW>
+__device__ __forceinline__ double grp_max(double v) {
+#pragma unroll
+  for (int off = GW / 2; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+template <int GW>
+__device__ __forceinline__ double grp_min(double v) {
+#pragma unroll
+  for (int off = GW / 2; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+template <int DIM, int GW>
 __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* __restrict__ xdata,
                                                       const double* __restrict__ z, const double* __restrict__ x0,
                                                       int64_t m, int k, int minneighbors,
@@ -159,79 +164,76 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
                                                       int aniso, double ir0, double ir1, double ir2,
                                                       double* __restrict__ mean_out, double* __restrict__ aux_out,
                                                       uint8_t* __restrict__ status_out) {
+  constexpr int PPW = 64 / GW;  // points per wave
   const int lane = threadIdx.x & 63;
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= m) return;  // whole wave
+  const int gl = lane % GW, grp = lane / GW;
+  const int64_t p = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + grp;
+  const bool valid = p < m;
+  const int64_t pc = valid ? p : m - 1;
   const double NaN = __builtin_nan("");
-  const int cnt = count[p];
-  if (cnt < minneighbors || cnt < 1) {  // idw.jl:123-124, lwr.jl:126-127
-    if (lane == 0) {
-      mean_out[p] = NaN;
-      aux_out[p] = NaN;
-      status_out[p] = GSS_PT_MISSING;
-    }
-    return;
-  }
+  const int cnt = count[pc];
+  const bool missing = cnt < minneighbors || cnt < 1;  // idw.jl:123-124, lwr.jl:126-127
   const double ir[3] = {ir0, ir1, ir2};
   double qc[DIM], c[DIM];
 #pragma unroll
-  for (int a = 0; a < DIM; ++a) qc[a] = x0[p * DIM + a];
-  const bool act = lane < cnt;
-  const int i = act ? idx[p * k + lane] : 0;
+  for (int a = 0; a < DIM; ++a) qc[a] = x0[pc * DIM + a];
+  const bool act = !missing && gl < cnt;
+  const int i = act ? idx[pc * k + gl] : 0;
 #pragma unroll
   for (int a = 0; a < DIM; ++a) c[a] = xdata[(int64_t)i * DIM + a];
   const double zi = z[i];
   const double d2 = est_key<DIM>(sp.metric, c, qc, ir, aniso != 0);  // the key the search ranked by
   const double d = metric_dist(sp.metric, d2, sp.mparam);
+  double res_mean = NaN, res_aux = NaN;
+  int res_status = GSS_PT_MISSING;
 
   if (sp.method == 0) {
-    const unsigned long long zero = __ballot(act && d2 == 0.0);
-    if (zero) {  // idw.jl:131-134: some distance is zero -> copy the first such sample
-      const int j = __builtin_ctzll(zero);
-      const double zj = __shfl(zi, j);
-      if (lane == 0) {
-        mean_out[p] = zj;
-        aux_out[p] = 0.0;
-        status_out[p] = GSS_PT_OK;
+    const unsigned long long zb = __ballot(act && d2 == 0.0);
+    unsigned long long gz = zb;
+    if (GW < 64) gz = (zb >> (grp * (GW & 63))) & ((1ull << (GW & 63)) - 1ull);
+    const bool haszero = gz != 0ull;  // idw.jl:131-134: some distance is zero -> copy the first such sample
+    const int jz = haszero ? __builtin_ctzll(gz) + grp * GW : lane;
+    const double zj = __shfl(zi, jz);
+    const double w = (act && !haszero) ? idw_weight(d, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : d * d, sp.exponent) : 0.0;
+    const double sw = grp_sum<GW>(w);
+    const double swz = grp_sum<GW>(w * zi);
+    const double dmin = grp_min<GW>(act ? d : __builtin_huge_val());
+    if (!missing) {
+      res_mean = haszero ? zj : swz / sw;
+      res_aux = haszero ? 0.0 : dmin;  // idw.jl:139
+      res_status = GSS_PT_OK;
+    }
+  } else {
+    constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
+    const double dmax = grp_max<GW>(act ? d : 0.0);
+    const double w = act ? lwr_weight(sp.wkind, sp.wa, sp.wp, d / dmax) : 0.0;  // lwr.jl:132,136
+    double u[NP];
+    u[0] = 1.0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) u[a + 1] = c[a] - qc[a];
+    double S1[NT], S2[NT], b[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      b[r] = grp_sum<GW>(w * u[r] * zi);
+#pragma unroll
+      for (int q = 0; q <= r; ++q) {
+        const double t = w * u[r] * u[q];
+        S1[r * (r + 1) / 2 + q] = grp_sum<GW>(t);
+        S2[r * (r + 1) / 2 + q] = grp_sum<GW>(w * t);
       }
-      return;
     }
-    const double w = act ? idw_weight(d, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : d * d, sp.exponent) : 0.0;
-    const double sw = wave_sum(w);
-    const double swz = wave_sum(w * zi);
-    const double dmin = wave_min(act ? d : __builtin_huge_val());
-    if (lane == 0) {
-      mean_out[p] = swz / sw;
-      aux_out[p] = dmin;  // idw.jl:139
-      status_out[p] = GSS_PT_OK;
-    }
-    return;
-  }
-
-  constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
-  const double dmax = wave_max(act ? d : 0.0);
-  const double w = act ? lwr_weight(sp.wkind, sp.wa, sp.wp, d / dmax) : 0.0;  // lwr.jl:132,136
-  double u[NP];
-  u[0] = 1.0;
-#pragma unroll
-  for (int a = 0; a < DIM; ++a) u[a + 1] = c[a] - qc[a];
-  double S1[NT], S2[NT], b[NP];
-#pragma unroll
-  for (int r = 0; r < NP; ++r) {
-    b[r] = wave_sum(w * u[r] * zi);
-#pragma unroll
-    for (int q = 0; q <= r; ++q) {
-      const double t = w * u[r] * u[q];
-      S1[r * (r + 1) / 2 + q] = wave_sum(t);
-      S2[r * (r + 1) / 2 + q] = wave_sum(w * t);
+    double mu = 0.0, var = 0.0;
+    const bool ok = !missing && (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+    if (!missing) {
+      res_mean = ok ? mu : NaN;
+      res_aux = ok ? var : NaN;
+      res_status = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
     }
   }
-  double mu, var;
-  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
-  if (lane == 0) {
-    mean_out[p] = ok ? mu : NaN;
-    aux_out[p] = ok ? var : NaN;
-    status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+  if (valid && gl == 0) {
+    mean_out[p] = res_mean;
+    aux_out[p] = res_aux;
+    status_out[p] = (uint8_t)res_status;
   }
 }
 
@@ -450,13 +452,22 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
                                cnt_s.as<int>(), s, sp.metric));
     }
     ProfScope pl(pname, s);
-    dim3 grid((unsigned)((mv + 3) / 4));
 #define GSS_EST_KNN_ARGS sp, xdata, z, x0 + off * dim, mv, k, minneighbors, idx_s.as<int>(), cnt_s.as<int>(), aniso, \
                          ir[0], ir[1], ir[2], mean + off, aux + off, status + off
-    switch (dim) {
-      case 1: hipLaunchKernelGGL((est_knn_kernel<1>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
-      case 2: hipLaunchKernelGGL((est_knn_kernel<2>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
-      default: hipLaunchKernelGGL((est_knn_kernel<3>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+    if (k <= 16) {  // sixteen lanes per point, sixteen points per workgroup
+      dim3 grid((unsigned)((mv + 15) / 16));
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((est_knn_kernel<1, 16>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+        case 2: hipLaunchKernelGGL((est_knn_kernel<2, 16>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+        default: hipLaunchKernelGGL((est_knn_kernel<3, 16>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+      }
+    } else {
+      dim3 grid((unsigned)((mv + 3) / 4));
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((est_knn_kernel<1, 64>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+        case 2: hipLaunchKernelGGL((est_knn_kernel<2, 64>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+        default: hipLaunchKernelGGL((est_knn_kernel<3, 64>), grid, dim3(256), 0, s, GSS_EST_KNN_ARGS); break;
+      }
     }
 #undef GSS_EST_KNN_ARGS
     GSS_HIP(hipGetLastError());
