@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   double qacc[4] = {0.0, 0.0, 0.0, 0.0};
   double macc[4] = {0.0, 0.0, 0.0, 0.0};  // row N1 of the product: wd . rhs
 
+  int buf = 0;  // LDS stage holding the operands of the stage about to be multiplied; runs on across row blocks
   for (int I = Ibeg; I < Iend; ++I) {
     const int i0 = I * BM;
     const int kend = (i0 + BM < N1pad) ? i0 + BM : N1pad;
@@ -160,26 +161,29 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     d2v ra[4], rb[4];
     const double* wp = W + (int64_t)kq * ldw + i0 + i2;
     const double* rp = R + (int64_t)kq * ldr + p0 + i2;
+    if (I == Ibeg) {  // later row blocks find their first stage in LDS: the last stage of the block before fetched it
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ra[r] = *reinterpret_cast<const d2v*>(wp + (int64_t)(4 * r) * ldw);
-      rb[r] = *reinterpret_cast<const d2v*>(rp + (int64_t)(4 * r) * ldr);
-    }
-    __syncthreads();  // previous row block finished reading both LDS stages
+      for (int r = 0; r < 4; ++r) {
+        ra[r] = *reinterpret_cast<const d2v*>(wp + (int64_t)(4 * r) * ldw);
+        rb[r] = *reinterpret_cast<const d2v*>(rp + (int64_t)(4 * r) * ldr);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      *reinterpret_cast<d2v*>(As + (kq + 4 * r) * LDS_LD + i2) = ra[r];
-      *reinterpret_cast<d2v*>(Bs + (kq + 4 * r) * LDS_LD + i2) = rb[r];
+      for (int r = 0; r < 4; ++r) {
+        *reinterpret_cast<d2v*>(As + (kq + 4 * r) * LDS_LD + i2) = ra[r];
+        *reinterpret_cast<d2v*>(Bs + (kq + 4 * r) * LDS_LD + i2) = rb[r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
 
     auto stage = [&](int t, auto guard) {
       constexpr bool GUARD = decltype(guard)::value;
-      const int cur = t & 1;
-      const bool more = (t + 1) < ntile;
+      const int cur = buf;
+      const bool last = (t + 1) >= ntile;
+      const bool more = !last || (I + 1 < Iend);
       if (more) {
-        const double* wq = wp + (int64_t)(t + 1) * BK * ldw;
-        const double* rq = rp + (int64_t)(t + 1) * BK * ldr;
+        // next stage of this row block, or stage 0 of the next one (same strip of R from k = 0, rows i0 + BM.. of W)
+        const double* wq = last ? wp + BM : wp + (int64_t)(t + 1) * BK * ldw;
+        const double* rq = last ? rp : rp + (int64_t)(t + 1) * BK * ldr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           ra[r] = *reinterpret_cast<const d2v*>(wq + (int64_t)(4 * r) * ldw);
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
         }
       }
       __syncthreads();
+      buf ^= 1;
     };
     if (W14) {
       const int tdiag = (i0 / BK + 1) < ntile ? (i0 / BK + 1) : ntile;
