@@ -213,9 +213,19 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
               : 0;
   const bool ai = (sa_i == 1) || (sa_k != 1);
   const bool bj = (sb_j == 1) || (sb_k != 1);
-  // 128-tiles only when they can fill at least half of the 256 CUs; otherwise 64-tiles (4x the workgroups)
-  const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  if (big_tiles >= 128) return gemm_dispatch<128>(g, ai, bj, s);
+  // Tile shape by wave quantisation: 512 workgroups of 128-tiles or 768 of 64-tiles are resident at once (LDS), and
+  // a 64-tile workgroup reaches about 3/4 of the 128-tile rate.  A launch whose last round is mostly empty (e.g. the
+  // 528 lower tiles of a 4096^2 trailing update: 2 rounds for 1.03 rounds of work) is better off with small tiles.
+  auto tiles = [&](int64_t T) {
+    const int64_t tm = (M + T - 1) / T, tn = (N + T - 1) / T;
+    if (!lower_only) return tm * tn;
+    const int64_t d = tm < tn ? tm : tn;          // tiles on or below the block diagonal
+    return d * (d + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0);
+  };
+  const int64_t t128 = tiles(128), t64 = tiles(64);
+  const double eff128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+  const double eff64 = 0.75 * (double)t64 / (double)(((t64 + 767) / 768) * 768);
+  if (t128 >= 128 && eff128 >= eff64) return gemm_dispatch<128>(g, ai, bj, s);
   return gemm_dispatch<64>(g, ai, bj, s);
 }
 

@@ -23,3 +23,5 @@ run(8192, 8192, 4096, False)
 run(11264, 11264, 1024, True)
 run(4096, 4096, 1024, True)
 run(12288, 4096, 4096, False)
+for mm in (2048, 3072, 5120, 6144, 7168, 9216):
+    run(mm, mm, 1024, True)
