@@ -81,3 +81,32 @@ def test_config5_share_moving_neighbourhood():
     r = K.approxsolve(K.UK, Variogram("matern", range=30.0, nu=1.5), x, z, x0[sel], k, degree=1)
     assert np.max(np.abs(mu2.cpu().numpy() - r[0])) < 1e-9 and np.max(np.abs(var2.cpu().numpy() - r[1])) < 1e-9
     assert np.max(np.abs(var2.cpu().numpy() - var[sel])) < 1e-12      # the variance does not depend on the data
+
+
+def test_config4_lugs_full_size():
+    """configs[3]: 128 x 128 grid, 4096 conditioning cells, spherical range 20, 100 realisations.  Hard data exact
+    (lu.jl:217); a zero-noise realisation is the conditional mean C21 C11^-1 z1 (lu.jl:136-138, numpy solve);
+    realisations scatter around it with at most the prior variance."""
+    import gss
+    from gss.engine import LUGSHandle
+    from oracle import fftgs as offt
+    from oracle.variogram import cov_pairwise
+    g = 128
+    cent = offt.grid_centroids((g, g))
+    N = g * g
+    rng = np.random.default_rng(5)
+    dl = np.sort(rng.permutation(N)[:4096])
+    z1 = rng.normal(size=4096)
+    h = LUGSHandle(gss.SphericalVariogram(range=20.0), cent, dl, z1)
+    y, _ = h.realize(123, 0, 100)
+    y0, _ = h.realize(0, 0, 1, noise=np.zeros((1, h.ns)))
+    h.close()
+    assert np.array_equal(y[:, dl], np.tile(z1, (100, 1))) and np.array_equal(y0[0, dl], z1)
+    sl = np.setdiff1d(np.arange(N), dl)
+    ovg = Variogram("spherical", range=20.0)
+    C11 = cov_pairwise(ovg, cent[dl])
+    rows = sl[:: len(sl) // 400]
+    cm = cov_pairwise(ovg, cent[rows], cent[dl]) @ np.linalg.solve(C11, z1)
+    assert np.max(np.abs(y0[0, rows] - cm)) < 1e-8
+    dev = y[:, sl] - y0[0, sl]
+    assert abs(dev.mean()) < 0.02 and 0.0 < dev.var() < 1.0 and np.abs(y[0] - y[1]).max() > 0.1
