@@ -206,7 +206,7 @@ static void kd_order(KdPoint* pts, int dim, int64_t lo, int64_t hi, int depth) {
   std::nth_element(pts + lo, pts + lo + left, pts + hi, [axis](const KdPoint& p, const KdPoint& q) {
     return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.idx < q.idx);
   });
-  if (depth < 3 && count > 16384) {  // the two halves are independent: up to 8 host threads on large inputs
+  if (depth < 4 && count > 4096) {  // the two halves are independent: up to 16 host threads on large inputs
     auto fut = std::async(std::launch::async, kd_order, pts, dim, lo, lo + left, depth + 1);
     kd_order(pts, dim, lo + left, hi, depth + 1);
     fut.get();
