@@ -1,8 +1,9 @@
 /*
  * gss.h -- C-ABI of libgss_hip.so: MI355X (gfx950) kernels for the kriging-estimation and
- * Gaussian-simulation hot path of juliohm/GeoStatsSolvers.jl (KrigingSolver, FFTGS, LUGS).
+ * Gaussian-simulation hot path of juliohm/GeoStatsSolvers.jl (KrigingSolver, FFTGS, LUGS) and, on the
+ * same kernels, IDWSolver, LWRSolver and SGS.
  *
- * This is the drop-in boundary (DESIGN.md section 2, SURVEY.md section 8b).  The reference is
+ * This is the drop-in boundary (DESIGN.md section 1, SURVEY.md section 8b).  The reference is
  * pure Julia and has no FFI of its own; each entry point below replaces the arithmetic that the
  * cited reference lines delegate to their Julia dependencies, and is what a `ccall` from the
  * reference's `solve` / `preprocess` / `solvesingle` methods binds.
