@@ -171,8 +171,11 @@ static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
       if (nu == 0.5) *out_kind = VG_MATERN12;
       else if (nu == 1.5) *out_kind = VG_MATERN32;
       else if (nu == 2.5) *out_kind = VG_MATERN52;
+      else if (nu == 1.0) *out_kind = VG_MATERN1;
+      else if (nu == 2.0) *out_kind = VG_MATERN2;
+      else if (nu == 3.0) *out_kind = VG_MATERN3;
       else {
-        set_error("Matern order nu=%g is not available on the device (0.5, 1.5, 2.5 only)", nu);
+        set_error("Matern order nu=%g is not available on the device (1/2, 1, 3/2, 2, 5/2, 3 only)", nu);
         return GSS_ERR_UNSUPPORTED;
       }
       *mscale = std::sqrt(2.0 * nu) * 3.0;

@@ -119,3 +119,28 @@ def test_power_variogram_is_refused_where_the_reference_refuses_it():
     sol = gss.solve(gss.EstimationProblem(gss.georef(dict(z=rng.normal(size=20)), x), gss.CartesianGrid(10, 10), "z"),
                     gss.KrigingSolver(("z", dict(variogram=gss.PowerVariogram(exponent=1.2, nugget=0.1)))))
     assert np.all(np.isfinite(sol["z"])) and np.all(sol["z_variance"] >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [1.0, 2.0, 3.0])
+def test_matern_integer_orders_on_device(order):
+    """MaternVariogram(order = 1) is the reference's default order ([DEP] Variography); integer orders need the
+    modified Bessel functions K0 / K1 on the device (Chebyshev expansions, csrc/gss_internal.h).  Oracle: scipy kv."""
+    from gss.engine import HipEngine, KrigHandle, OK
+    rng = np.random.default_rng(int(order) + 40)
+    a = rng.uniform(0, 60, (200, 3))
+    b = np.vstack([a[:5], rng.uniform(0, 60, (120, 3)), a[:1] + 1e-7, a[:1] + 500.0])   # zero, tiny and huge lags
+    gv = gss.MaternVariogram(range=25.0, order=order, sill=1.7, nugget=0.1)
+    ov = Variogram("matern", range=25.0, nu=order, sill=1.7, nugget=0.1)
+    assert np.max(np.abs(HipEngine.cov_pairwise(gv, a, b) - cov_pairwise(ov, a, b))) < 5e-14
+    z = rng.normal(size=200)
+    h = KrigHandle(gv, OK, a, z)
+    mu, var, st = h.predict_global(b[:125])
+    rmu, rvar = K.exactsolve(K.OK, ov, a, z, b[:125])
+    assert not st.any() and np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    hl = KrigHandle(gv, OK, a, z, factor=False)
+    lmu, lvar, lst = hl.predict_knn(b[:125], 20)
+    r = K.approxsolve(K.OK, ov, a, z, b[:125], 20)
+    assert np.max(np.abs(lmu - r[0])) < 1e-9 and np.max(np.abs(lvar - r[1])) < 1e-9
+    with pytest.raises(gss._lib.GSSError, match="not available"):
+        KrigHandle(gss.MaternVariogram(range=25.0, order=0.7), OK, a, z)
