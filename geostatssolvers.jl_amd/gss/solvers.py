@@ -96,6 +96,22 @@ def _distance(p):
     return None if p["neighborhood"] is not None else d
 
 
+def _path_order(path, n):
+    """Traversal order of the estimation loop (krig.jl:179, idw.jl:112, lwr.jl:115): None for LinearPath, else a
+    permutation of 0..n-1 -- ("random", seed) or an explicit visiting order.  The reference stores its results in
+    traversal order (`pred = map(inds) do ind ...`, krig.jl:180-183), so the columns are permuted accordingly."""
+    if path is None or (isinstance(path, str) and path == "linear"):
+        return None
+    if isinstance(path, tuple) and len(path) == 2 and path[0] == "random":
+        return np.random.default_rng(path[1]).permutation(n)
+    if isinstance(path, str):
+        raise NotImplementedError(f"path {path!r}: give 'linear', ('random', seed) or a visiting order")
+    order = np.asarray(path, dtype=np.int64)
+    if order.shape != (n,) or not np.array_equal(np.sort(order), np.arange(n)):
+        raise ValueError("path must be a permutation of the domain elements")
+    return order
+
+
 def _ball(neighborhood):
     if neighborhood is None:
         return None, None
@@ -152,8 +168,7 @@ class KrigingSolver(_Solver):
             if inds.size == 0:
                 raise AssertionError(f"all samples of {var} are missing, aborting...")   # krig.jl:100-102
             _distance(p)
-            if p["path"] not in ("linear", None):
-                raise NotImplementedError("only LinearPath is available (results are per-point independent)")
+            _path_order(p["path"], problem.domain.nelements())
             vdom = PointSet(coords[inds])
             variant = kriging_ui(problem.domain, p["variogram"], p["mean"], p["degree"], p["drifts"])
             kind, nmax = searcher_ui(vdom, p["maxneighbors"], p["distance"], p["neighborhood"])
@@ -198,6 +213,9 @@ class KrigingSolver(_Solver):
             if gather and ws > 1:
                 mu = parallel.all_gather_concat(mu, m)
                 var_ = parallel.all_gather_concat(var_, m)
+            order = _path_order(p["path"], m)
+            if order is not None and (gather or ws == 1):              # results in traversal order, krig.jl:179-183
+                mu, var_ = mu[order], var_[order]
             cols[var] = mu
             cols[f"{var}_variance"] = var_                             # krig.jl:160
         if gather or ws == 1:
@@ -254,8 +272,7 @@ class _NeighborEstimator(_Solver):
             n = inds.size
             assert n > 0, "estimation requires data"                      # idw.jl:95
             _distance(p)
-            if p["path"] not in ("linear", None):
-                raise NotImplementedError("only LinearPath is available (results are per-point independent)")
+            order = _path_order(p["path"], m)
             nmin = p["minneighbors"]
             nmax = n if p["maxneighbors"] is None else min(p["maxneighbors"], n)      # idw.jl:93
             self._check(p)
@@ -272,6 +289,8 @@ class _NeighborEstimator(_Solver):
             if gather and ws > 1:
                 mu = parallel.all_gather_concat(mu, m)
                 ax = parallel.all_gather_concat(ax, m)
+            if order is not None and (gather or ws == 1):              # results in traversal order, idw.jl:112-113
+                mu, ax = mu[order], ax[order]
             cols[var] = mu
             aux[f"{var}_{self.AUX}"] = ax
         cols.update(aux)                                                  # (; mus..., sigmas...) idw.jl:152

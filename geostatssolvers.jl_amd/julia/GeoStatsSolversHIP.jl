@@ -202,8 +202,9 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
       end
     end
     miss = status .!= 0                                                  # krig.jl:213-214
-    push!(μs, var => [miss[i] ? missing : μ[i] for i in 1:m])
-    push!(σs, Symbol(var, "_variance") => [miss[i] ? missing : σ²[i] for i in 1:m])
+    inds = collect(traverse(pdomain, p.path))                            # results in traversal order, krig.jl:179-183
+    push!(μs, var => [miss[i] ? missing : μ[i] for i in inds])
+    push!(σs, Symbol(var, "_variance") => [miss[i] ? missing : σ²[i] for i in inds])
   end
   georef((; μs..., σs...), pdomain)                                      # krig.jl:163
 end
@@ -268,8 +269,9 @@ function neighbor_estimate(problem, solver, auxname, call)
     μ = Vector{Float64}(undef, m); aux = similar(μ); status = Vector{UInt8}(undef, m)
     GC.@preserve X z X0 ir μ aux status check(call(p, X, z, n, d, X0, m, Int32(k), radius, ir, μ, aux, status))
     miss = status .!= 0                                                  # idw.jl:123-124
-    push!(μs, var => [miss[i] ? missing : μ[i] for i in 1:m])
-    push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] for i in 1:m])
+    inds = collect(traverse(pdomain, p.path))                            # results in traversal order, idw.jl:112-113
+    push!(μs, var => [miss[i] ? missing : μ[i] for i in inds])
+    push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] for i in inds])
   end
   georef((; μs..., σs...), pdomain)
 end

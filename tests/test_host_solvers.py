@@ -99,7 +99,7 @@ def test_kriging_variants_through_solve_match_direct_oracle():
 def test_unsupported_options_fail_loudly():
     data = gss.georef({"z": [1.0, 0.0]}, [(0.0, 0.0), (1.0, 1.0)])
     grid = gss.CartesianGrid(4, 4)
-    for bad in (dict(distance="minkowski"), dict(path="multigrid")):
+    for bad in (dict(distance="minkowski"), dict(path="multigrid")):   # named paths other than "linear" need an order
         with pytest.raises(NotImplementedError):
             gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", bad), engine=OracleEngine))
     with pytest.raises(ValueError, match="Cartesian grids"):                                    # fft.jl:40-42
@@ -132,3 +132,23 @@ def test_product_engine_refuses_to_run_without_a_device():
     data = gss.georef({"z": [1.0, 0.0]}, [(0.0, 0.0), (1.0, 1.0)])
     with pytest.raises(_lib.GSSError, match="no CPU fallback"):
         gss.solve(gss.EstimationProblem(data, gss.CartesianGrid(4, 4), "z"), gss.KrigingSolver())
+
+
+def test_custom_paths_return_results_in_traversal_order():
+    """`path` (krig.jl:73, idw.jl:55): estimation is per-point independent, but the reference stores the results in
+    the order the path visits the domain (krig.jl:179-183) -- so does the twin."""
+    rng = np.random.default_rng(4)
+    data = gss.georef({"z": rng.normal(size=12)}, rng.uniform(0, 8, (12, 2)))
+    grid = gss.CartesianGrid(8, 6)
+    prob = gss.EstimationProblem(data, grid, "z")
+    vg = gss.ExponentialVariogram(range=5.0)
+    base = gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=5)), engine=OracleEngine))
+    order = np.random.default_rng(9).permutation(48)
+    for path, perm in ((order, order), (("random", 9), order)):
+        sol = gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=5, path=path)), engine=OracleEngine))
+        assert np.array_equal(sol["z"], base["z"][perm]) and np.array_equal(sol["z_variance"], base["z_variance"][perm])
+    ib = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=4)), engine=OracleEngine))
+    ip = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=4, path=order)), engine=OracleEngine))
+    assert np.array_equal(ip["z"], ib["z"][order]) and np.array_equal(ip["z_distance"], ib["z_distance"][order])
+    with pytest.raises(ValueError, match="permutation"):
+        gss.solve(prob, gss.LWRSolver(("z", dict(path=np.zeros(48, dtype=int))), engine=OracleEngine))
