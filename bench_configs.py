@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs,est_all] [--quick]
+    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
 """
 import argparse
 import json
@@ -287,6 +287,32 @@ def cfg_sgs(a, gss, _lib):
                              "sample": "oracle.sgs.realize, one realisation of a %dx%d grid in %.1f s" % (ce, ce, cdt)}}
 
 
+def cfg_cond_fftgs(a, gss, _lib):
+    """Section 8f.1 row: conditional FFTGS through the solver API (fft.jl:106-135,176-192): e^3 grid, exponential
+    range 20, 1 000 conditioning points, global kriging of the data and of every unconditional realisation."""
+    e = 64 if a.quick else 128
+    R = 16
+    rng = np.random.default_rng(9)
+    grid = gss.CartesianGrid((e, e, e))
+    N = e ** 3
+    xd = rng.uniform(0.0, float(e), (1000, 3))
+    zd = rng.normal(size=1000)
+    prob = gss.SimulationProblem(gss.georef({"z": zd}, xd), grid, "z", R)
+    solver = gss.FFTGS(("z", dict(variogram=gss.ExponentialVariogram(range=20.0))), rng=3)
+    solver.solve(prob)                     # warm-up (rocFFT-free plans, kernels, allocator)
+    sync()
+    t0 = time.perf_counter()
+    ens = solver.solve(prob)
+    sync()
+    dt = time.perf_counter() - t0
+    z0 = ens["z"][0]
+    # honouring: cells that hold a datum reproduce the value kriged there (exact at a coincident centroid only)
+    return {"config": "8f.1 conditional FFTGS %d^3 grid, exponential range 20, 1000 data, %d realisations, solver API "
+                      "(host arrays in / out)" % (e, R),
+            "metric": "conditional realisations/s", "value": round(R / dt, 2), "unit": "realisations/s",
+            "cells_per_s": round(N * R / dt, 1), "solve_s": round(dt, 3), "field_std": round(float(np.std(z0)), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4")
@@ -295,7 +321,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all}
+    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

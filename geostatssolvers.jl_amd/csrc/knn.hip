@@ -501,7 +501,10 @@ int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* ce
   GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3, "knn: bad sizes");
   if (m <= 0) return GSS_OK;
   const char* e = std::getenv("GSS_KNN_BRUTE");
-  if (metric == GSS_METRIC_EUCLIDEAN && !(e && e[0] == '1')) {
+  // few queries into a large set (e.g. the data -> grid-cell lookup of conditional simulation, fft.jl:129-132):
+  // one brute-force sweep of the set costs less than ordering it on the host for the index
+  const bool few_queries = m <= 4096 && n >= 32768;
+  if (metric == GSS_METRIC_EUCLIDEAN && !(e && e[0] == '1') && !few_queries) {
     KnnIndex ix;
     GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
     GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s));

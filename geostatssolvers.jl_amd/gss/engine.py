@@ -312,6 +312,7 @@ class SGSHandle:
 class HipEngine:
     """The product engine: every call lands in a gfx950 kernel."""
     name = "hip"
+    device_resident = True     # handles accept / return CUDA tensors, so solvers may keep intermediates in HBM
     Krig = KrigHandle
     FFTGS = FFTGSHandle
     LUGS = LUGSHandle
@@ -332,19 +333,31 @@ class HipEngine:
 
     @staticmethod
     def knn_search(xdata, centers, k, radius=None, radii=None, distance=None):
+        """Host arrays in -> host arrays out; CUDA tensors for both point sets keep the search in HBM."""
         l = _lib.lib()
         met, mpar = _lib.metric_spec(distance)
-        x = np.ascontiguousarray(xdata, dtype=np.float64)
-        if x.ndim == 1:
-            x = x[:, None]
-        c = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, x.shape[1])
-        m = c.shape[0]
-        idx = np.empty((m, k), dtype=np.int32)
-        cnt = np.empty(m, dtype=np.int32)
+        dev = is_torch(xdata) and xdata.is_cuda
+        if dev != (is_torch(centers) and centers.is_cuda):
+            raise ValueError("xdata and centers must live in the same memory space")
+        if dev:
+            import torch
+            x = _prep_in(xdata.reshape(xdata.shape[0], -1))
+            c = _prep_in(centers.reshape(-1, x.shape[1]))
+            m = c.shape[0]
+            idx = torch.empty((m, k), dtype=torch.int32, device=x.device)
+            cnt = torch.empty(m, dtype=torch.int32, device=x.device)
+        else:
+            x = np.ascontiguousarray(xdata, dtype=np.float64)
+            if x.ndim == 1:
+                x = x[:, None]
+            c = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, x.shape[1])
+            m = c.shape[0]
+            idx = np.empty((m, k), dtype=np.int32)
+            cnt = np.empty(m, dtype=np.int32)
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
         check(l.gss_knn_search(ptr(x), x.shape[0], x.shape[1], ptr(c), m, int(k), r, ptr(ir), met, mpar, ptr(idx),
-                               ptr(cnt), MEM_HOST, current_stream()))
+                               ptr(cnt), MEM_DEVICE if dev else MEM_HOST, current_stream()))
         return idx, cnt
 
     @staticmethod

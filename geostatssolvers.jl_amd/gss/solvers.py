@@ -348,22 +348,41 @@ class FFTGS(_Solver):
             if not vg.isstationary():
                 raise ValueError("variogram model must be stationary")              # fft.jl:91-93
             h = self.engine.FFTGS(vg, pgrid.dims, pgrid.spacing, p["mean"])         # fft.jl:96-103
-            zbar = krig = dinds = None
+            zbar = krig = dinds = cdev = None
             pdata = problem.data
             if pdata is not None and var in pdata.table:                             # fft.jl:106-135
                 xd = pdata.domain.centroids()
                 zd = np.asarray(pdata[var], dtype=np.float64)
-                kdom = PointSet(pdom.centroids())
+                cent = None
                 krig = KrigingSolver((var, dict(variogram=vg, mean=p["mean"], minneighbors=p["minneighbors"],
                                                 maxneighbors=p["maxneighbors"], neighborhood=p["neighborhood"],
                                                 distance=p["distance"])), engine=self.globals.get("engine"))
-                ksol = _solve_local(krig, georef({var: zd}, xd), kdom, var)           # fft.jl:125
-                zbar = ksol[var]
-                idx, _ = self.engine.knn_search(kdom.coords, xd, 1)                   # fft.jl:129-132
-                found = idx[:, 0]
+                if p["maxneighbors"] is None and getattr(self.engine, "device_resident", False):
+                    # global neighbourhood on the device engine: centroids go to HBM once and serve the kriging of
+                    # the data (fft.jl:125), the cell lookup (fft.jl:129-132) and every realisation in solve()
+                    import torch
+                    cdev = _centroids_device(pdom)
+                    keep = ~np.isnan(zd)                                              # krig.jl:97
+                    if not keep.any():
+                        raise AssertionError(f"all samples of {var} are missing, aborting...")
+                    kh = self.engine.Krig(vg, SK, xd[keep], zd[keep], mean=p["mean"])
+                    try:
+                        zbar = kh.predict_global(cdev)[0]
+                    finally:
+                        kh.close()
+                    idx, _ = self.engine.knn_search(cdev, torch.as_tensor(xd, device="cuda"), 1)
+                    found = idx[:, 0].cpu().numpy()
+                else:
+                    cent = pdom.centroids()
+                    kdom = PointSet(cent)
+                    ksol = _solve_local(krig, georef({var: zd}, xd), kdom, var)       # fft.jl:125
+                    zbar = ksol[var]
+                    idx, _ = self.engine.knn_search(kdom.coords, xd, 1)               # fft.jl:129-132
+                    found = idx[:, 0]
                 _, first = np.unique(found, return_index=True)
                 dinds = found[np.sort(first)]
-            pre[var] = dict(vg=vg, mean=p["mean"], handle=h, zbar=zbar, krig=krig, dinds=dinds)
+                pre[var] = dict(cent=cent, cdev=cdev)
+            pre[var] = dict(pre.get(var, {}), vg=vg, mean=p["mean"], handle=h, zbar=zbar, krig=krig, dinds=dinds)
         return pre
 
     def solve(self, problem: SimulationProblem, gather: bool = True):
@@ -378,13 +397,22 @@ class FFTGS(_Solver):
         reals = {}
         for vi, var in enumerate(problem.variables):
             q = pre[var]
-            zu = q["handle"].realize(seed + vi, lo, hi - lo, inds=inds) if hi > lo else \
-                np.empty((0, pdom.nelements()))
-            if q["krig"] is not None and hi > lo:                                     # fft.jl:176-192
-                cent = pdom.centroids()
+            cond = q["krig"] is not None and hi > lo
+            on_device = (cond and q["krig"].params(var)["maxneighbors"] is None
+                         and getattr(self.engine, "device_resident", False))
+            if on_device:
+                zu = None
+            elif hi > lo:
+                zu = q["handle"].realize(seed + vi, lo, hi - lo, inds=inds)
+            else:
+                zu = np.empty((0, pdom.nelements()))
+            if cond:                                                                  # fft.jl:176-192
+                cent = q["cent"]
                 dinds = q["dinds"]
                 kp = q["krig"].params(var)
-                if kp["maxneighbors"] is None:
+                if on_device:
+                    zu = self._condition_on_device(q, cent, dinds, seed + vi, lo, hi - lo, inds)
+                elif kp["maxneighbors"] is None:
                     # one kriging system (same locations) serves every realisation: factor once, batch the data
                     h = self.engine.Krig(q["vg"], SK, cent[dinds], zu[0, dinds], mean=q["mean"])
                     try:
@@ -404,6 +432,40 @@ class FFTGS(_Solver):
                 zu = parallel.all_gather_concat(zu, problem.nreals)
             reals[var] = [zu[r] for r in range(zu.shape[0])]
         return Ensemble(pdom, reals)
+
+
+def _centroids_device(pdom):
+    """`pdom.centroids()` assembled in HBM: the per-axis coordinates are computed on the host exactly as
+    CartesianGrid.centroids does (so the values are bit-identical), only the tensor product happens on the device."""
+    import torch
+    g = parent(pdom)
+    d = len(g.dims)
+    axes = [torch.as_tensor(g.origin[a] + (np.arange(g.dims[a]) + 0.5) * g.spacing[a], device="cuda") for a in range(d)]
+    mesh = torch.meshgrid(*axes[::-1], indexing="ij")
+    c = torch.stack([t.reshape(-1) for t in mesh[::-1]], dim=1).contiguous()
+    inds = parentindices(pdom)
+    return c if inds is None else c.index_select(0, torch.as_tensor(np.asarray(inds, dtype=np.int64), device="cuda"))
+
+
+def _fftgs_condition_on_device(self, q, cent, dinds, seed, first, count, inds):
+    """fft.jl:176-192 with the realisations, the kriged fields and their combination kept in HBM: the only
+    transfer is the conditioned block going out (torch is the device-memory plumbing)."""
+    import torch
+    zu = q["handle"].realize(seed, first, count, inds=inds, device=True)
+    ddev = torch.as_tensor(np.asarray(dinds, dtype=np.int64), device=zu.device)
+    zdat = zu.index_select(1, ddev).contiguous()
+    xdat = q["cdev"].index_select(0, ddev).cpu().numpy()
+    h = self.engine.Krig(q["vg"], SK, xdat, np.zeros(len(dinds)), mean=q["mean"])
+    try:
+        zbar_u = h.predict_global_batch(q["cdev"], zdat)
+    finally:
+        h.close()
+    zu -= zbar_u
+    zu += q["zbar"][None, :]                                                          # fft.jl:191
+    return zu.cpu().numpy()
+
+
+FFTGS._condition_on_device = _fftgs_condition_on_device
 
 
 def _solve_local(krig: KrigingSolver, data: GeoTable, dom, var):
