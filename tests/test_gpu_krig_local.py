@@ -40,7 +40,7 @@ def test_knn_pruned_equals_brute_force_on_large_clustered_data(monkeypatch, dim,
     and as the float64 numpy ranking by (d2, index) on a subset."""
     from gss.engine import HipEngine
     rng = np.random.default_rng(17 + dim + k)
-    n, m = 150_000, 4000
+    n, m = 150_000, 5000          # > 4096 centres: stays on the indexed path (fewer go to the brute-force sweep)
     centres_of_mass = rng.uniform(0, 1000, (40, dim))
     x = centres_of_mass[rng.integers(0, 40, n)] + rng.normal(0, 15.0, (n, dim))
     x[1000:1200] = x[:200]                                   # exact duplicates -> ties broken by index
@@ -56,6 +56,24 @@ def test_knn_pruned_equals_brute_force_on_large_clustered_data(monkeypatch, dim,
     assert np.array_equal(idx[::40], ridx) and np.array_equal(cnt[::40], rcnt)
     if ball:
         assert cnt.min() == 0 and cnt.max() == k
+
+
+def test_knn_few_queries_into_large_set_host_and_device():
+    """m <= 4096 centres into n >= 32768 points takes the brute-force sweep (no host index build); same lists as the
+    oracle ranking, and the same again when both point sets are CUDA tensors (the conditional-FFTGS cell lookup)."""
+    import torch
+    from gss.engine import HipEngine
+    g = offt.grid_centroids((40, 40, 30))                 # 48 000 lattice cells: ties at every face / edge
+    rng = np.random.default_rng(77)
+    c = np.concatenate([rng.uniform(0, 40, (60, 3)), np.array([[20.0, 20.0, 15.0], [0.0, 0.0, 0.0], [39.5, 1.0, 29.5]])])
+    for k in (1, 8):
+        idx, cnt = HipEngine.knn_search(g, c, k)
+        ridx, rcnt = K.knn_search(g, c, k)
+        assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
+        didx, dcnt = HipEngine.knn_search(torch.as_tensor(g, device="cuda"), torch.as_tensor(c, device="cuda"), k)
+        assert np.array_equal(didx.cpu().numpy(), ridx) and np.array_equal(dcnt.cpu().numpy(), rcnt)
+    with pytest.raises(ValueError):
+        HipEngine.knn_search(torch.as_tensor(g, device="cuda"), c, 1)
 
 
 def test_knn_lattice_ties_and_balls():
