@@ -174,9 +174,10 @@ static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
       else if (nu == 1.0) *out_kind = VG_MATERN1;
       else if (nu == 2.0) *out_kind = VG_MATERN2;
       else if (nu == 3.0) *out_kind = VG_MATERN3;
+      else if (nu > 0.0 && nu <= 50.0) *out_kind = VG_MATERN_NU;   // general order: Temme's K_nu on the device
       else {
-        set_error("Matern order nu=%g is not available on the device (1/2, 1, 3/2, 2, 5/2, 3 only)", nu);
-        return GSS_ERR_UNSUPPORTED;
+        set_error("Matern order nu=%g must lie in (0, 50]", nu);
+        return GSS_ERR_INVALID;
       }
       *mscale = std::sqrt(2.0 * nu) * 3.0;
       return GSS_OK;
@@ -253,6 +254,7 @@ int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
     return GSS_OK;
   }
   GSS_TRY(device_kind(vg->kind, vg->nu, &v.kind, &v.mscale));
+  if (v.kind == VG_MATERN_NU) v.pw = vg->nu;
   for (int e = 0; e < vg->nextra; ++e) {
     VgExtra& x = v.ex[e];
     GSS_REQUIRE(vg->extra[e].sill > 0.0, "nested structure %d needs a positive sill contribution", e + 1);
@@ -270,6 +272,7 @@ int32_t make_vgdev(const gss_variogram_t* vg, VgDev* out) {
       x.inv_range = 1.0 / vg->extra[e].range;
     }
     GSS_TRY(device_kind(vg->extra[e].kind, vg->extra[e].nu, &x.kind, &x.mscale));
+    if (x.kind == VG_MATERN_NU) x.pw = vg->extra[e].nu;
     v.sill += x.cs;
   }
   *out = v;

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void drift_rows_kernel(DriftSpec ds, const dou
 }
 
 // R[j * ldr + p] = C(x_j, x0_p) for the j rows of segment blockIdx.y
-template <int DIM>
+// KIND >= 0: single-structure model fixed at compile time -- the same arithmetic as cov_pair (which the fit uses, so
+// a domain point on a datum reproduces that datum's column of C bit for bit) with the model switch folded away; the
+// common models then carry no out-of-line call (the Bessel routines of the rarer Matern orders would otherwise set the
+// register budget of every launch).  KIND < 0: any model, nested or not.
+template <int DIM, int KIND>
 __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* __restrict__ xd, int n,
                                                        const double* __restrict__ x0, int64_t m_valid,
                                                        double* __restrict__ R, int64_t ldr, int seg_len,
@@ -90,10 +94,33 @@ __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* _
       double x[DIM];
 #pragma unroll
       for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
-      *rp = cov_pair<DIM>(vg, x, c);
+      if (KIND < 0) {
+        *rp = cov_pair<DIM>(vg, x, c);
+      } else {
+        const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
+        *rp = d2 <= 0.0 ? vg.sill : vg.cs * vg_shape(KIND < 0 ? 0 : KIND, d2, vg.inv_range, vg.mscale, vg.pw);
+      }
       rp += ldr;
     }
   }
+}
+
+template <int DIM>
+static void launch_krig_rhs(dim3 grid, hipStream_t s, const VgDev& vg, const double* xd, int n, const double* x0,
+                            int64_t m_valid, double* R, int64_t ldr, int seg_len, int nblk) {
+#define GSS_K1_LAUNCH(KIND)                                                                                       \
+  hipLaunchKernelGGL((krig_rhs_kernel<DIM, KIND>), grid, dim3(256), 0, s, vg, xd, n, x0, m_valid, R, ldr, seg_len, \
+                     nblk)
+  switch (vg.nextra == 0 ? vg.kind : -1) {
+    case GSS_VG_GAUSSIAN: GSS_K1_LAUNCH(GSS_VG_GAUSSIAN); break;
+    case GSS_VG_EXPONENTIAL: GSS_K1_LAUNCH(GSS_VG_EXPONENTIAL); break;
+    case GSS_VG_SPHERICAL: GSS_K1_LAUNCH(GSS_VG_SPHERICAL); break;
+    case VG_MATERN12: GSS_K1_LAUNCH(VG_MATERN12); break;
+    case VG_MATERN32: GSS_K1_LAUNCH(VG_MATERN32); break;
+    case VG_MATERN52: GSS_K1_LAUNCH(VG_MATERN52); break;
+    default: GSS_K1_LAUNCH(-1); break;
+  }
+#undef GSS_K1_LAUNCH
 }
 
 // K3.  One workgroup owns a strip of BN = 128 points and walks the row blocks I of W' (lower
@@ -797,19 +824,10 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
     {
       ProfScope ps("krig_rhs", s);
       switch (dim) {
-      case 1:
-        hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, Rws, ldr, seg_len, nblk);
-        break;
-      case 2:
-        hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, Rws, ldr, seg_len, nblk);
-        break;
-      default:
-        hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0,
-                           mv, Rws, ldr, seg_len, nblk);
-        break;
-    }
+        case 1: launch_krig_rhs<1>(g1, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, seg_len, nblk); break;
+        case 2: launch_krig_rhs<2>(g1, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, seg_len, nblk); break;
+        default: launch_krig_rhs<3>(g1, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, seg_len, nblk); break;
+      }
     GSS_HIP(hipGetLastError());
     // drift rows n..N1-1 and zero rows up to N1pad, plus their share of the mean
     if (nrows > 0) {
@@ -951,18 +969,9 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
     const int nblk = (int)(cols / 256);
     dim3 g1((unsigned)(nblk * NSEG));
     switch (dim) {
-      case 1:
-        hipLaunchKernelGGL((krig_rhs_kernel<1>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           Rws, ldr, seg_len, nblk);
-        break;
-      case 2:
-        hipLaunchKernelGGL((krig_rhs_kernel<2>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           Rws, ldr, seg_len, nblk);
-        break;
-      default:
-        hipLaunchKernelGGL((krig_rhs_kernel<3>), g1, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv,
-                           Rws, ldr, seg_len, nblk);
-        break;
+      case 1: launch_krig_rhs<1>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
+      case 2: launch_krig_rhs<2>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
+      default: launch_krig_rhs<3>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
     }
     GSS_HIP(hipGetLastError());
     const int nrows = (int)(h->N1pad - n);

@@ -52,7 +52,7 @@ enum {
   GSS_VG_GAUSSIAN = 0,
   GSS_VG_EXPONENTIAL = 1,
   GSS_VG_SPHERICAL = 2,
-  GSS_VG_MATERN = 3,         /* nu in {0.5, 1, 1.5, 2, 2.5, 3} on device (1 is the reference's default order) */
+  GSS_VG_MATERN = 3,         /* any order nu in (0, 50]; 1 is the reference's default order                   */
   GSS_VG_CUBIC = 4,
   GSS_VG_PENTASPHERICAL = 5,
   GSS_VG_SINEHOLE = 6,       /* gamma = (sill - nugget) (1 - sin(pi h/r) / (pi h/r)) + nugget          */

@@ -142,5 +142,41 @@ def test_matern_integer_orders_on_device(order):
     lmu, lvar, lst = hl.predict_knn(b[:125], 20)
     r = K.approxsolve(K.OK, ov, a, z, b[:125], 20)
     assert np.max(np.abs(lmu - r[0])) < 1e-9 and np.max(np.abs(lvar - r[1])) < 1e-9
-    with pytest.raises(gss._lib.GSSError, match="not available"):
-        KrigHandle(gss.MaternVariogram(range=25.0, order=0.7), OK, a, z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [0.2, 0.7, 1.25, 2.6, 4.2, 9.5])
+def test_matern_general_order_on_device(order):
+    """Any positive Matern order, as [DEP] Variography allows: K_nu by Temme's series / Steed's continued fraction
+    on the device (csrc/gss_internal.h gss_matern_general, tables from tools/gen_matern_general.py).  Oracle: scipy kv."""
+    from gss.engine import HipEngine, KrigHandle, OK, UK
+    rng = np.random.default_rng(int(order * 100))
+    a = rng.uniform(0, 60, (150, 2))
+    b = np.vstack([a[:5], rng.uniform(0, 60, (100, 2)), a[:1] + 1e-7, a[:1] + 800.0])     # zero, tiny and huge lags
+    gv = gss.MaternVariogram(range=25.0, order=order, sill=1.3, nugget=0.05)
+    ov = Variogram("matern", range=25.0, nu=order, sill=1.3, nugget=0.05)
+    assert np.max(np.abs(HipEngine.cov_pairwise(gv, a, b) - cov_pairwise(ov, a, b))) < 2e-13
+    z = rng.normal(size=150)
+    h = KrigHandle(gv, OK, a, z)
+    mu, var, st = h.predict_global(b[:105])
+    rmu, rvar = K.exactsolve(K.OK, ov, a, z, b[:105])
+    assert not st.any() and np.max(np.abs(mu - rmu)) < 1e-8 and np.max(np.abs(var - rvar)) < 1e-8
+    hl = KrigHandle(gv, UK, a, z, degree=1, factor=False)
+    lmu, lvar, lst = hl.predict_knn(b[:105], 24)
+    r = K.approxsolve(K.UK, ov, a, z, b[:105], 24, degree=1)
+    assert np.array_equal(lst, r[2]) and np.max(np.abs(lmu - r[0])) < 1e-8 and np.max(np.abs(lvar - r[1])) < 1e-8
+    # nested with a second structure of general order
+    from oracle.variogram import Nested
+    gn = 0.6 * gss.GaussianVariogram(range=10.0) + 0.4 * gv
+    on = Nested([(0.6, Variogram("gaussian", range=10.0)), (0.4, ov)])
+    assert np.max(np.abs(HipEngine.cov_pairwise(gn, a, b) - cov_pairwise(on, a, b))) < 2e-13
+
+
+@pytest.mark.gpu
+def test_matern_order_outside_range_is_invalid():
+    from gss.engine import KrigHandle, OK
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 10, (10, 2))
+    for bad in (0.0, -1.0, 80.0):
+        with pytest.raises(gss._lib.GSSError, match="must lie"):
+            KrigHandle(gss.MaternVariogram(range=5.0, order=bad), OK, a, rng.normal(size=10))
