@@ -110,3 +110,32 @@ def test_config4_lugs_full_size():
     assert np.max(np.abs(y0[0, rows] - cm)) < 1e-8
     dev = y[:, sl] - y0[0, sl]
     assert abs(dev.mean()) < 0.02 and 0.0 < dev.var() < 1.0 and np.abs(y[0] - y[1]).max() > 0.1
+
+
+def test_large_data_set_global_universal_kriging():
+    """n = 8 000 samples (the factor-and-inverse recursion runs five levels deep, W' is 0.5 GB), UK degree 1,
+    60 000 domain points: oracle sample, exactness at samples and affine reproduction (SURVEY.md 8c KATs)."""
+    import torch
+    import gss
+    from gss.engine import KrigHandle, UK
+    n, m = 8000, 60_000
+    rng = np.random.default_rng(8000)
+    x = rng.uniform(0.0, 100.0, (n, 3))
+    z = rng.normal(size=n)
+    x0 = rng.uniform(0.0, 100.0, (m, 3))
+    x0[:500] = x[:500]
+    xd = torch.as_tensor(x0, device="cuda")
+    vg = gss.MaternVariogram(range=30.0, order=1.5, nugget=0.01)
+    h = KrigHandle(vg, UK, x, z, degree=1)
+    mu, var, st = (t.cpu().numpy() for t in h.predict_global(xd))
+    h.close()
+    assert not st.any() and var.min() >= 0.0
+    sel = np.concatenate([np.arange(5), np.linspace(500, m - 1, 25).astype(np.int64)])
+    rmu, rvar = K.exactsolve(K.UK, Variogram("matern", range=30.0, nu=1.5, nugget=0.01), x, z, x0[sel], degree=1)
+    assert np.max(np.abs(mu[sel] - rmu)) < 1e-9 and np.max(np.abs(var[sel] - rvar)) < 1e-9
+    assert np.max(np.abs(mu[:500] - z[:500])) < 1e-8 and np.max(var[:500]) < 1e-8
+    aff = 2.0 - 0.3 * x[:, 0] + 0.05 * x[:, 1] + 0.7 * x[:, 2]
+    h = KrigHandle(vg, UK, x, aff, degree=1)
+    mu2 = h.predict_global(xd)[0].cpu().numpy()
+    h.close()
+    assert np.max(np.abs(mu2 - (2.0 - 0.3 * x0[:, 0] + 0.05 * x0[:, 1] + 0.7 * x0[:, 2]))) < 1e-8
