@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   double rsr = 0.0, tsr = 0.0;
   bool okS = true;
   if (nc > 0) {
-    const int i = lane < LMAX_NC ? lane : LMAX_NC - 1;
+    const int i = (lane & 15) < LMAX_NC ? (lane & 15) : LMAX_NC - 1;  // lanes 16..63 shadow lanes 0..15 (bc16)
     double srow[LMAX_NC];
 #pragma unroll
     for (int cc = 0; cc < LMAX_NC; ++cc) srow[cc] = G[2 + i][2 + cc];
@@ -474,10 +474,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (se[i][0] + se[i][1] + se[i][2]) == 0 ? 1.0 : 0.0;
     else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + (i < nc ? i : 0)];
     double u = G[2 + i][0] - f0, v = G[2 + i][1];
-#pragma unroll
-    for (int j = 0; j < LMAX_NC; ++j) {
+    static_for<0, LMAX_NC>([&](auto J) {
+      constexpr int j = decltype(J)::value;
       if (j < nc) {
-        double d = rl64(srow[j], j);
+        double d = bc16<j>(srow[j]);
         if (!(d > 0.0)) {
           okS = false;
           d = 1.0;
@@ -486,16 +486,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const double h = 0.5 * d;
         y = fma(y, fma(-h * y, y, 0.5), y);
         y = fma(y, fma(-h * y, y, 0.5), y);
-        const double lij = srow[j] * y;  // L[i][j] for i > j
-#pragma unroll
-        for (int cc = j + 1; cc < LMAX_NC; ++cc) srow[cc] = fma(-lij, rl64(srow[j], cc) * y, srow[cc]);
-        const double uj = rl64(u, j) * y, vj = rl64(v, j) * y;
+        const double lij = srow[j] * y;  // L[i][j] for i > j; lane cc holds L[cc][j]
+        static_for<j + 1, LMAX_NC>([&](auto CC) {
+          constexpr int cc = decltype(CC)::value;
+          fmac_bc16<cc, true>(srow[cc], lij, lij);  // srow[cc] -= L[cc][j] * L[i][j]
+        });
+        const double uj = bc16<j>(u) * y, vj = bc16<j>(v) * y;
         rsr = fma(uj, uj, rsr);
         tsr = fma(uj, vj, tsr);
         u = fma(-lij, uj, u);
         v = fma(-lij, vj, v);
       }
-    }
+    });
   }
   if (lane == 0) {
     if (!okS) {

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace gss {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -22,6 +24,50 @@ __device__ __forceinline__ double rl64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Lane J of every 16-lane row, to all lanes of that row (v_mov_b64_dpp row_newbcast): one VALU instruction and no
+// SGPR round trip where v_readlane needs two plus the SGPR pair.  In the factorisations below lanes 16..63 shadow
+// lanes 0..15, so the row broadcast returns what a wave-wide readlane would.
+template <int J>
+__device__ __forceinline__ double bc16(double x) {
+  const long v = __builtin_bit_cast(long, x);
+  const long r = __builtin_amdgcn_update_dpp(0L, v, 0x150 + J, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, r);
+}
+// acc (+/-)= (lane J of src's row) * mul as one v_fmac_f64_dpp.  The s_nop covers the two wait states a DPP read needs
+// after a VALU write of its source register: inline assembly is opaque to the compiler's hazard recogniser.
+template <int J, bool NEG>
+__device__ __forceinline__ void fmac_bc16(double& acc, double src, double mul) {
+  if (NEG)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+  else
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// One right-looking Cholesky step and one trtri step on rows held one per lane (row[q] = element (i, q) of lane i's row)
+template <int J>
+__device__ __forceinline__ void chol16_update(double (&row)[16]) {  // row[q] -= row[J] * L[q][J], q > J
+  static_for<J + 1, 16>([&](auto Q) { fmac_bc16<decltype(Q)::value, true>(row[decltype(Q)::value], row[J], row[J]); });
+}
+template <int J>
+__device__ __forceinline__ double trtri16_dot(const double (&row)[16]) {  // sum_{q > J} row[q] * L[q][J]
+  double a0 = 0.0, a1 = 0.0;
+  static_for<J + 1, 16>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    if ((q - J) & 1) fmac_bc16<q, false>(a0, row[J], row[q]);
+    else fmac_bc16<q, false>(a1, row[J], row[q]);
+  });
+  return a0 + a1;
+}
+
 // t: symmetric positive definite 16 x 16 tile (tile layout).  Returns V = U^-1 (tile layout, upper triangular) for
 // t = U'U; *bad is set when a pivot is not positive.  S: 16 x 17 doubles of LDS owned by this wave.
 __device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int lane, bool* bad) {
@@ -36,9 +82,9 @@ __device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int la
   __syncthreads();
   // lower Cholesky t = L L', right-looking so that the updates of one step are independent of each other; lane i
   // owns row i (its upper part holds don't-care values); the diagonal keeps 1 / L_jj
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double d = rl64(row[j], j);
+  static_for<0, 16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    double d = bc16<j>(row[j]);
     if (!(d > 0.0)) {
       *bad = true;
       d = 1.0;
@@ -48,28 +94,19 @@ __device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int la
     y = fma(y, fma(-h * y, y, 0.5), y);
     y = fma(y, fma(-h * y, y, 0.5), y);
     row[j] = (i == j) ? y : row[j] * y;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) row[q] = fma(-row[j], rl64(row[j], q), row[q]);
-    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of later columns from being hoisted (SGPR pressure)
-  }
+    chol16_update<j>(row);
+  });
   // W = L^-1 in place (unblocked trtri, last column first): lane i ends up with row i of W.  Column j of W is
   // -W22 * L[j+1.., j] / L_jj with W22 the already inverted trailing block, whose row i is in lane i's registers.
 #pragma unroll
   for (int q = 1; q < 16; ++q)
     if (q > i) row[q] = 0.0;  // clear the don't-care upper part: W is lower triangular
-#pragma unroll
-  for (int j = 15; j >= 0; --j) {
-    const double dinv = rl64(row[j], j);  // 1 / L_jj (kept on the diagonal by the factorisation)
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) {
-      const double lqj = rl64(row[j], q);  // L[q][j]
-      if ((q - j) & 1) a0 = fma(row[q], lqj, a0);
-      else a1 = fma(row[q], lqj, a1);
-    }
-    row[j] = (i == j) ? dinv : (i > j ? -(a0 + a1) * dinv : 0.0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  static_for<0, 16>([&](auto JJ) {
+    constexpr int j = 15 - decltype(JJ)::value;
+    const double dinv = bc16<j>(row[j]);  // 1 / L_jj (kept on the diagonal by the factorisation)
+    const double dot = trtri16_dot<j>(row);
+    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
+  });
   // V = W' back to tile layout: V[a][b] = W[b][a], lane b writes column b
 #pragma unroll
   for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
@@ -99,9 +136,9 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
   __syncthreads();
   double mydiag = 1.0;
   int badc = -1;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double d = rl64(row[j], j);
+  static_for<0, 16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    double d = bc16<j>(row[j]);
     if (!(d > 0.0)) {
       if (badc < 0) badc = j;
       d = 1.0;
@@ -112,10 +149,8 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
     y = fma(y, fma(-h * y, y, 0.5), y);
     if (i == j) mydiag = d * y;
     row[j] = (i == j) ? y : row[j] * y;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) row[q] = fma(-row[j], rl64(row[j], q), row[q]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+    chol16_update<j>(row);
+  });
   // U[a][b] = L[b][a]: lane b writes column b of U
 #pragma unroll
   for (int q = 0; q < 16; ++q) S2[q * 17 + i] = (q < i) ? row[q] : (q == i ? mydiag : 0.0);
@@ -126,19 +161,12 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
 #pragma unroll
   for (int q = 1; q < 16; ++q)
     if (q > i) row[q] = 0.0;
-#pragma unroll
-  for (int j = 15; j >= 0; --j) {
-    const double dinv = rl64(row[j], j);
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int q = j + 1; q < 16; ++q) {
-      const double lqj = rl64(row[j], q);
-      if ((q - j) & 1) a0 = fma(row[q], lqj, a0);
-      else a1 = fma(row[q], lqj, a1);
-    }
-    row[j] = (i == j) ? dinv : (i > j ? -(a0 + a1) * dinv : 0.0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  static_for<0, 16>([&](auto JJ) {
+    constexpr int j = 15 - decltype(JJ)::value;
+    const double dinv = bc16<j>(row[j]);
+    const double dot = trtri16_dot<j>(row);
+    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
+  });
   // lane i holds row i of W = L^-1: V = W' (lane b writes column b), VT = W (lane a writes row a)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
