@@ -304,8 +304,15 @@ __device__ __forceinline__ void k5_block_step(d4_t (&T)[10], d4_t (&B)[4], const
   }
 }
 
+// Four domain points per workgroup, one per wave.  The waves only meet for the diagonal tiles: the row broadcasts of
+// the 16 x 16 factorisation are local to a 16-lane row (tile16.h), so ONE wave factors the four waves' diagonal tiles
+// in its four lane rows for the issue cost of one, and the duty rotates with the block step (wave kk does step kk)
+// so that the four SIMDs share it.  Every wave passes every barrier: points without enough neighbours, and tile
+// steps beyond a point's neighbour count, take part with an identity tile.
+constexpr int K5_WAVES = 4;
+
 template <int DIM, int KIND>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
+__global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
                                                              const double* __restrict__ z,
                                                              const double* __restrict__ drift_data,
                                                              const double* __restrict__ x0,
@@ -315,24 +322,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                                                              double* __restrict__ mean_out,
                                                              double* __restrict__ var_out,
                                                              uint8_t* __restrict__ status_out) {
-  __shared__ double nx[LMAX_K][3];
-  __shared__ double colv[2][LMAX_K];  // c0 column and data column, one entry per neighbour
-  __shared__ int nidx[LMAX_K];
+  __shared__ double nx_[K5_WAVES][LMAX_K][3];
+  __shared__ double colv_[K5_WAVES][2][LMAX_K];  // c0 column and data column, one entry per neighbour
+  __shared__ int nidx_[K5_WAVES][LMAX_K];
   __shared__ signed char se[LMAX_NC][4];
-  __shared__ double S[16 * 17];
-  __shared__ double G[16][17];
+  __shared__ double S4[2][K5_WAVES][16 * 17];    // diagonal tiles in / inverse factors out, double buffered by step parity
+  __shared__ int badflag[2][K5_WAVES];
+  __shared__ double G_[K5_WAVES][16][17];
 
-  const int64_t p = blockIdx.x;
-  const int lane = threadIdx.x;
-  const int cnt = count[p];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  double (*nx)[3] = nx_[wave];
+  double (*colv)[LMAX_K] = colv_[wave];
+  int* nidx = nidx_[wave];
+  double (*G)[17] = G_[wave];
+  const int64_t pw = (int64_t)blockIdx.x * K5_WAVES + wave;
+  const bool inrange = pw < m;
+  const int64_t p = inrange ? pw : m - 1;
   const double NaN = __longlong_as_double(0x7ff8000000000000LL);
+  int cnt = inrange ? count[p] : 0;
+  bool live = inrange;
   if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
-    if (lane == 0) {
+    if (inrange && lane == 0) {
       mean_out[p] = NaN;
       var_out[p] = NaN;
       status_out[p] = GSS_PT_MISSING;
     }
-    return;
+    live = false;
+    cnt = 0;
   }
   const int nc = sp.nc;
   const int g = lane >> 4, c = lane & 15;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
     colv[0][lane] = act ? cov_pair_k<DIM, KIND>(vg, xj, c0) : 0.0;
     colv[1][lane] = act ? zz : 0.0;
-    if (lane == 0) {  // static indices only: a lane-indexed read would force the argument struct into scratch
+    if (threadIdx.x == 0) {  // static indices only: a lane-indexed read would force the argument struct into scratch
 #pragma unroll
       for (int cc = 0; cc < LMAX_NC; ++cc)
 #pragma unroll
@@ -435,8 +452,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // per-step code, shrinks the kernel from 84 KB to 53 KB but measured 5 % slower)
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
+    double* mine = S4[kk & 1][wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      mine[(g + 4 * r) * 17 + c] = (kk < nt) ? T[tile_id(kk, kk)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
+    __syncthreads();
+    if (wave == kk) potrf16_inverse_x4(&S4[kk & 1][0][0], lane, badflag[kk & 1]);
+    __syncthreads();
     if (kk < nt) {
-      const d4_t V = potrf16_inverse(T[tile_id(kk, kk)], S, lane, &bad);
+      d4_t V;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) V[r] = mine[(g + 4 * r) * 17 + c];
+      bad = bad || (badflag[kk & 1][wave] != 0);
       switch (kk) {
         case 0: k5_block_step<0>(T, B, V, nt); break;
         case 1: k5_block_step<1>(T, B, V, nt); break;
@@ -445,13 +472,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
     }
   }
-  if (bad) {
+  if (bad && live) {
     if (lane == 0) {
       mean_out[p] = NaN;
       var_out[p] = NaN;
       status_out[p] = GSS_PT_SINGULAR;
     }
-    return;
+    live = false;
   }
   d4_t Gt = zero4;
 #pragma unroll
@@ -486,7 +513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const double h = 0.5 * d;
         y = fma(y, fma(-h * y, y, 0.5), y);
         y = fma(y, fma(-h * y, y, 0.5), y);
-        const double lij = srow[j] * y;  // L[i][j] for i > j; lane cc holds L[cc][j]
+        double lij = srow[j] * y;  // L[i][j] for i > j; lane cc holds L[cc][j]
+        if (j + 1 < LMAX_NC) dpp_fence(lij);
         static_for<j + 1, LMAX_NC>([&](auto CC) {
           constexpr int cc = decltype(CC)::value;
           fmac_bc16<cc, true>(srow[cc], lij, lij);  // srow[cc] -= L[cc][j] * L[i][j]
@@ -499,7 +527,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       }
     });
   }
-  if (lane == 0) {
+  if (live && lane == 0) {
     if (!okS) {
       mean_out[p] = NaN;
       var_out[p] = NaN;
@@ -560,7 +588,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
 #define GSS_K5_ARGS vg, sp, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, \
                     var + off, st
 #define GSS_K5_LAUNCH(D, K) \
-  hipLaunchKernelGGL((krig_local_mfma_kernel<D, K>), dim3((unsigned)mv), dim3(64), 0, s, GSS_K5_ARGS)
+  hipLaunchKernelGGL((krig_local_mfma_kernel<D, K>), dim3((unsigned)((mv + K5_WAVES - 1) / K5_WAVES)), \
+                     dim3(64 * K5_WAVES), 0, s, GSS_K5_ARGS)
       // one instantiation per common single-structure model in 2-D / 3-D, the general kernel otherwise
       const int kind = vg.nextra == 0 ? vg.kind : -1;
       if (dim == 3) {

@@ -33,17 +33,19 @@ __device__ __forceinline__ double bc16(double x) {
   const long r = __builtin_amdgcn_update_dpp(0L, v, 0x150 + J, 0xf, 0xf, true);
   return __builtin_bit_cast(double, r);
 }
-// acc (+/-)= (lane J of src's row) * mul as one v_fmac_f64_dpp.  The s_nop covers the two wait states a DPP read needs
-// after a VALU write of its source register: inline assembly is opaque to the compiler's hazard recogniser.
+// acc (+/-)= (lane J of src's row) * mul as one v_fmac_f64_dpp.  Inline assembly is opaque to the compiler's hazard
+// recogniser, and a VGPR written by a VALU instruction may be read through DPP only two wait states later: the
+// caller puts dpp_fence(src) between the instruction that produces src and the first fmac_bc16 that reads it, and
+// tools/check_dpp_hazards.py (run by tests/test_abi.py) scans the built code objects for any such read that the
+// register allocator might have placed too early after a copy.
 template <int J, bool NEG>
 __device__ __forceinline__ void fmac_bc16(double& acc, double src, double mul) {
   if (NEG)
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
   else
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
 }
+__device__ __forceinline__ void dpp_fence(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) {
@@ -55,15 +57,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // One right-looking Cholesky step and one trtri step on rows held one per lane (row[q] = element (i, q) of lane i's row)
 template <int J>
 __device__ __forceinline__ void chol16_update(double (&row)[16]) {  // row[q] -= row[J] * L[q][J], q > J
+  if (J < 15) dpp_fence(row[J]);
   static_for<J + 1, 16>([&](auto Q) { fmac_bc16<decltype(Q)::value, true>(row[decltype(Q)::value], row[J], row[J]); });
 }
 template <int J>
 __device__ __forceinline__ double trtri16_dot(const double (&row)[16]) {  // sum_{q > J} row[q] * L[q][J]
   double a0 = 0.0, a1 = 0.0;
+  double src = row[J];
+  if (J < 15) dpp_fence(src);
   static_for<J + 1, 16>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
-    if ((q - J) & 1) fmac_bc16<q, false>(a0, row[J], row[q]);
-    else fmac_bc16<q, false>(a1, row[J], row[q]);
+    if ((q - J) & 1) fmac_bc16<q, false>(a0, src, row[q]);
+    else fmac_bc16<q, false>(a1, src, row[q]);
   });
   return a0 + a1;
 }
@@ -116,6 +121,47 @@ __device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int la
   for (int r = 0; r < 4; ++r) v[r] = S[(g + 4 * r) * 17 + c];
   __syncthreads();
   return v;
+}
+
+// Four tiles at once, one per 16-lane row of the calling wave: S4 holds four symmetric positive definite tiles
+// (tile t at S4 + t * 272, element (a, b) at [a * 17 + b]); on return each holds V = U^-1 of its own tile in the same
+// storage and flags[t] says whether a pivot of tile t was not positive.  Same arithmetic as potrf16_inverse; the
+// caller puts a workgroup barrier before (tiles written by other waves) and after (inverse factors read by them).
+__device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* flags) {
+  const int t = lane >> 4, i = lane & 15;
+  double* S = S4 + t * (16 * 17);
+  double row[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
+  bool bad = false;
+  static_for<0, 16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    double d = bc16<j>(row[j]);
+    if (!(d > 0.0)) {
+      bad = true;
+      d = 1.0;
+    }
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    row[j] = (i == j) ? y : row[j] * y;
+    chol16_update<j>(row);
+  });
+#pragma unroll
+  for (int q = 1; q < 16; ++q)
+    if (q > i) row[q] = 0.0;
+  static_for<0, 16>([&](auto JJ) {
+    constexpr int j = 15 - decltype(JJ)::value;
+    const double dinv = bc16<j>(row[j]);
+    const double dot = trtri16_dot<j>(row);
+    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
+  });
+  // V = W': V[a][b] = W[b][a], lane b = i writes column b.  Every lane of the row has read its row before any writes
+  // (LDS operations of one wave complete in order), so the tile is overwritten in place.
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
+  if (i == 0) flags[t] = bad ? 1 : 0;
 }
 
 constexpr int tile_id(int i, int j) { return i * 4 - (i * (i - 1)) / 2 + (j - i); }  // upper block triangle, i <= j

@@ -52,7 +52,23 @@ def test_invalid_arguments_do_not_need_a_device():
     code = lib.gss_krig_create(ctypes.byref(h), ctypes.byref(v), 1, 0.0, 0, 0, ctypes.c_void_p(8), ctypes.c_void_p(8),
                                None, 0, 0, None)
     assert code == _lib.ERR_INVALID and "missing" in _lib.last_error()
-    bad = _lib.make_variogram("matern", 2, nu=0.7)
+    bad = _lib.make_variogram("matern", 2, nu=80.0)          # orders in (0, 50] only
     code = lib.gss_krig_create(ctypes.byref(h), ctypes.byref(bad), 1, 0.0, 0, 0, ctypes.c_void_p(8),
                                ctypes.c_void_p(8), None, 4, 0, None)
-    assert code == _lib.ERR_UNSUPPORTED
+    assert code == _lib.ERR_INVALID and "must lie" in _lib.last_error()
+
+
+def test_no_dpp_read_follows_a_write_too_closely():
+    """csrc/tile16.h issues v_fmac_f64_dpp from inline assembly, which the compiler's hazard recogniser cannot see;
+    tools/check_dpp_hazards.py disassembles the gfx950 code objects of the built library and checks the two wait
+    states between a VALU write and a DPP read of the same register."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dpp_hazards.py"), _lib.LIB_PATH],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert int(r.stdout.split()[0]) > 1000, r.stdout        # the tile factorisations are in the library
