@@ -125,8 +125,15 @@ __device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int la
 
 // Four tiles at once, one per 16-lane row of the calling wave: S4 holds four symmetric positive definite tiles
 // (tile t at S4 + t * 272, element (a, b) at [a * 17 + b]); on return each holds V = U^-1 of its own tile in the same
-// storage and flags[t] says whether a pivot of tile t was not positive.  Same arithmetic as potrf16_inverse; the
-// caller puts a workgroup barrier before (tiles written by other waves) and after (inverse factors read by them).
+// storage and flags[t] says whether a pivot of tile t was not positive.  The caller puts a workgroup barrier before
+// (tiles written by other waves) and after (inverse factors read by them).
+//
+// The other waves of the workgroup wait for this routine, so it is arranged for a short dependent chain rather than
+// for few instructions: W = L^-1 is built during the factorisation instead of by a second 16-step sweep.  Lane i
+// holds row i; once column j of L has been used (step j) its registers take column j of M = D W (D = diag(L), i.e.
+// the rows of W before their final scaling by 1 / L_ii):  M_i. = e_i - sum_{j < i} L_ij W_j.  and W_j. = M_j. / L_jj
+// is complete when step j starts, so step j applies  M_ic -= (L_ij / L_jj) M_jc  (c < j, rows i > j) next to the
+// usual  A_iq -= L_ij L_qj  (q > j): sixteen independent multiply-adds per step on one chain of sixteen steps.
 __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* flags) {
   const int t = lane >> 4, i = lane & 15;
   double* S = S4 + t * (16 * 17);
@@ -134,6 +141,7 @@ __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* fl
 #pragma unroll
   for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
   bool bad = false;
+  double myy = 1.0;  // 1 / L_ii
   static_for<0, 16>([&](auto J) {
     constexpr int j = decltype(J)::value;
     double d = bc16<j>(row[j]);
@@ -145,22 +153,24 @@ __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* fl
     const double h = 0.5 * d;
     y = fma(y, fma(-h * y, y, 0.5), y);
     y = fma(y, fma(-h * y, y, 0.5), y);
-    row[j] = (i == j) ? y : row[j] * y;
-    chol16_update<j>(row);
+    double lij = row[j] * y;                      // L_ij (rows i >= j)
+    double tm = (i > j) ? -(lij * y) : 0.0;       // -L_ij / L_jj for the rows still being eliminated, 0 for finished rows
+    if (i == j) myy = y;
+    if (j < 15) dpp_fence(lij);
+    static_for<j + 1, 16>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      fmac_bc16<q, true>(row[q], lij, lij);       // A_iq -= L_qj L_ij
+    });
+    static_for<0, j>([&](auto C) {
+      constexpr int c = decltype(C)::value;
+      fmac_bc16<j, false>(row[c], row[c], tm);    // M_ic += tm M_jc  (row j's own entry is final: tm = 0 there)
+    });
+    row[j] = (i == j) ? 1.0 : tm;                 // column j of M: M_jj = 1, M_ij = -L_ij / L_jj below, 0 above
   });
+  // V = W' with W_ic = M_ic / L_ii: lane b = i writes column b.  Every lane has read its row before any write (LDS
+  // operations of one wave complete in order), so the tile is overwritten in place.
 #pragma unroll
-  for (int q = 1; q < 16; ++q)
-    if (q > i) row[q] = 0.0;
-  static_for<0, 16>([&](auto JJ) {
-    constexpr int j = 15 - decltype(JJ)::value;
-    const double dinv = bc16<j>(row[j]);
-    const double dot = trtri16_dot<j>(row);
-    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
-  });
-  // V = W': V[a][b] = W[b][a], lane b = i writes column b.  Every lane of the row has read its row before any writes
-  // (LDS operations of one wave complete in order), so the tile is overwritten in place.
-#pragma unroll
-  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
+  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r] * myy;
   if (i == 0) flags[t] = bad ? 1 : 0;
 }
 
