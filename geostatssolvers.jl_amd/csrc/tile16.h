@@ -18,12 +18,6 @@ __device__ __forceinline__ d4_t xty(const d4_t& x, const d4_t& y, d4_t acc) {  /
   return acc;
 }
 
-__device__ __forceinline__ double rl64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
 // Lane J of every 16-lane row, to all lanes of that row (v_mov_b64_dpp row_newbcast): one VALU instruction and no
 // SGPR round trip where v_readlane needs two plus the SGPR pair.  In the factorisations below lanes 16..63 shadow
 // lanes 0..15, so the row broadcast returns what a wave-wide readlane would.
@@ -52,75 +46,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     f(std::integral_constant<int, B>{});
     static_for<B + 1, E>(f);
   }
-}
-
-// One right-looking Cholesky step and one trtri step on rows held one per lane (row[q] = element (i, q) of lane i's row)
-template <int J>
-__device__ __forceinline__ void chol16_update(double (&row)[16]) {  // row[q] -= row[J] * L[q][J], q > J
-  if (J < 15) dpp_fence(row[J]);
-  static_for<J + 1, 16>([&](auto Q) { fmac_bc16<decltype(Q)::value, true>(row[decltype(Q)::value], row[J], row[J]); });
-}
-template <int J>
-__device__ __forceinline__ double trtri16_dot(const double (&row)[16]) {  // sum_{q > J} row[q] * L[q][J]
-  double a0 = 0.0, a1 = 0.0;
-  double src = row[J];
-  if (J < 15) dpp_fence(src);
-  static_for<J + 1, 16>([&](auto Q) {
-    constexpr int q = decltype(Q)::value;
-    if ((q - J) & 1) fmac_bc16<q, false>(a0, src, row[q]);
-    else fmac_bc16<q, false>(a1, src, row[q]);
-  });
-  return a0 + a1;
-}
-
-// t: symmetric positive definite 16 x 16 tile (tile layout).  Returns V = U^-1 (tile layout, upper triangular) for
-// t = U'U; *bad is set when a pivot is not positive.  S: 16 x 17 doubles of LDS owned by this wave.
-__device__ __forceinline__ d4_t potrf16_inverse(const d4_t& t, double* S, int lane, bool* bad) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
-  __syncthreads();
-  const int i = c;  // lanes 16..63 shadow lanes 0..15
-  double row[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
-  __syncthreads();
-  // lower Cholesky t = L L', right-looking so that the updates of one step are independent of each other; lane i
-  // owns row i (its upper part holds don't-care values); the diagonal keeps 1 / L_jj
-  static_for<0, 16>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    double d = bc16<j>(row[j]);
-    if (!(d > 0.0)) {
-      *bad = true;
-      d = 1.0;
-    }
-    double y = __builtin_amdgcn_rsq(d);  // refined to full precision by two Newton steps
-    const double h = 0.5 * d;
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    row[j] = (i == j) ? y : row[j] * y;
-    chol16_update<j>(row);
-  });
-  // W = L^-1 in place (unblocked trtri, last column first): lane i ends up with row i of W.  Column j of W is
-  // -W22 * L[j+1.., j] / L_jj with W22 the already inverted trailing block, whose row i is in lane i's registers.
-#pragma unroll
-  for (int q = 1; q < 16; ++q)
-    if (q > i) row[q] = 0.0;  // clear the don't-care upper part: W is lower triangular
-  static_for<0, 16>([&](auto JJ) {
-    constexpr int j = 15 - decltype(JJ)::value;
-    const double dinv = bc16<j>(row[j]);  // 1 / L_jj (kept on the diagonal by the factorisation)
-    const double dot = trtri16_dot<j>(row);
-    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
-  });
-  // V = W' back to tile layout: V[a][b] = W[b][a], lane b writes column b
-#pragma unroll
-  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r];
-  __syncthreads();
-  d4_t v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = S[(g + 4 * r) * 17 + c];
-  __syncthreads();
-  return v;
 }
 
 // Four tiles at once, one per 16-lane row of the calling wave: S4 holds four symmetric positive definite tiles
@@ -176,9 +101,10 @@ __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* fl
 
 constexpr int tile_id(int i, int j) { return i * 4 - (i * (i - 1)) / 2 + (j - i); }  // upper block triangle, i <= j
 
-// Same factorisation, with everything the 64 x 64 leaf needs from a diagonal tile: u = U (tile layout, upper,
-// zero below the diagonal), v = U^-1, vt = (U^-1)' (lower), and the first column whose pivot was not positive
-// (-1 if none).  S and S2: 16 x 17 doubles of LDS each.
+// One tile (lanes 16..63 shadow lanes 0..15), with everything the 64 x 64 leaf needs from a diagonal tile:
+// u = U (tile layout, upper, zero below the diagonal) for t = U'U, v = U^-1, vt = (U^-1)' (lower), and the first column
+// whose pivot was not positive (-1 if none).  Same single sweep as potrf16_inverse_x4: the leaf is one wave on the
+// latency chain of the fit, so the dependent chain counts.  S and S2: 16 x 17 doubles of LDS each.
 __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S2, int lane, d4_t* u, d4_t* v,
                                              d4_t* vt, int* bad_col) {
   const int g = lane >> 4, c = lane & 15;
@@ -190,7 +116,7 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
 #pragma unroll
   for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
   __syncthreads();
-  double mydiag = 1.0;
+  double myy = 1.0;
   int badc = -1;
   static_for<0, 16>([&](auto J) {
     constexpr int j = decltype(J)::value;
@@ -203,31 +129,31 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
     const double h = 0.5 * d;
     y = fma(y, fma(-h * y, y, 0.5), y);
     y = fma(y, fma(-h * y, y, 0.5), y);
-    if (i == j) mydiag = d * y;
-    row[j] = (i == j) ? y : row[j] * y;
-    chol16_update<j>(row);
+    double lij = row[j] * y;                      // L_ij (rows i >= j); lane j: sqrt(d)
+    S2[j * 17 + i] = (i >= j) ? lij : 0.0;        // U[j][i] = L[i][j]
+    double tm = (i > j) ? -(lij * y) : 0.0;
+    if (i == j) myy = y;
+    if (j < 15) dpp_fence(lij);
+    static_for<j + 1, 16>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      fmac_bc16<q, true>(row[q], lij, lij);
+    });
+    static_for<0, j>([&](auto C) {
+      constexpr int cc = decltype(C)::value;
+      fmac_bc16<j, false>(row[cc], row[cc], tm);
+    });
+    row[j] = (i == j) ? 1.0 : tm;
   });
-  // U[a][b] = L[b][a]: lane b writes column b of U
-#pragma unroll
-  for (int q = 0; q < 16; ++q) S2[q * 17 + i] = (q < i) ? row[q] : (q == i ? mydiag : 0.0);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) (*u)[r] = S2[(g + 4 * r) * 17 + c];
   __syncthreads();
-#pragma unroll
-  for (int q = 1; q < 16; ++q)
-    if (q > i) row[q] = 0.0;
-  static_for<0, 16>([&](auto JJ) {
-    constexpr int j = 15 - decltype(JJ)::value;
-    const double dinv = bc16<j>(row[j]);
-    const double dot = trtri16_dot<j>(row);
-    row[j] = (i == j) ? dinv : (i > j ? -dot * dinv : 0.0);
-  });
-  // lane i holds row i of W = L^-1: V = W' (lane b writes column b), VT = W (lane a writes row a)
+  // lane i holds row i of W = L^-1 (after the scaling by 1 / L_ii): V = W' (lane b writes column b), VT = W
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    S[r * 17 + i] = row[r];
-    S2[i * 17 + r] = row[r];
+    const double w = row[r] * myy;
+    S[r * 17 + i] = w;
+    S2[i * 17 + r] = w;
   }
   __syncthreads();
 #pragma unroll
