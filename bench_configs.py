@@ -239,7 +239,7 @@ def cfg_sgs(a, gss, _lib):
     from gss.engine import SGSHandle
     from oracle import fftgs as offt
     e = 128 if a.quick else 512
-    R = 1024          # one wave carries 64 realisations through the path; 16 waves run side by side
+    R = a.sgs_reals   # one wave carries 64 realisations through the path; R / 64 waves run side by side
     cent = offt.grid_centroids((e, e))
     N = cent.shape[0]
     rng = np.random.default_rng(5)
@@ -251,11 +251,11 @@ def cfg_sgs(a, gss, _lib):
     h = SGSHandle(vg, cent, None, dl, zd, 0.0, 16, 1, 30.0)
     sync()
     t_pre = time.perf_counter() - t0
-    h.realize(1, 0, R, device=True)
+    z = h.realize(1, 0, R, device=True)
     sync()
     _lib.profile_reset()
     t0 = time.perf_counter()
-    z = h.realize(1, 0, R, device=True)
+    h.realize(1, 0, R, out=z)              # same buffer: the 2 GiB allocation is not part of the sweep
     sync()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
@@ -317,6 +317,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--sgs-reals", type=int, default=1024, help="realisations of the SGS row (multiple of 64)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     import gss

@@ -297,9 +297,12 @@ class SGSHandle:
         check(self._l.gss_sgs_weights(self._h, ptr(idx), ptr(nc), ptr(w), ptr(sg), MEM_HOST, current_stream()))
         return idx, nc, w, sg
 
-    def realize(self, seed, first_real, nreals, noise=None, device=False):
+    def realize(self, seed, first_real, nreals, noise=None, device=False, out=None):
         noise = _prep_in(noise)
-        if device or is_torch(noise):
+        if out is not None:
+            if tuple(out.shape) != (nreals, self.N):
+                raise ValueError(f"out must have shape ({nreals}, {self.N})")
+        elif device or is_torch(noise):
             import torch
             out = torch.empty((nreals, self.N), dtype=torch.float64, device="cuda")
         else:
