@@ -51,7 +51,9 @@ __device__ __forceinline__ void bitonic_cx(double& d, int& i, int lane, int stri
   const double od = __shfl_xor(d, stride);
   const int oi = __shfl_xor(i, stride);
   const bool lower = (lane & stride) == 0;
-  const bool take = (lower == up) ? key_less(od, oi, d, i) : key_less(d, i, od, oi);
+  // keys are distinct (unique indices) except for two empty slots, where the choice does not matter: "mine is less"
+  // is the negation of "the other is less", so one comparison serves both directions
+  const bool take = key_less(od, oi, d, i) == (lower == up);
   if (take) {
     d = od;
     i = oi;
