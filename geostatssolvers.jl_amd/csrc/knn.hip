@@ -37,10 +37,34 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// v of lane (l ^ stride).  Strides 1, 2, 4, 8 stay inside a 16-lane row and are DPP moves (quad_perm, row_shl / row_shr
+// by bank, row_ror: one or two VALU instructions per dword, no LDS round trip); 16 and 32 cross rows: ds_bpermute.
+// The kernels below call this with every lane of the wave active.
+__device__ __forceinline__ int xor_shfl_b32(int v, int stride) {
+  switch (stride) {
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    case 4: {
+      const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0, 2
+      return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xf, 0xa, false);         // row_shr:4 into banks 1, 3
+    }
+    case 8: return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    default: return __shfl_xor(v, stride);
+  }
+}
+__device__ __forceinline__ double xor_shfl_f64(double v, int stride) {
+  return __hiloint2double(xor_shfl_b32(__double2hiint(v), stride), xor_shfl_b32(__double2loint(v), stride));
+}
+// v of lane l - 1 (lane 0 keeps its own): wave_shr:1
+__device__ __forceinline__ int shfl_up1_b32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double shfl_up1_f64(double v) {
+  return __hiloint2double(shfl_up1_b32(__double2hiint(v)), shfl_up1_b32(__double2loint(v)));
+}
+
 __device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(v, off);
+    const double o = xor_shfl_f64(v, off);
     v = o < v ? o : v;
   }
   return v;
@@ -48,8 +72,8 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 
 // one compare-exchange stage of a bitonic network on (d, i) keys: lanes `stride` apart, ascending when `up`
 __device__ __forceinline__ void bitonic_cx(double& d, int& i, int lane, int stride, bool up) {
-  const double od = __shfl_xor(d, stride);
-  const int oi = __shfl_xor(i, stride);
+  const double od = xor_shfl_f64(d, stride);
+  const int oi = xor_shfl_b32(i, stride);
   const bool lower = (lane & stride) == 0;
   // keys are distinct (unique indices) except for two empty slots, where the choice does not matter: "mine is less"
   // is the negation of "the other is less", so one comparison serves both directions
@@ -139,8 +163,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
           const int ci = __builtin_amdgcn_readlane(gidx, src);
           if (!key_less(cd, ci, tau_d[q], tau_i[q])) continue;  // an earlier insertion tightened tau
           const int pos = __popcll(__ballot(key_less(ld[q], li[q], cd, ci)));
-          const double up_d = __shfl_up(ld[q], 1);
-          const int up_i = __shfl_up(li[q], 1);
+          const double up_d = shfl_up1_f64(ld[q]);
+          const int up_i = shfl_up1_b32(li[q]);
           if (lane > pos) {
             ld[q] = up_d;
             li[q] = up_i;
@@ -400,8 +424,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
           const int ci = __builtin_amdgcn_readlane(oidx, src);
           if (!key_less(cd, ci, tau_d, tau_i)) continue;
           const int pos = __popcll(__ballot(key_less(ld, li, cd, ci)));
-          const double up_d = __shfl_up(ld, 1);
-          const int up_i = __shfl_up(li, 1);
+          const double up_d = shfl_up1_f64(ld);
+          const int up_i = shfl_up1_b32(li);
           if (lane > pos) {
             ld = up_d;
             li = up_i;
