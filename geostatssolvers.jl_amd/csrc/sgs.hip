@@ -267,6 +267,7 @@ struct gss_sgs {
   int64_t N = 0, nd = 0;
   double mean = 0.0;
   DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;
+  DevBuf field;  // node-major [N][R] working field of gss_sgs_realize, kept between calls (grows to the largest R seen)
 };
 
 extern "C" {
@@ -394,8 +395,12 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
   Staged sn, so;
   if (noise) GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(N * R), mem, s));
   GSS_TRY(so.out(out, sizeof(double) * (size_t)(N * R), mem));
-  DevBuf zt;
-  GSS_TRY(zt.alloc(sizeof(double) * (size_t)(N * R)));
+  // the working field is GBs (8 N R bytes): allocating and freeing it on every call costs more than a short sweep
+  if (h->field.bytes < sizeof(double) * (size_t)(N * R)) {
+    h->field.release();
+    GSS_TRY(h->field.alloc(sizeof(double) * (size_t)(N * R)));
+  }
+  DevBuf& zt = h->field;
   {
     ProfScope ps("sgs_noise", s);
     hipLaunchKernelGGL(sgs_noise_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real, N, R,
@@ -418,7 +423,7 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
                      zt.as<double>(), N, R, so.as<double>());
   GSS_HIP(hipGetLastError());
   GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
-  GSS_HIP(hipStreamSynchronize(s));  // zt is released on return
+  GSS_HIP(hipStreamSynchronize(s));
   return GSS_OK;
 }
 

@@ -259,7 +259,8 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
  *   maxneighbors <= 64; radius / inv_radii as gss_knn_search.  All realisations of a handle share the path.
  * gss_sgs_realize replaces solvesingle (seq.jl:76-141) for realisations first_real..first_real+nreals-1:
  *   z[node] = mean + sum_j lambda_j (z[nb_j] - mean) + sigma eps, eps = Philox normal (seed, realisation,
- *   cell) or noise[r * N + cell] when given.  out is nreals x N.
+ *   cell) or noise[r * N + cell] when given.  out is nreals x N.  The handle keeps its node-major working field
+ *   (8 N nreals bytes for the largest nreals seen) until gss_sgs_destroy.
  * gss_sgs_weights (test support): per node the neighbour list (N x k), the number of conditioning
  *   neighbours actually used (0 = marginal or data cell), the weights (N x k) and sigma (N). */
 int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
