@@ -140,6 +140,31 @@ def test_ball_search_and_minneighbors_missing():
     h.close()
 
 
+@pytest.mark.parametrize("variant,okw", [(K.UK, dict(degree=1)), (K.SK, dict(mean=0.3)), (K.OK, {})])
+def test_mixed_neighbour_counts_inside_a_workgroup(variant, okw):
+    """The moving-neighbourhood kernel works on four points per workgroup and shares the diagonal-tile factorisation
+    between their waves; with a search ball over samples of very uneven density neighbouring domain points get anything
+    from 0 to 64 neighbours (0 to 4 tile steps, `missing` points included) in the same workgroup, and the number of
+    points is not a multiple of four."""
+    from gss.engine import KrigHandle
+    gvg, ovg = _vgs("matern", range=30.0, nu=1.5, nugget=0.02)
+    rng = np.random.default_rng(4242)
+    x = np.vstack([rng.uniform(0, 100, (600, 3)), rng.normal(50.0, 4.0, (1400, 3)), rng.normal(20.0, 1.5, (500, 3))])
+    z = rng.normal(size=len(x)) + 0.01 * x[:, 0]
+    x0 = rng.uniform(-10, 110, (1003, 3))
+    h = KrigHandle(gvg, variant, x, z, mean=okw.get("mean"), degree=okw.get("degree"), factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, 64, minneighbors=6, radius=9.0, return_idx=True)
+    h.close()
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(variant, ovg, x, z, x0, 64, mean=okw.get("mean") or 0.0,
+                                               degree=okw.get("degree"), minneighbors=6, radius=9.0, return_idx=True)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and np.array_equal(st, rst)
+    tiles = (cnt + 15) // 16
+    assert set(np.unique(tiles[st == 0])) >= {1, 2, 3, 4} and (st == 1).sum() > 50 and cnt.min() == 0
+    ok = st == 0
+    assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-8 and np.max(np.abs(var[ok] - rvar[ok])) < 1e-8
+    assert np.all(np.isnan(mu[st != 0]))
+
+
 def test_k_equals_n_reproduces_global():
     from gss.engine import KrigHandle
     gvg, ovg = _vgs("matern", range=30.0, nu=1.5)
