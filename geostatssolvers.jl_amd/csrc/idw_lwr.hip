@@ -242,6 +242,71 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
 // ---------------------------------------------------------------------------------------------
 constexpr int EST_TILE = 1024;
 
+// The reference's default IDW -- every sample a neighbour (idw.jl:93), Euclidean distance, no ball, exponent 1 or 2 --
+// as a dedicated kernel: thread = estimation point, and the sample index is wave-uniform, so coordinates and values
+// arrive through the scalar cache into SGPRs (no LDS staging, no vector loads) and enter the VALU instructions as
+// scalar operands.  Seventeen vector instructions per sample and point: three differences, the squared distance,
+// its running minimum (idw.jl:137 returns the nearest distance), 1 / d from v_rsq_f64 (1 / d^2 from v_rcp_f64) with two
+// Newton steps, and the two sums.  A coincident sample turns the weight into NaN (0 * inf inside the Newton step): that
+// is detected once at the end, and only such points rescan the samples for the first zero distance (idw.jl:131-134).
+template <int DIM, bool E1>
+__global__ __launch_bounds__(256) void idw_all_fast_kernel(const double* __restrict__ xdata,
+                                                           const double* __restrict__ z, int n,
+                                                           const double* __restrict__ x0, int64_t m,
+                                                           double* __restrict__ mean_out,
+                                                           double* __restrict__ aux_out,
+                                                           uint8_t* __restrict__ status_out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < m;
+  double qc[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = live ? x0[p * DIM + a] : 0.0;
+  double sw = 0.0, swz = 0.0, dmin2 = __builtin_huge_val();
+#pragma unroll 8
+  for (int j = 0; j < n; ++j) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      const double t = xdata[(int64_t)j * DIM + a] - qc[a];
+      d2 = fma(t, t, d2);
+    }
+    dmin2 = fmin(dmin2, d2);
+    double y;
+    if (E1) {
+      y = __builtin_amdgcn_rsq(d2);
+      const double hh = 0.5 * d2;
+      y = fma(y, fma(-hh * y, y, 0.5), y);
+      y = fma(y, fma(-hh * y, y, 0.5), y);
+    } else {
+      y = __builtin_amdgcn_rcp(d2);
+      y = fma(y, fma(-d2, y, 1.0), y);
+      y = fma(y, fma(-d2, y, 1.0), y);
+    }
+    sw += y;
+    swz = fma(y, z[j], swz);
+  }
+  if (!live) return;
+  double mu = swz / sw, dist = gss_sqrt(dmin2);
+  if (!(sw < __builtin_huge_val())) {  // NaN (coincident sample) or overflow: the estimate is the first coincident value
+    for (int j = 0; j < n; ++j) {
+      double d2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        const double t = xdata[(int64_t)j * DIM + a] - qc[a];
+        d2 = fma(t, t, d2);
+      }
+      if (d2 == 0.0) {
+        mu = z[j];
+        dist = 0.0;
+        break;
+      }
+    }
+  }
+  mean_out[p] = mu;
+  aux_out[p] = dist;
+  status_out[p] = GSS_PT_OK;
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* __restrict__ xdata,
                                                       const double* __restrict__ z, int n,
@@ -404,6 +469,72 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
   status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
 }
 
+// The reference's default LWR -- every sample a neighbour (lwr.jl:96), Euclidean distance, no ball, weight
+// exp(-a delta^2) (lwr.jl:58 has a = 3) -- with the samples as scalar operands like idw_all_fast_kernel.  Sweep 1: the
+// farthest sample (lwr.jl:132 normalises by it); sweep 2: the weighted moments of lwr.jl:136-145; the weight needs no
+// square root because delta^2 = d^2 / dmax^2.
+template <int DIM>
+__global__ __launch_bounds__(256) void lwr_all_fast_kernel(double wa, const double* __restrict__ xdata,
+                                                           const double* __restrict__ z, int n,
+                                                           const double* __restrict__ x0, int64_t m,
+                                                           double* __restrict__ mean_out,
+                                                           double* __restrict__ aux_out,
+                                                           uint8_t* __restrict__ status_out) {
+  constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < m;
+  double qc[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = live ? x0[p * DIM + a] : 0.0;
+  double dmax2 = 0.0;
+#pragma unroll 8
+  for (int j = 0; j < n; ++j) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      const double t = xdata[(int64_t)j * DIM + a] - qc[a];
+      d2 = fma(t, t, d2);
+    }
+    dmax2 = fmax(dmax2, d2);
+  }
+  const double scale = -wa / dmax2;
+  double S1[NT], S2[NT], b[NP];
+#pragma unroll
+  for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < NP; ++e) b[e] = 0.0;
+#pragma unroll 2
+  for (int j = 0; j < n; ++j) {
+    double u[NP];
+    u[0] = 1.0;
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      u[a + 1] = xdata[(int64_t)j * DIM + a] - qc[a];
+      d2 = fma(u[a + 1], u[a + 1], d2);
+    }
+    const double w = gss_exp_poly(scale * d2);
+    const double w2 = w * w, wz = w * z[j];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      b[r] = fma(wz, u[r], b[r]);
+#pragma unroll
+      for (int q = 0; q <= r; ++q) {
+        const double t = u[r] * u[q];
+        S1[r * (r + 1) / 2 + q] = fma(w, t, S1[r * (r + 1) / 2 + q]);
+        S2[r * (r + 1) / 2 + q] = fma(w2, t, S2[r * (r + 1) / 2 + q]);
+      }
+    }
+  }
+  if (!live) return;
+  const double NaN = __builtin_nan("");
+  double mu, var;
+  const bool ok = (dmax2 > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  mean_out[p] = ok ? mu : NaN;
+  aux_out[p] = ok ? var : NaN;
+  status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+}
+
 static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int dim,
                              const double* x0, int64_t m, int k, int minneighbors, double radius,
                              const double* inv_radii_host, double* mean, double* aux, uint8_t* status,
@@ -421,6 +552,34 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
                                  "only maxneighbors = nothing (all %lld samples) is available", k, (long long)n);
     ProfScope ps(pname, s);
     dim3 grid((unsigned)((m + 255) / 256));
+    if (sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && (sp.exponent == 1.0 || sp.exponent == 2.0) &&
+        minneighbors <= n) {
+#define GSS_IDW_FAST(D)                                                                                               \
+  if (sp.exponent == 1.0)                                                                                            \
+    hipLaunchKernelGGL((idw_all_fast_kernel<D, true>), grid, dim3(256), 0, s, xdata, z, (int)n, x0, m, mean, aux,     \
+                       status);                                                                                      \
+  else                                                                                                               \
+    hipLaunchKernelGGL((idw_all_fast_kernel<D, false>), grid, dim3(256), 0, s, xdata, z, (int)n, x0, m, mean, aux,    \
+                       status)
+      switch (dim) {
+        case 1: GSS_IDW_FAST(1); break;
+        case 2: GSS_IDW_FAST(2); break;
+        default: GSS_IDW_FAST(3); break;
+      }
+#undef GSS_IDW_FAST
+      GSS_HIP(hipGetLastError());
+      return GSS_OK;
+    }
+    if (sp.method == 1 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && sp.wkind == GSS_WEIGHT_EXP && sp.wp == 2.0 &&
+        minneighbors <= n) {
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((lwr_all_fast_kernel<1>), grid, dim3(256), 0, s, sp.wa, xdata, z, (int)n, x0, m, mean, aux, status); break;
+        case 2: hipLaunchKernelGGL((lwr_all_fast_kernel<2>), grid, dim3(256), 0, s, sp.wa, xdata, z, (int)n, x0, m, mean, aux, status); break;
+        default: hipLaunchKernelGGL((lwr_all_fast_kernel<3>), grid, dim3(256), 0, s, sp.wa, xdata, z, (int)n, x0, m, mean, aux, status); break;
+      }
+      GSS_HIP(hipGetLastError());
+      return GSS_OK;
+    }
 #define GSS_EST_ALL_ARGS sp, xdata, z, (int)n, x0, m, minneighbors, r2, use_ball, aniso, ir[0], ir[1], ir[2], mean, \
                          aux, status
     switch (dim) {
