@@ -246,6 +246,8 @@ def cfg_sgs(a, gss, _lib):
     dl = np.sort(rng.choice(N, 200, replace=False))
     zd = rng.normal(size=200)
     vg = gss.SphericalVariogram(range=35.0)
+    SGSHandle(vg, cent[:20000], None, dl[dl < 20000], zd[dl < 20000], 0.0, 16, 1, 30.0).close()   # code objects loaded
+    sync()
     _lib.profile_reset(); _lib.profile_enable(True)
     t0 = time.perf_counter()
     h = SGSHandle(vg, cent, None, dl, zd, 0.0, 16, 1, 30.0)

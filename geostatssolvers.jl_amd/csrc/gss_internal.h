@@ -653,6 +653,9 @@ struct KnnIndex {
 };
 int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
 int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
+// the same ordering rule carried out on the device (knn_build.hip); used from KNN_DEVICE_BUILD_MIN samples
+int32_t knn_index_build_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s);
+constexpr int64_t KNN_DEVICE_BUILD_MIN = 16384;
 // rank / qrank / bminrank (all or none): masked search of sequential simulation, see knn.hip
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s,

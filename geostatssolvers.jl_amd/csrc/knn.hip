@@ -304,6 +304,10 @@ int32_t knn_index_build(const double* xhost, int64_t n, int dim, KnnIndex* ix, h
 }
 
 int32_t knn_index_build_from_device(const double* xdev, int64_t n, int dim, KnnIndex* ix, hipStream_t s) {
+  // large sets are ordered on the device (no copy back, no host sort); GSS_KNN_BUILD=host / device forces one path
+  const char* e = std::getenv("GSS_KNN_BUILD");
+  const bool dev = e ? (e[0] == 'd') : (n >= KNN_DEVICE_BUILD_MIN);
+  if (dev) return knn_index_build_device(xdev, n, dim, ix, s);
   std::vector<double> xh((size_t)(n * dim));
   GSS_HIP(hipMemcpyAsync(xh.data(), xdev, sizeof(double) * xh.size(), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));

@@ -337,7 +337,8 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
     GSS_HIP(hipMemcpyAsync(h->zd.p, zdata, h->zd.bytes, hipMemcpyHostToDevice, s));
   }
   KnnIndex ix;
-  GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
+  if (N >= KNN_DEVICE_BUILD_MIN) GSS_TRY(knn_index_build_device(cent.as<double>(), N, dim, &ix, s));  // already in HBM
+  else GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
   GSS_TRY(bmin.alloc(sizeof(int) * (size_t)ix.nb));
   hipLaunchKernelGGL(sgs_batch_minrank_kernel, dim3((unsigned)((ix.nb + 3) / 4)), dim3(256), 0, s, ix.perm.as<int>(),
                      h->rank.as<int>(), (int)N, ix.nb, bmin.as<int>());

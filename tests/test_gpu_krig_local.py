@@ -58,6 +58,27 @@ def test_knn_pruned_equals_brute_force_on_large_clustered_data(monkeypatch, dim,
         assert cnt.min() == 0 and cnt.max() == k
 
 
+@pytest.mark.parametrize("n,dim,k", [(3000, 3, 17), (70, 2, 5), (20000, 1, 9), (40000, 2, 33)])
+def test_knn_index_built_on_host_and_on_device_give_the_same_neighbours(monkeypatch, n, dim, k):
+    """The k-d ordering is an internal matter of the index: whether the host (nth_element) or the device (radix sort per
+    level, knn_build.hip) produced it, the neighbour lists equal the oracle's.  Lattice points (ties along every axis)
+    and exact duplicates included."""
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(n + k)
+    x = np.round(rng.uniform(0, 50, (n, dim)), 1)          # coarse lattice: many equal coordinates
+    x[: n // 10] = x[n // 10: 2 * (n // 10)]                # duplicates
+    c = rng.uniform(-5, 55, (600, dim))
+    ridx, rcnt = K.knn_search(x, c[:150], k)
+    for how in ("host", "device"):
+        monkeypatch.setenv("GSS_KNN_BUILD", how)
+        idx, cnt = HipEngine.knn_search(x, c, k)
+        assert np.array_equal(idx[:150], ridx) and np.array_equal(cnt[:150], rcnt), how
+        if how == "host":
+            first = idx
+        else:
+            assert np.array_equal(idx, first)
+
+
 def test_knn_few_queries_into_large_set_host_and_device():
     """m <= 4096 centres into n >= 32768 points takes the brute-force sweep (no host index build); same lists as the
     oracle ranking, and the same again when both point sets are CUDA tensors (the conditional-FFTGS cell lookup)."""
