@@ -202,7 +202,7 @@ static __device__ const double GSS_EXP2_TAB[64] = {
 };
 
 __device__ __forceinline__ double gss_exp(double x) {
-  x = x < -800.0 ? -800.0 : x;                             // exp underflows to 0 from -745.2 on; keeps n in int range
+  x = fmax(x, -800.0);                                     // exp underflows to 0 from -745.2 on; keeps n in int range
   const double n = __builtin_rint(x * 92.33248261689366);  // 64 / ln 2
   double r = fma(-n, 0.010830424493178725, x);             // ln2/64, 27 trailing bits cleared
   r = fma(-n, 2.030704202170295e-10, r);                    // ln2/64 - high part
@@ -219,7 +219,7 @@ __device__ __forceinline__ double gss_exp(double x) {
 // Table-free form for kernels that run few waves per SIMD (K5, SGS weights): a degree-13 polynomial costs four more
 // FMAs than the table lookup but no memory round trip.  Same 2.2e-16 maximum relative error.
 __device__ __forceinline__ double gss_exp_poly(double x) {
-  x = x < -800.0 ? -800.0 : x;
+  x = fmax(x, -800.0);
   const double n = __builtin_rint(x * 1.4426950408889634);
   double r = fma(-n, 6.93147180369123816490e-01, x);
   r = fma(-n, 1.90821492927058770002e-10, r);
