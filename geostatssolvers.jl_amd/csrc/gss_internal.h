@@ -573,11 +573,51 @@ __device__ __forceinline__ void cov_pair4(const VgDev& v, const double (*a)[DIM]
 }
 
 // KIND < 0: any model (the general functions above); otherwise one structure of device kind KIND, v.nextra == 0
+// KIND >= 0 (single structure): the coordinates arrive already divided by the radii of the structure's ball (the caller
+// scales each point once, krig_local.hip), so a pair costs three differences and one fused sum of squares instead of
+// a multiply and a select per coordinate; the square root runs on max(d2, 1e-300) without its zero guard (a zero lag
+// is replaced by the total sill afterwards anyway).  KIND < 0: any model, coordinates as they are.
+template <int KIND>
+__device__ __forceinline__ double vg_shape_kpos(double d2, double inv_range, double mscale, double pw) {
+  if (KIND == GSS_VG_GAUSSIAN) return gss_exp_poly(-3.0 * (d2 * inv_range * inv_range));
+  const double y = __builtin_amdgcn_rsq(d2);  // gss_sqrt without the zero guard
+  double sq = d2 * y;
+  const double hy = 0.5 * y;
+  sq = fma(fma(-sq, sq, d2), hy, sq);
+  sq = fma(fma(-sq, sq, d2), hy, sq);
+  if (KIND == GSS_VG_EXPONENTIAL) return gss_exp_poly(-3.0 * (sq * inv_range));
+  if (KIND == VG_MATERN12) return gss_exp_poly(-(mscale * (sq * inv_range)));
+  if (KIND == VG_MATERN32) {
+    const double d = mscale * (sq * inv_range);
+    return (1.0 + d) * gss_exp_poly(-d);
+  }
+  if (KIND == VG_MATERN52) {
+    const double d = mscale * (sq * inv_range);
+    return (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp_poly(-d);
+  }
+  if (KIND == GSS_VG_SPHERICAL) {
+    const double x = sq * inv_range;
+    return x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
+  }
+  return vg_shape(KIND, d2, inv_range, mscale, pw);
+}
+
+template <int DIM>
+__device__ __forceinline__ double sqdist_scaled(const double* a, const double* b) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const double t = a[k] - b[k];
+    acc = fma(t, t, acc);
+  }
+  return acc;
+}
+
 template <int DIM, int KIND>
 __device__ __forceinline__ double cov_pair_k(const VgDev& v, const double* a, const double* b) {
   if (KIND < 0) return cov_pair<DIM>(v, a, b);
-  const double d2 = sqdist_nofma<DIM>(a, b, v.ir, v.aniso != 0);
-  const double g = vg_shape_k<(KIND < 0 ? 0 : KIND)>(d2, v.inv_range, v.mscale, v.pw);
+  const double d2 = sqdist_scaled<DIM>(a, b);
+  const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2, 1e-300), v.inv_range, v.mscale, v.pw);
   return d2 <= 0.0 ? v.sill : v.cs * g;
 }
 
@@ -589,10 +629,10 @@ __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DI
   }
   double d2[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) d2[u] = sqdist_nofma<DIM>(a[u], b, v.ir, v.aniso != 0);
+  for (int u = 0; u < 4; ++u) d2[u] = sqdist_scaled<DIM>(a[u], b);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const double g = vg_shape_k<(KIND < 0 ? 0 : KIND)>(d2[u], v.inv_range, v.mscale, v.pw);
+    const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
     out[u] = d2[u] <= 0.0 ? v.sill : v.cs * g;
   }
 }

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
                                                              double* __restrict__ var_out,
                                                              uint8_t* __restrict__ status_out) {
   __shared__ double nx_[K5_WAVES][LMAX_K][3];
+  __shared__ double nxs_[K5_WAVES][LMAX_K][3];   // the same coordinates divided by the radii of the model's ball (KIND >= 0)
   __shared__ double colv_[K5_WAVES][2][LMAX_K];  // c0 column and data column, one entry per neighbour
   __shared__ int nidx_[K5_WAVES][LMAX_K];
   __shared__ signed char se[LMAX_NC][4];
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   double (*nx)[3] = nx_[wave];
+  double (*nxs)[3] = nxs_[wave];
   double (*colv)[LMAX_K] = colv_[wave];
   int* nidx = nidx_[wave];
   double (*G)[17] = G_[wave];
@@ -353,22 +355,27 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   }
   const int nc = sp.nc;
   const int g = lane >> 4, c = lane & 15;
-  double c0[DIM];
+  double c0[DIM], c0s[DIM];
 #pragma unroll
-  for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
+  for (int a = 0; a < DIM; ++a) {
+    c0[a] = x0[p * DIM + a];
+    c0s[a] = (KIND >= 0 && vg.aniso) ? c0[a] * vg.ir[a] : c0[a];
+  }
   {
     const bool act = lane < cnt;
     const int nj = act ? idx[p * k + lane] : 0;
-    double xj[DIM];
+    double xj[DIM], xjs[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
       xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
+      xjs[a] = (KIND >= 0 && vg.aniso) ? xj[a] * vg.ir[a] : xj[a];
       nx[lane][a] = xj[a];
+      nxs[lane][a] = xjs[a];
     }
     nidx[lane] = nj;
     double zz = act ? z[nj] : 0.0;
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-    colv[0][lane] = act ? cov_pair_k<DIM, KIND>(vg, xj, c0) : 0.0;
+    colv[0][lane] = act ? cov_pair_k<DIM, KIND>(vg, xjs, c0s) : 0.0;
     colv[1][lane] = act ? zz : 0.0;
     if (threadIdx.x == 0) {  // static indices only: a lane-indexed read would force the argument struct into scratch
 #pragma unroll
@@ -389,14 +396,14 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int a = 0; a < DIM; ++a) xr[r][a] = nx[16 * I + g + 4 * r][a];
+        for (int a = 0; a < DIM; ++a) xr[r][a] = nxs[16 * I + g + 4 * r][a];
 #pragma unroll
       for (int J = I; J < 4; ++J) {
         if (J < nt) {
           const int col = 16 * J + c;
           double xcol[DIM], v[4];
 #pragma unroll
-          for (int a = 0; a < DIM; ++a) xcol[a] = nx[col][a];
+          for (int a = 0; a < DIM; ++a) xcol[a] = nxs[col][a];
           cov_pair4_k<DIM, KIND>(vg, xr, xcol, v);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
