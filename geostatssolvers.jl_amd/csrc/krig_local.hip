@@ -342,7 +342,9 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   const bool inrange = pw < m;
   const int64_t p = inrange ? pw : m - 1;
   const double NaN = __longlong_as_double(0x7ff8000000000000LL);
-  int cnt = inrange ? count[p] : 0;
+  // wave-uniform by construction (one point per wave): telling the compiler turns the tile-count tests below into
+  // scalar branches instead of EXEC-masked regions
+  int cnt = __builtin_amdgcn_readfirstlane(inrange ? count[p] : 0);
   bool live = inrange;
   if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
     if (inrange && lane == 0) {
