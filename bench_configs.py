@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 2,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
+    python bench_configs.py [--configs 1h,2,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
 """
 import argparse
 import json
@@ -289,6 +289,40 @@ def cfg_sgs(a, gss, _lib):
                              "sample": "oracle.sgs.realize, one realisation of a %dx%d grid in %.1f s" % (ce, ce, cdt)}}
 
 
+def cfg1_host(a, gss, _lib):
+    """configs[1] with host buffers on both sides of the call (the second number, PCIe included):
+    coordinates staged host -> device, mean / variance / status copied back, per step as in bench.py."""
+    from gss.engine import KrigHandle, OK
+    n, m = 1000, (100_000 if a.quick else 1_000_000)
+    x = np.random.default_rng(2).uniform(0.0, 100.0, (n, 3))
+    z = np.random.default_rng(1002).normal(size=n)
+    x0 = np.random.default_rng(3).uniform(0.0, 100.0, (m, 3))
+    vg = gss.MaternVariogram(range=30.0, order=1.5)
+
+    def step(dom):
+        h = KrigHandle(vg, OK, x, z)
+        out = h.predict_global(dom)
+        sync()
+        h.close()
+        return out
+
+    step(x0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        mu, var, st = step(x0)
+    dt_host = (time.perf_counter() - t0) / 3
+    x0d = torch.as_tensor(x0, device="cuda")
+    step(x0d)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step(x0d)
+    dt_dev = (time.perf_counter() - t0) / 3
+    return {"config": "configs[1] OK, 1000 3-D data -> %d points, host arrays in / out (pageable memory)" % m,
+            "metric": "kriged points/s including PCIe", "value": round(m / dt_host, 1), "unit": "points/s",
+            "ms_per_step_host_buffers": round(dt_host * 1e3, 2), "ms_per_step_device_buffers": round(dt_dev * 1e3, 2),
+            "bytes_over_pcie_per_point": 24 + 17, "finite": bool(np.isfinite(mu).all())}
+
+
 def cfg_cond_fftgs(a, gss, _lib):
     """Section 8f.1 row: conditional FFTGS through the solver API (fft.jl:106-135,176-192): e^3 grid, exponential
     range 20, 1 000 conditioning points, global kriging of the data and of every unconditional realisation."""
@@ -324,7 +358,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 
