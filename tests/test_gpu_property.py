@@ -69,3 +69,58 @@ def test_moving_neighbourhood_kriging_matches_oracle(n, dim, var, k, m, seed, ki
     tol = 1e-6 if kind == "gaussian" else 1e-8
     assert np.all(np.abs(mu[ok] - rmu[ok]) < tol * np.maximum(1.0, np.abs(rmu[ok])))
     assert np.all(np.abs(var_[ok] - rvar[ok]) < tol)
+
+
+@settings(**SET)
+@given(st.integers(3, 420), st.integers(1, 3), st.sampled_from([(K.SK, {}), (K.OK, {}), (K.UK, dict(degree=1)),
+                                                                 (K.UK, dict(degree=2))]),
+       st.integers(1, 3000), st.integers(0, 10_000), st.sampled_from(["exponential", "matern", "spherical"]))
+def test_global_kriging_matches_oracle(n, dim, var, m, seed, kind):
+    """Every padding of the factor (n + nc against the 16- and 128-row tiles), launches of whole rounds and of split
+    tails only, all kriging variants."""
+    from gss.engine import KrigHandle
+    import gss
+    variant, okw = var
+    nc = 0 if variant == K.SK else (1 if variant == K.OK else {1: dim + 1, 2: (dim + 1) * (dim + 2) // 2}[okw["degree"]])
+    if n < nc + 3:
+        n = nc + 3
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 100, (n, dim))
+    if dim == 1:
+        x = (np.linspace(0, 100, n) + rng.uniform(-0.1, 0.1, n))[:, None]
+    z = rng.normal(size=n) + 0.01 * x[:, 0]
+    gv = dict(exponential=gss.ExponentialVariogram, matern=gss.MaternVariogram,
+              spherical=gss.SphericalVariogram)[kind](range=35.0, nugget=0.02)
+    ov = Variogram(kind, range=35.0, nugget=0.02)
+    x0 = rng.uniform(0, 100, (m, dim))
+    x0[0] = x[0]
+    h = KrigHandle(gv, variant, x, z, mean=0.2 if variant == K.SK else None, degree=okw.get("degree"))
+    mu, var_, st_ = h.predict_global(x0)
+    h.close()
+    rmu, rvar = K.exactsolve(variant, ov, x, z, x0, mean=0.2, degree=okw.get("degree"))
+    assert not st_.any()
+    assert np.max(np.abs(mu - rmu)) < 1e-8 * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var_ - rvar)) < 1e-8
+
+
+@settings(**SET)
+@given(st.integers(2, 300), st.integers(1, 3), st.integers(1, 64), st.integers(1, 60), st.integers(0, 10_000),
+       st.sampled_from([1.0, 2.0, 0.7]), st.booleans())
+def test_idw_lwr_match_oracle(n, dim, k, m, seed, exponent, all_samples):
+    from gss.engine import HipEngine
+    from oracle import idw_lwr as E
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 100, (n, dim))
+    z = rng.normal(size=n)
+    kk = None if all_samples else min(k, n)
+    c = np.vstack([x[:1], rng.uniform(0, 100, (m, dim))])
+    mu, sd, st_ = HipEngine.idw(x, z, c, n if kk is None else kk, 1, exponent)
+    rmu, rsd, rst = E.idw(x, z, c, kk, 1, exponent)
+    assert np.array_equal(st_, rst) and np.allclose(mu, rmu, rtol=1e-10, atol=1e-12) and np.allclose(sd, rsd, rtol=1e-12, atol=1e-12)
+    assert mu[0] == z[0] and sd[0] == 0.0                     # idw.jl:131-134
+    if n >= dim + 2:
+        lmu, lvar, lst = HipEngine.lwr(x, z, c, n if kk is None else max(kk, min(n, dim + 2)), 1, (0, 3.0, 2.0))
+        rlmu, rlvar, rlst = E.lwr(x, z, c, None if kk is None else max(kk, min(n, dim + 2)), 1)
+        ok = (lst == 0) & (rlst == 0)
+        assert np.array_equal(lst == 1, rlst == 1)
+        scale = np.maximum(1.0, np.abs(rlmu[ok]))
+        assert np.all(np.abs(lmu[ok] - rlmu[ok]) < 1e-6 * scale)
