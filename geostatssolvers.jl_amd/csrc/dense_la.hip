@@ -27,6 +27,7 @@ struct GemmArgs {
   double* D;
   int64_t sd_i, sd_j;
   int lower_only;
+  int tri;  // zero structure of an operand, so that k-tiles that only meet zeros are skipped (GEMM_TRI_*)
   int vec;  // both operands contiguous along their tile edge, 16-byte aligned, K a multiple of BK: interior tiles may
             // stage with 16-byte loads
 };
@@ -35,6 +36,13 @@ struct GemmArgs {
 // are coalesced along whichever index is contiguous.  Two tile shapes: 128 x 128 (4 waves x 4x4 MFMA tiles) for
 // large problems and 64 x 64 (4 waves x 2x2 MFMA tiles) for the many small products of the recursions, where a
 // 128-tile grid would leave most CUs idle and waste 3/4 of the matrix work on padding.
+// B(k, j) = 0 for k > j (the transpose of a lower-triangular factor): columns j0.. need k < j0 + T only
+constexpr int GEMM_TRI_B_UPPER = 1;
+// B(k, j) = 0 for k < j (a lower-triangular factor): columns j0.. need k >= j0 only
+constexpr int GEMM_TRI_B_LOWER = 2;
+// A(i, k) = 0 for k > i (a lower-triangular factor on the left): rows i0.. need k < i0 + T only
+constexpr int GEMM_TRI_A_LOWER = 4;
+
 template <int T>
 struct GemmTile {
   static constexpr int TILE = T;             // workgroup tile edge
@@ -55,8 +63,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t i0 = (int64_t)blockIdx.y * T;
-  const int64_t j0 = (int64_t)blockIdx.x * T;
+  // Workgroups reach the CUs in launch order, a CU's next workgroup waits for that CU (measured: a launch whose cost
+  // varies with the FAST block index takes as long as if every workgroup had the maximum cost).  When the k-range
+  // depends on the column tile the row tile is therefore the fast index, and the expensive columns go first.
+  // For the same reason a lower-tiles-only product is launched as a 1-D grid over the tiles that exist (block
+  // triangle, then the full rows below it), not as a 2-D grid whose upper workgroups exit at once.
+  const bool by_col = (g.tri & (GEMM_TRI_B_UPPER | GEMM_TRI_B_LOWER)) != 0;
+  int64_t bx = by_col ? blockIdx.y : blockIdx.x, by = by_col ? blockIdx.x : blockIdx.y;
+  const int64_t ncol = by_col ? gridDim.y : gridDim.x;
+  if (g.lower_only) {
+    const int64_t tn = (g.N + T - 1) / T, tm = (g.M + T - 1) / T;
+    const int64_t d = tm < tn ? tm : tn, ntri = d * (d + 1) / 2;
+    const int64_t L = blockIdx.x;
+    if (L < ntri) {
+      by = (int64_t)((__builtin_sqrt(8.0 * (double)L + 1.0) - 1.0) * 0.5);
+      while (by * (by + 1) / 2 > L) --by;            // the square root may be one off either way
+      while ((by + 1) * (by + 2) / 2 <= L) ++by;
+      bx = L - by * (by + 1) / 2;
+    } else {
+      by = tn + (L - ntri) / tn;
+      bx = (L - ntri) % tn;
+    }
+  }
+  const int64_t i0 = by * T;
+  const int64_t j0 = ((g.tri & GEMM_TRI_B_UPPER) ? ncol - 1 - bx : bx) * T;
   if (g.lower_only && j0 > i0 + T - 1) return;
 
   // staging map of this thread: NLOAD elements of each operand tile per stage
@@ -131,13 +161,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
 #pragma unroll
     for (int tn = 0; tn < G::WT; ++tn) acc[tm][tn] = d4{0.0, 0.0, 0.0, 0.0};
   const int lr = lane & 15, lk = lane >> 4;
-  const int64_t ntile = (g.K + BK - 1) / BK;
-  if (ntile > 0) {
-    load_stage(0);
-    store_stage(0);
+  int64_t kend = g.K, kbeg = 0;
+  if ((g.tri & GEMM_TRI_B_UPPER) && j0 + T < kend) kend = j0 + T;
+  if ((g.tri & GEMM_TRI_A_LOWER) && i0 + T < kend) kend = i0 + T;
+  if (g.tri & GEMM_TRI_B_LOWER) kbeg = j0 < g.K ? j0 : g.K;   // j0 is a multiple of T, hence of BK
+  const int64_t t0 = kbeg / BK;
+  const int64_t ntile = (kend + BK - 1) / BK;
+  if (ntile > t0) {
+    load_stage(t0 * BK);
+    store_stage((int)(t0 & 1));
   }
   __syncthreads();
-  for (int64_t t = 0; t < ntile; ++t) {
+  for (int64_t t = t0; t < ntile; ++t) {
     const int cur = (int)(t & 1);
     const bool more = (t + 1) < ntile;
     if (more) load_stage((t + 1) * BK);
@@ -188,7 +223,13 @@ static int32_t gemm_launch(const GemmArgs& g, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmTile<T>::LDS_BYTES));
     attr = true;
   }
-  dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T));
+  const unsigned tn = (unsigned)((g.N + T - 1) / T), tm = (unsigned)((g.M + T - 1) / T);
+  const bool by_col = (g.tri & (GEMM_TRI_B_UPPER | GEMM_TRI_B_LOWER)) != 0;   // see the kernel: row tile = fast index
+  dim3 grid(by_col ? tm : tn, by_col ? tn : tm);
+  if (g.lower_only) {
+    const unsigned d = tm < tn ? tm : tn;
+    grid = dim3(d * (d + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0));
+  }
   hipLaunchKernelGGL((gemm_f64_generic_kernel<T, AI, BJ>), grid, dim3(256), GemmTile<T>::LDS_BYTES, s, g);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
@@ -204,9 +245,9 @@ static int32_t gemm_dispatch(const GemmArgs& g, bool ai, bool bj, hipStream_t s)
 
 int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
                  const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
-                 int64_t sd_j, bool lower_only, hipStream_t s) {
+                 int64_t sd_j, bool lower_only, hipStream_t s, int tri) {
   if (M <= 0 || N <= 0) return GSS_OK;
-  GemmArgs g{M, N, K, alpha, beta, A, sa_i, sa_k, B, sb_k, sb_j, D, sd_i, sd_j, lower_only ? 1 : 0, 0};
+  GemmArgs g{M, N, K, alpha, beta, A, sa_i, sa_k, B, sb_k, sb_j, D, sd_i, sd_j, lower_only ? 1 : 0, tri, 0};
   g.vec = (sa_i == 1 && sb_j == 1 && K % BK == 0 && sa_k % 2 == 0 && sb_k % 2 == 0 &&
            reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0)
               ? 1
@@ -643,12 +684,12 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
   double* L21 = scr;            // n2 x n1, column-major, ld n2
   double* T2 = scr + n1 * n2;   // n2 x n1
   double* rest = T2 + n1 * n2;
-  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, A21, 1, lda, W, ldw, 1, 0.0, L21, 1, n2, false, s));
+  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, A21, 1, lda, W, ldw, 1, 0.0, L21, 1, n2, false, s, GEMM_TRI_B_UPPER));
   if (keep_L) GSS_TRY(copy_block(L21, n2, n2, n1, A21, lda, s));
   GSS_TRY(gemm_f64(n2, n2, n1, -1.0, L21, 1, n2, L21, n2, 1, 1.0, A22, 1, lda, true, s));
   GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, keep_L, s));
-  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, n2, W, 1, ldw, 0.0, T2, 1, n2, false, s));
-  GSS_TRY(gemm_f64(n2, n1, n2, -1.0, W22, 1, ldw, T2, 1, n2, 0.0, W21, 1, ldw, false, s));
+  GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, n2, W, 1, ldw, 0.0, T2, 1, n2, false, s, GEMM_TRI_B_LOWER));
+  GSS_TRY(gemm_f64(n2, n1, n2, -1.0, W22, 1, ldw, T2, 1, n2, 0.0, W21, 1, ldw, false, s, GEMM_TRI_A_LOWER));
   return GSS_OK;
 }
 
@@ -684,7 +725,7 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     if (m2 > 0) {
       double* Ap = Akk + nb;                 // rows below the diagonal block
       double* A22 = Akk + nb + nb * lda;
-      GSS_TRY(gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s));
+      GSS_TRY(gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s, GEMM_TRI_B_UPPER));
       GSS_TRY(copy_block(P, m2, m2, nb, Ap, lda, s));
       GSS_TRY(gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s));
     }
@@ -731,8 +772,9 @@ int32_t gss_dev_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double
                      const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
                      int64_t sd_j, int32_t lower_only, void* stream) {
   GSS_REQUIRE(A && B && D && M >= 0 && N >= 0 && K >= 0, "gss_dev_gemm: bad arguments");
-  return gemm_f64(M, N, K, alpha, A, sa_i, sa_k, B, sb_k, sb_j, beta, D, sd_i, sd_j, lower_only != 0,
-                  to_stream(stream));
+  // bit 0: lower tiles only; bits 1..3: zero structure of an operand (GEMM_TRI_* << 1), test support
+  return gemm_f64(M, N, K, alpha, A, sa_i, sa_k, B, sb_k, sb_j, beta, D, sd_i, sd_j, (lower_only & 1) != 0,
+                  to_stream(stream), (lower_only >> 1) & 7);
 }
 
 }  // extern "C"

@@ -643,7 +643,9 @@ __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DI
 // D(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * D(i,j), arbitrary element strides.
 int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
                  const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
-                 int64_t sd_j, bool lower_only, hipStream_t s);
+                 int64_t sd_j, bool lower_only, hipStream_t s, int tri = 0);
+// `tri`: zero structure of an operand (k-tiles that only meet zeros are skipped): 1 = B(k,j) = 0 for k > j,
+// 2 = B(k,j) = 0 for k < j, 4 = A(i,k) = 0 for k > i (GEMM_TRI_* in dense_la.hip)
 // y = op(A) x for column-major A (m x n, lda); trans: y = A' x.  work: gemv_work_doubles(trans, m, n) doubles.
 int64_t gemv_work_doubles(bool trans, int64_t m, int64_t n);
 int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda, const double* x, double* y,

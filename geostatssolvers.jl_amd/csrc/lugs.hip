@@ -164,7 +164,7 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
       GSS_TRY(check_info(info, "data covariance C11", s));
       // A21 = C21 * inv(L11)'  (= B12', lu.jl:135)
       GSS_TRY(gemm_f64(ns, nd, nd, 1.0, C21.as<double>(), 1, ns, W11.as<double>(), nd, 1, 0.0, A21.as<double>(), 1, ns,
-                       false, s));
+                       false, s, 1 /* W11' is upper triangular: half of the k-tiles are skipped */));
       // w = L11 \ z1 = W11 z1,  d2 = A21 w                                                               // :138
       GSS_TRY(gemv_f64(false, nd, nd, W11.as<double>(), nd, h->z1.as<double>(), w.as<double>(), gwork.as<double>(), s));
       GSS_TRY(gemv_f64(false, ns, nd, A21.as<double>(), ns, w.as<double>(), h->d2(), gwork.as<double>(), s));
