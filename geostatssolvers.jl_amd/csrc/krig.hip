@@ -128,11 +128,9 @@ static void launch_krig_rhs(dim3 grid, hipStream_t s, const VgDev& vg, const dou
 // contributes.  Global -> register -> LDS staging is double buffered: one barrier per BK stage.
 constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 
-// SPLIT: one workgroup per (strip, row block I) instead of one per strip.  Block ids are mapped so that the
-// row blocks of a strip run on ONE XCD at about the same time (ids b and b + 8 share an XCD): the strip's R
-// tile is then fetched from HBM once and re-read from that XCD's L2 / the Infinity Cache by the other row
-// blocks, instead of 4.6 times from HBM.  Partial column sums go to qpart[I][p]; krig_finish_kernel adds them
-// in fixed order.  Heavy row blocks (large I) are issued first.
+// SPLIT: one workgroup per (strip, row block I) instead of one per strip.  The row block is the slow block index,
+// heaviest first, so that the workgroups in flight at any time cost the same (see the kernel); a strip's units keep
+// one XCD.  Partial column sums go to qpart[I][p]; krig_finish_kernel adds them in fixed order.
 template <bool W14, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
@@ -152,11 +150,14 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   int64_t strip = blockIdx.x;  // strips strip0 .. strip0 + nstrips - 1 belong to this launch
   int Ibeg = 0, Iend = nI;
   if (SPLIT) {
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    strip = (int64_t)(slot / nI) * 8 + xcd;
+    // The row block is the SLOW index (heaviest first) and the strip the fast one: workgroups reach the CUs in launch
+    // order, so costs that alternate along the fast index pile the expensive units onto the same CUs (dense_la.hip).
+    // The launch pads the strips to a multiple of 8, hence blockIdx.x % 8 == strip % 8: the units of one strip still
+    // share an XCD.
+    const int per = (int)(gridDim.x / nI);
+    strip = blockIdx.x % per;
     if (strip >= nstrips) return;
-    Ibeg = nI - 1 - (slot % nI);
+    Ibeg = nI - 1 - (int)(blockIdx.x / per);
     Iend = Ibeg + 1;
   }
   const int64_t p0 = (strip0 + strip) * BN;
@@ -785,7 +786,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   const int dim = h->dim;
 
   static bool attr_set = false;
-  static int split = 0;    // 0: one workgroup per strip (default); 1: per (strip, row block), XCD-aware ids -- measured 24 % slower
+  static int split = 0;    // 0: one workgroup per strip (default); 1: per (strip, row block) for every strip -- 2 % slower than the hybrid (24 % before the row block became the slow block index)
   static int variant = 1;  // 1: 1 x 4 waves with zero-tile skipping in the diagonal block (default); 0: 2 x 2 waves
   if (!attr_set) {
     GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, false>),
