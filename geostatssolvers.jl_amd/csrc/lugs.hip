@@ -265,7 +265,8 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
   if (ns) {
     ProfScope ps("lugs_gemm", s);
     // Y2 (ns x R, column-major) = L22 * W                                                      // lu.jl:211
-    GSS_TRY(gemm_f64(ns, R, ns, 1.0, h->L22(), 1, ns, weff, 1, ns, 0.0, Y2.as<double>(), 1, ns, false, s));
+    GSS_TRY(gemm_f64(ns, R, ns, 1.0, h->L22(), 1, ns, weff, 1, ns, 0.0, Y2.as<double>(), 1, ns, false, s,
+                     4 /* L22 is lower triangular: row tile i0 needs k < i0 + T only */));
   }
   const double add = nd == 0 ? h->mean : 0.0;                                                   // lu.jl:221
   hipLaunchKernelGGL(lugs_scatter_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)R), dim3(256), 0, s,
