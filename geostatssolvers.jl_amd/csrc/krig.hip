@@ -123,6 +123,90 @@ static void launch_krig_rhs(dim3 grid, hipStream_t s, const VgDev& vg, const dou
 #undef GSS_K1_LAUNCH
 }
 
+// Means only, for up to BATCH_NB data vectors at once (conditional simulation: fft.jl:125,187 krige the data and every
+// unconditional realisation at the same locations and use the means only):  out(b, p) = sum_k WD(k, b) R(k, p)  without
+// ever writing R.  Thread = domain point; the data index is wave-uniform, so x_j and the BATCH_NB dual weights of row j
+// come through the scalar cache and enter the FMAs as scalar operands; drift rows are added the same way.
+constexpr int BATCH_NB = 16;
+
+template <int DIM, int KIND>
+__global__ __launch_bounds__(256) void krig_batch_mean_kernel(VgDev vg, DriftSpec ds, const double* __restrict__ xd, int n,
+                                                              const double* __restrict__ x0, int64_t m,
+                                                              const double* __restrict__ WDt, int nb, double add,
+                                                              double* __restrict__ out, int64_t ldo) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < m;
+  const int64_t pc = live ? p : m - 1;
+  double c[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) c[k] = x0[pc * DIM + k];
+  double acc[BATCH_NB];
+#pragma unroll
+  for (int b = 0; b < BATCH_NB; ++b) acc[b] = 0.0;
+#pragma unroll 2
+  for (int j = 0; j < n; ++j) {
+    double x[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
+    double cv;
+    if (KIND < 0) {
+      cv = cov_pair<DIM>(vg, x, c);
+    } else {
+      const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
+      cv = d2 <= 0.0 ? vg.sill : vg.cs * vg_shape(KIND < 0 ? 0 : KIND, d2, vg.inv_range, vg.mscale, vg.pw);
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH_NB; ++b) acc[b] = fma(cv, WDt[(int64_t)j * BATCH_NB + b], acc[b]);
+  }
+  if (ds.nc > 0) {
+    double xs[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) xs[k] = (c[k] - ds.center[k]) * ds.inv_scale[k];
+    for (int r = 0; r < ds.nc; ++r) {
+      double f = 1.0;
+      if (ds.variant == GSS_KRIG_UNIVERSAL) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          for (int q = 0; q < ds.e[r][k]; ++q) f *= xs[k];
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH_NB; ++b) acc[b] = fma(f, WDt[(int64_t)(n + r) * BATCH_NB + b], acc[b]);
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int b = 0; b < BATCH_NB; ++b)
+    if (b < nb) out[(int64_t)b * ldo + p] = acc[b] + add;
+}
+
+// WDt[k][b] = WD(k, b) for b < nb, 0 up to BATCH_NB: the weights of one row side by side for the scalar loads
+__global__ __launch_bounds__(256) void wd_rows_kernel(const double* __restrict__ WD, int64_t ldw, int N1, int nb,
+                                                      double* __restrict__ WDt) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N1) return;
+#pragma unroll
+  for (int b = 0; b < BATCH_NB; ++b) WDt[(int64_t)k * BATCH_NB + b] = b < nb ? WD[k + (int64_t)b * ldw] : 0.0;
+}
+
+template <int DIM>
+static void launch_krig_batch_mean(hipStream_t s, const VgDev& vg, const DriftSpec& ds, const double* xd, int n,
+                                   const double* x0, int64_t m, const double* WDt, int nb, double add, double* out,
+                                   int64_t ldo) {
+  const dim3 grid((unsigned)((m + 255) / 256));
+#define GSS_BM_LAUNCH(KIND)                                                                                          \
+  hipLaunchKernelGGL((krig_batch_mean_kernel<DIM, KIND>), grid, dim3(256), 0, s, vg, ds, xd, n, x0, m, WDt, nb, add, \
+                     out, ldo)
+  switch (vg.nextra == 0 ? vg.kind : -1) {
+    case GSS_VG_GAUSSIAN: GSS_BM_LAUNCH(GSS_VG_GAUSSIAN); break;
+    case GSS_VG_EXPONENTIAL: GSS_BM_LAUNCH(GSS_VG_EXPONENTIAL); break;
+    case GSS_VG_SPHERICAL: GSS_BM_LAUNCH(GSS_VG_SPHERICAL); break;
+    case VG_MATERN32: GSS_BM_LAUNCH(VG_MATERN32); break;
+    case VG_MATERN52: GSS_BM_LAUNCH(VG_MATERN52); break;
+    default: GSS_BM_LAUNCH(-1); break;
+  }
+#undef GSS_BM_LAUNCH
+}
+
 // K3.  One workgroup owns a strip of BN = 128 points and walks the row blocks I of W' (lower
 // triangular, column-major, zero padded to ldw x N1pad).  For row block I only k < (I+1)*BM
 // contributes.  Global -> register -> LDS staging is double buffered: one barrier per BK stage.
@@ -958,33 +1042,20 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
                    false, s));
   GSS_HIP(hipGetLastError());
 
-  const int64_t mc = krig_chunk_points(h->N1pad, m);
-  double *Rws = nullptr, *mpart = nullptr;
-  GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
-  const int64_t ldr = mc;
-  const int seg_len = (int)((n + NSEG - 1) / NSEG);
-  for (int64_t off = 0; off < m; off += mc) {
-    const int64_t mv = (m - off) < mc ? (m - off) : mc;
-    const int64_t cols = round_up(mv, 256);
-    const double* x0 = sx.as<double>() + off * dim;
-    const int nblk = (int)(cols / 256);
-    dim3 g1((unsigned)(nblk * NSEG));
+  // out(b, p) = sum_k WD(k, b) R(k, p), sixteen data vectors per pass, R never materialised
+  const double add = (h->variant == GSS_KRIG_SIMPLE) ? h->sk_mean : 0.0;
+  DevBuf WDt;
+  GSS_TRY(WDt.alloc(sizeof(double) * (size_t)(N1 * BATCH_NB)));
+  for (int64_t b0 = 0; b0 < nbatch; b0 += BATCH_NB) {
+    const int nb = (int)((nbatch - b0) < BATCH_NB ? (nbatch - b0) : BATCH_NB);
+    hipLaunchKernelGGL(wd_rows_kernel, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, s, WD.as<double>() + b0 * ldw, ldw,
+                       (int)N1, nb, WDt.as<double>());
     switch (dim) {
-      case 1: launch_krig_rhs<1>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
-      case 2: launch_krig_rhs<2>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
-      default: launch_krig_rhs<3>(g1, s, h->vg, h->xdata.as<double>(), (int)n, x0, mv, Rws, ldr, seg_len, nblk); break;
+      case 1: launch_krig_batch_mean<1>(s, h->vg, h->ds, h->xdata.as<double>(), (int)n, sx.as<double>(), m, WDt.as<double>(), nb, add, so.as<double>() + b0 * m, m); break;
+      case 2: launch_krig_batch_mean<2>(s, h->vg, h->ds, h->xdata.as<double>(), (int)n, sx.as<double>(), m, WDt.as<double>(), nb, add, so.as<double>() + b0 * m, m); break;
+      default: launch_krig_batch_mean<3>(s, h->vg, h->ds, h->xdata.as<double>(), (int)n, sx.as<double>(), m, WDt.as<double>(), nb, add, so.as<double>() + b0 * m, m); break;
     }
     GSS_HIP(hipGetLastError());
-    const int nrows = (int)(h->N1pad - n);
-    if (nrows > 0)
-      GSS_TRY(launch_drift_rows(h, x0, nullptr, mv, cols, Rws + n * ldr, ldr, nrows, s));
-    // out(b, off + p) = sum_k WD(k, b) R(k, p)
-    GSS_TRY(gemm_f64(nbatch, mv, N1, 1.0, WD.as<double>(), ldw, 1, Rws, ldr, 1, 0.0,
-                     so.as<double>() + off, m, 1, false, s));
-  }
-  if (h->variant == GSS_KRIG_SIMPLE && h->sk_mean != 0.0) {
-    hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)((nbatch * m + 255) / 256)), dim3(256), 0, s,
-                       so.as<double>(), nbatch * m, h->sk_mean);
   }
   GSS_HIP(hipGetLastError());
   GSS_TRY(so.back(mean_out, sizeof(double) * (size_t)(nbatch * m), mem, s));

@@ -367,7 +367,8 @@ class FFTGS(_Solver):
                         raise AssertionError(f"all samples of {var} are missing, aborting...")
                     kh = self.engine.Krig(vg, SK, xd[keep], zd[keep], mean=p["mean"])
                     try:
-                        zbar = kh.predict_global(cdev)[0]
+                        # only the mean is used (fft.jl:126): the batched means-only path, no quadratic form
+                        zbar = kh.predict_global_batch(cdev, torch.as_tensor(zd[keep][None, :], device="cuda"))[0]
                     finally:
                         kh.close()
                     idx, _ = self.engine.knn_search(cdev, torch.as_tensor(xd, device="cuda"), 1)
