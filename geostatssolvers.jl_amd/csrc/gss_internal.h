@@ -701,8 +701,9 @@ constexpr int64_t KNN_DEVICE_BUILD_MIN = 16384;
 // rank / qrank / bminrank (all or none): masked search of sequential simulation, see knn.hip
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s,
-                           const int* rank = nullptr, const int* qrank = nullptr, const int* bminrank = nullptr);
-// metric != GSS_METRIC_EUCLIDEAN: exhaustive kernel (no box bounds for those keys), balls not allowed
+                           const int* rank = nullptr, const int* qrank = nullptr, const int* bminrank = nullptr,
+                           int metric = 0 /* Euclidean, Cityblock or Chebyshev */);
+// Haversine: exhaustive kernel (no box bounds for that key); non-Euclidean metrics do not combine with balls
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
                        int metric = 0);

@@ -594,7 +594,7 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
 
   const int64_t chunk = 1 << 20;
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call (Euclidean / Mahalanobis search only)
-  const bool use_index = sp.metric == GSS_METRIC_EUCLIDEAN;
+  const bool use_index = sp.metric != GSS_METRIC_HAVERSINE;
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s;
   GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
@@ -605,7 +605,7 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
       ProfScope ps("knn", s);
       if (use_index)
         GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
-                                   cnt_s.as<int>(), s));
+                                   cnt_s.as<int>(), s, nullptr, nullptr, nullptr, sp.metric));
       else
         GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
                                cnt_s.as<int>(), s, sp.metric));

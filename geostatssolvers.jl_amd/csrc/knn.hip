@@ -332,10 +332,29 @@ __device__ __forceinline__ double box_sqdist_nofma(const double* lo, const doubl
   return acc;
 }
 
+// Lower bound of the search key between a query and any point of a box, per metric: the per-axis gap
+// max(lo - q, q - hi, 0) never exceeds |x - q| for lo <= x <= hi (floating-point subtraction is monotone and
+// antisymmetric), and it is accumulated with the same operation, in the same order, as the key itself.
+template <int DIM, int METRIC>
+__device__ __forceinline__ double box_key(const double* lo, const double* hi, const double* q, const double* ir, bool aniso) {
+#pragma clang fp contract(off)
+  if (METRIC == GSS_METRIC_EUCLIDEAN) return box_sqdist_nofma<DIM>(lo, hi, q, ir, aniso);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {
+    const double a = lo[k] - q[k], b = q[k] - hi[k];
+    double t = a > b ? a : b;
+    t = t > 0.0 ? t : 0.0;
+    if (METRIC == GSS_METRIC_CITYBLOCK) acc = acc + t;
+    else acc = t > acc ? t : acc;
+  }
+  return acc;
+}
+
 // MASKED (sequential simulation, seq.jl:105 `search!(..., mask=simulated)`): a sample qualifies only if its
 // visiting rank is lower than the query's (rank[] per original index, qrank[] per query, bminrank[] = lowest
 // rank inside each batch so that batches with nothing simulated yet are skipped).
-template <int DIM, bool MASKED>
+template <int DIM, bool MASKED, int METRIC = GSS_METRIC_EUCLIDEAN>
 __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restrict__ xs, const int* __restrict__ perm,
                                                          const double* __restrict__ blo, const double* __restrict__ bhi,
                                                          const double* __restrict__ blo1,
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
         lo[a] = blo1[g * DIM + a];
         hi[a] = bhi1[g * DIM + a];
       }
-      d1 = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
+      d1 = box_key<DIM, METRIC>(lo, hi, qc, ir, aniso != 0);
     }
     bool done1 = !(g < nb1);
     while (true) {
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
           lo[a] = blo[b * DIM + a];
           hi[a] = bhi[b * DIM + a];
         }
-        dmin = box_sqdist_nofma<DIM>(lo, hi, qc, ir, aniso != 0);
+        dmin = box_key<DIM, METRIC>(lo, hi, qc, ir, aniso != 0);
         if (MASKED && !(bminrank[b] < myrank)) done = true;
       }
       while (true) {
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
 #pragma unroll
         for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
         const int oidx = valid ? perm[j] : INT_MAX;
-        const double d2 = sqdist_nofma<DIM>(c, qc, ir, aniso != 0);
+        const double d2 = metric_key<DIM, METRIC>(c, qc, ir, aniso != 0);
         bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
         if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
         unsigned long long qm = __ballot(qual);
@@ -451,7 +470,7 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
 
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s, const int* rank,
-                           const int* qrank, const int* bminrank) {
+                           const int* qrank, const int* bminrank, int metric) {
   GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
                                  "(use the global neighbourhood beyond that)", k);
   if (m <= 0) return GSS_OK;
@@ -465,12 +484,27 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
 #define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), \
                      ix.lo1.as<double>(), ix.hi1.as<double>(), (int)ix.n, ix.nb, ix.nb1, \
                      centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count
+  GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV,
+              "the indexed search has box bounds for the Euclidean, Cityblock and Chebyshev keys only");
   if (rank) {
+    GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN, "the masked search is Euclidean");
     GSS_REQUIRE(qrank && bminrank, "masked search needs query ranks and per-batch minimum ranks");
     switch (ix.dim) {
       case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
       case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
       default: hipLaunchKernelGGL((knn_pruned_kernel<3, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    }
+  } else if (metric == GSS_METRIC_CITYBLOCK) {
+    switch (ix.dim) {
+      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+    }
+  } else if (metric == GSS_METRIC_CHEBYSHEV) {
+    switch (ix.dim) {
+      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
+      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
     }
   } else {
     switch (ix.dim) {
@@ -534,10 +568,10 @@ int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* ce
   // few queries into a large set (e.g. the data -> grid-cell lookup of conditional simulation, fft.jl:129-132):
   // one brute-force sweep of the set costs less than ordering it on the host for the index
   const bool few_queries = m <= 4096 && n >= 32768;
-  if (metric == GSS_METRIC_EUCLIDEAN && !(e && e[0] == '1') && !few_queries) {
+  if (metric != GSS_METRIC_HAVERSINE && !(e && e[0] == '1') && !few_queries) {
     KnnIndex ix;
     GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
-    GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s));
+    GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s, nullptr, nullptr, nullptr, metric));
     GSS_HIP(hipStreamSynchronize(s));  // the index is released on return
     return GSS_OK;
   }

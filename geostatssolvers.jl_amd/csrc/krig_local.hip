@@ -573,7 +573,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   const int64_t chunk = 1 << 20;
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
-  const bool use_index = metric == GSS_METRIC_EUCLIDEAN && !(brute && brute[0] == '1');
+  const bool use_index = metric != GSS_METRIC_HAVERSINE && !(brute && brute[0] == '1');
   const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
   const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
@@ -588,7 +588,9 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     uint8_t* st = status ? status + off : st_s.as<uint8_t>();
     {
       ProfScope ps("knn", s);
-      if (use_index) GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s));
+      if (use_index)
+        GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, nullptr, nullptr, nullptr,
+                                   metric));
       else GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, metric));
     }
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;

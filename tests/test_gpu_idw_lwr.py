@@ -176,3 +176,23 @@ def test_reference_haversine_cases_and_metric_errors():
                                current_stream()))
     with pytest.raises(_lib.GSSError, match="longitude"):
         HipEngine.knn_search(np.zeros((4, 3)), np.zeros((2, 3)), 2, distance=("haversine", 1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distance", ["cityblock", "chebyshev"])
+@pytest.mark.parametrize("n,dim,k", [(30000, 3, 20), (5000, 2, 64), (20000, 1, 7)])
+def test_metric_search_with_box_bounds_equals_exhaustive_search(monkeypatch, distance, n, dim, k):
+    """Cityblock and Chebyshev searches use the k-d ordered index with per-metric box bounds; the lists equal the
+    exhaustive kernel's (GSS_KNN_BRUTE=1) and the oracle's on a subset, ties on a coarse lattice included."""
+    from gss.engine import HipEngine
+    from oracle import kriging as K
+    rng = np.random.default_rng(n + k)
+    x = np.round(rng.uniform(0, 60, (n, dim)), 1 if dim > 1 else 3)
+    c = np.vstack([x[rng.integers(0, n, 2500)] + rng.normal(0, 0.3, (2500, dim)), rng.uniform(-10, 70, (2500, dim))])
+    idx, cnt = HipEngine.knn_search(x, c, k, distance=distance)
+    monkeypatch.setenv("GSS_KNN_BRUTE", "1")
+    bidx, bcnt = HipEngine.knn_search(x, c, k, distance=distance)
+    monkeypatch.delenv("GSS_KNN_BRUTE")
+    assert np.array_equal(idx, bidx) and np.array_equal(cnt, bcnt)
+    ridx, rcnt = K.knn_search(x, c[::50], k, distance=distance)
+    assert np.array_equal(idx[::50], ridx) and np.array_equal(cnt[::50], rcnt)
