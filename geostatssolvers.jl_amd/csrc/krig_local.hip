@@ -5,7 +5,7 @@
 //   :223  fit(estimator, view(pdata, neighbors))            -> k' x k' covariance, Cholesky in LDS
 //   :226  predictprob(krig, var, pdomain[ind])              -> mean / variance by block elimination
 //
-// One wave (a 64-thread workgroup) owns one domain point; lane j owns neighbour j.  With
+// One wave owns one domain point; lane j owns neighbour j.  With
 // C = L L', Y = L^-1 [c0 | F | z] (forward substitution, all right-hand sides in one sweep):
 //   q = |y_c|^2, a = y_z . y_c, S = Y_F' Y_F, r = Y_F' y_c - f0, t = Y_F' y_z
 //   sigma^2 = max(0, sill - q + r' S^-1 r),   mu = a - t' S^-1 r        (SK: mu = mean + a, nc = 0)
@@ -274,8 +274,9 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
 // K5, MFMA-tiled variant (default).  Same mathematics as krig_local_kernel above, but the k x k system is held in
 // registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r <-> element
 // (row (l >> 4) + 4 r, column l & 15)) and factorised as A = U'U by tiles:
-//   diagonal tile   : through LDS into "lane = row" form, 16 x 16 Cholesky and triangular inverse V = U_kk^-1 with
-//                     v_readlane broadcasts, V back in tile layout (U_kk itself is never needed again)
+//   diagonal tile   : through LDS into "lane = row" form, 16 x 16 Cholesky with the inverse V = U_kk^-1 built in the
+//                     same sweep, row-local DPP broadcasts; one wave does this for the four points of its workgroup
+//                     (tile16.h potrf16_inverse_x4); V back in tile layout (U_kk itself is never needed again)
 //   U_kj  = V' A_kj,  A_ij -= U_ki' U_kj,  right-hand sides  Y_k = V' B_k,  B_i -= U_ki' Y_k
 // Every product has the form X'Y with X and Y in tile layout, which is exactly what the MFMA consumes: register s
 // of X is the A operand of k-slice s (A[i][k] on lane i + 16 k) and register s of Y is its B operand, so no data
