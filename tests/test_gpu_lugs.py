@@ -160,3 +160,29 @@ def test_batched_global_prediction_matches_loop():
         for b in range(5):
             ref, _ = K.exactsolve(variant, Variogram("exponential", range=25.0), x, zb[b], x0, mean=mean or 0.0)
             assert np.max(np.abs(out[b] - ref)) < 1e-9
+
+
+@pytest.mark.parametrize("variant,okw,dim,nb", [(2, dict(degree=1), 3, 37), (1, {}, 1, 16), (0, dict(mean=-0.4), 2, 17)])
+def test_batched_means_more_vectors_than_one_pass_and_drifts(variant, okw, dim, nb):
+    """The fused means-only kernel takes sixteen data vectors per pass: 37 vectors need three passes; universal kriging
+    adds the drift rows; a nested model goes through the generic instantiation."""
+    from gss.engine import KrigHandle
+    import gss
+    from oracle import kriging as K
+    from oracle.variogram import Nested
+    rng = np.random.default_rng(40 + nb)
+    x = rng.uniform(0, 100, (120, dim))
+    if dim == 1:
+        x = (np.linspace(0, 100, 120) + rng.uniform(-0.2, 0.2, 120))[:, None]
+    x0 = rng.uniform(0, 100, (1001, dim))
+    zb = rng.normal(size=(nb, 120))
+    gv = 0.7 * gss.SphericalVariogram(range=40.0, nugget=0.02) + 0.3 * gss.ExponentialVariogram(range=15.0)
+    ov = Nested([(0.7, Variogram("spherical", range=40.0, nugget=0.02)), (0.3, Variogram("exponential", range=15.0))])
+    kvar = {0: K.SK, 1: K.OK, 2: K.UK}[variant]
+    h = KrigHandle(gv, kvar, x, zb[0], mean=okw.get("mean"), degree=okw.get("degree"))
+    out = h.predict_global_batch(x0, zb)
+    h.close()
+    assert out.shape == (nb, 1001)
+    for b in sorted({0, 15, min(16, nb - 1), nb - 1}):
+        ref, _ = K.exactsolve(kvar, ov, x, zb[b], x0, mean=okw.get("mean") or 0.0, degree=okw.get("degree"))
+        assert np.max(np.abs(out[b] - ref)) < 1e-9
