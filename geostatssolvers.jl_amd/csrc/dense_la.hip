@@ -521,6 +521,142 @@ __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restr
       }
 }
 
+// The same leaf for blocks of up to 128 x 128, one workgroup of four waves: the 8 x 8 grid of 16 x 16 tiles lives in
+// LDS in tile layout (element of lane l, register r at [r * 64 + l]: conflict-free), wave 0 factors the diagonal tile
+// of a step (potrf16_full, wave-local synchronisation) and all four waves share the X'Y products of the row solve, the
+// trailing update and the block forward substitution for W = inv(L).  Row J of W overwrites column J of U, which is
+// dead once that row is known (held in registers across the barrier).  One such launch replaces two 64 x 64 leaves,
+// four 64^3 GEMM launches and a copy of the recursion.
+constexpr int L128_TILES = 36;  // upper block triangle of 8 x 8
+constexpr size_t L128_LDS_BYTES = sizeof(double) * ((L128_TILES + 16) * 256 + 2 * 16 * 17);
+__host__ __device__ constexpr int tile_id8(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }
+
+__global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restrict__ A, int n, int64_t lda, int row_offset,
+                                                                int* __restrict__ info, double* __restrict__ dinv,
+                                                                int64_t ldd) {
+  extern __shared__ __attribute__((aligned(16))) double sm128[];
+  double* Tl = sm128;                  // 36 tiles: U (upper block triangle), later W below the diagonal
+  double* Vl = Tl + L128_TILES * 256;  // V_k = U_kk^-1
+  double* VTl = Vl + 8 * 256;          // V_k'
+  double* S = VTl + 8 * 256;
+  double* S2 = S + 16 * 17;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int nt = (n + 15) >> 4;
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto ld = [&](const double* base, int id) {
+    d4_t t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = base[id * 256 + r * 64 + lane];
+    return t;
+  };
+  auto st = [&](double* base, int id, const d4_t& t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) base[id * 256 + r * 64 + lane] = t[r];
+  };
+  // block -> tiles (lower triangle of A is the storage; rows / columns beyond n are the identity)
+  {
+    int q = 0;
+    for (int I = 0; I < nt; ++I)
+      for (int J = I; J < nt; ++J) {
+        if ((q++ & 3) != wave) continue;
+        d4_t t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + g + 4 * r, col = 16 * J + c;
+          double v = (row == col) ? 1.0 : 0.0;
+          if (row < n && col < n) {
+            const int hi = row > col ? row : col, lo = row > col ? col : row;
+            v = A[hi + (int64_t)lo * lda];
+          }
+          t[r] = v;
+        }
+        st(Tl, tile_id8(I, J), t);
+      }
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int kk = 0; kk < nt; ++kk) {
+    if (wave == 0) {
+      d4_t U, V, VT;
+      int bc;
+      potrf16_full<true>(ld(Tl, tile_id8(kk, kk)), S, S2, lane, &U, &V, &VT, &bc);
+      if (bc >= 0 && bad == 0) bad = row_offset + 16 * kk + bc + 1;
+      st(Tl, tile_id8(kk, kk), U);
+      st(Vl, kk, V);
+      st(VTl, kk, VT);
+    }
+    __syncthreads();
+    {
+      const d4_t V = ld(Vl, kk);
+      for (int j = kk + 1 + wave; j < nt; j += 4) st(Tl, tile_id8(kk, j), xty(V, ld(Tl, tile_id8(kk, j)), zero4));
+    }
+    __syncthreads();
+    {
+      int q = 0;
+      for (int i = kk + 1; i < nt; ++i) {
+        const bool mine_any = true;
+        (void)mine_any;
+        for (int j = i; j < nt; ++j) {
+          if ((q++ & 3) != wave) continue;
+          const d4_t N = -ld(Tl, tile_id8(kk, i));
+          st(Tl, tile_id8(i, j), xty(N, ld(Tl, tile_id8(kk, j)), ld(Tl, tile_id8(i, j))));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && bad != 0 && lane == 0 && *info == 0) *info = bad;
+  // L = U': element (r, c) of U_IJ is L[16 J + c][16 I + r]
+  {
+    int q = 0;
+    for (int I = 0; I < nt; ++I)
+      for (int J = I; J < nt; ++J) {
+        if ((q++ & 3) != wave) continue;
+        const d4_t t = ld(Tl, tile_id8(I, J));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = 16 * J + c, lcol = 16 * I + g + 4 * r;
+          if (lrow < n && lcol < n && lrow >= lcol) A[lrow + (int64_t)lcol * lda] = t[r];
+        }
+      }
+  }
+  if (!dinv) return;
+  // W = inv(L): W_II = V_I', W_JI = -V_J' sum_{K = I .. J-1} U_KJ' W_KI (J > I); W_KI sits in slot (I, K) once row K is done
+  for (int J = 1; J < nt; ++J) {
+    d4_t wreg[2] = {zero4, zero4};
+    int cnt = 0;
+    for (int I = wave; I < J; I += 4) {
+      d4_t acc = zero4;
+      for (int K = I; K < J; ++K) {
+        const d4_t Wki = (K == I) ? ld(VTl, I) : ld(Tl, tile_id8(I, K));
+        acc = xty(ld(Tl, tile_id8(K, J)), Wki, acc);
+      }
+      wreg[cnt++] = xty(-ld(Vl, J), acc, zero4);
+    }
+    __syncthreads();  // every wave has read what it needs of column J of U
+    cnt = 0;
+    for (int I = wave; I < J; I += 4) st(Tl, tile_id8(I, J), wreg[cnt++]);
+    __syncthreads();
+  }
+  // dinv (column-major, leading dimension ldd): the n x n block, zero above the diagonal
+  {
+    int q = 0;
+    for (int I = 0; I < nt; ++I)
+      for (int J = 0; J < nt; ++J) {
+        if ((q++ & 3) != wave) continue;
+        d4_t t = zero4;
+        if (J == I) t = ld(VTl, I);
+        else if (J > I) t = ld(Tl, tile_id8(I, J));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int wrow = 16 * J + g + 4 * r, wcol = 16 * I + c;
+          if (wrow < n && wcol < n) dinv[wrow + (int64_t)wcol * ldd] = t[r];
+        }
+      }
+  }
+}
+
 // W = inv(L) for one lower-triangular block (used when no cached inverse exists)
 __global__ __launch_bounds__(64) void trtri_leaf_kernel(const double* __restrict__ L, int n, int64_t ldl,
                                                         double* __restrict__ W, int64_t ldw) {
@@ -672,6 +808,22 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
   if (n <= LEAF) {
     hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, W,
                        ldw, 0);
+    GSS_HIP(hipGetLastError());
+    return GSS_OK;
+  }
+  static const bool leaf128 = [] {
+    const char* e = std::getenv("GSS_LEAF128");
+    return !(e && e[0] == '0');
+  }();
+  if (n <= 2 * LEAF && leaf128) {
+    static bool attr = false;
+    if (!attr) {
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_leaf128_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
+      attr = true;
+    }
+    hipLaunchKernelGGL(potrf_inv_leaf128_kernel, dim3(1), dim3(256), L128_LDS_BYTES, s, A, (int)n, lda, (int)row_offset,
+                       d_info, W, ldw);
     GSS_HIP(hipGetLastError());
     return GSS_OK;
   }

@@ -40,6 +40,12 @@ __device__ __forceinline__ void fmac_bc16(double& acc, double src, double mul) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
 }
 __device__ __forceinline__ void dpp_fence(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
+// The same with the wait states inside the block, for a source that an earlier fmac_bc16 may have written only just
+// before (the compiler is free to schedule the independent updates of consecutive steps back to back).
+template <int J>
+__device__ __forceinline__ void fmac_bc16_after_write(double& acc, double src, double mul) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+}
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) {
@@ -91,6 +97,9 @@ __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* fl
       fmac_bc16<j, false>(row[c], row[c], tm);    // M_ic += tm M_jc  (row j's own entry is final: tm = 0 there)
     });
     row[j] = (i == j) ? 1.0 : tm;                 // column j of M: M_jj = 1, M_ij = -L_ij / L_jj below, 0 above
+    // nothing moves across the step boundary: the updates of M_ic in consecutive steps read the register the step
+    // before wrote, through DPP, and must stay separated by the next step's pivot chain (checked on the built code)
+    __builtin_amdgcn_sched_barrier(0);
   });
   // V = W' with W_ic = M_ic / L_ii: lane b = i writes column b.  Every lane has read its row before any write (LDS
   // operations of one wave complete in order), so the tile is overwritten in place.
@@ -101,21 +110,35 @@ __device__ __forceinline__ void potrf16_inverse_x4(double* S4, int lane, int* fl
 
 constexpr int tile_id(int i, int j) { return i * 4 - (i * (i - 1)) / 2 + (j - i); }  // upper block triangle, i <= j
 
+// Barrier between the LDS phases of a tile routine: the whole workgroup (one wave per workgroup, or every wave taking
+// part), or -- WAVE_LOCAL -- only the calling wave of a larger workgroup whose other waves are busy elsewhere (LDS
+// operations of one wave complete in order; the fence keeps the compiler from moving them).
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void tile_sync() {
+  if (WAVE_LOCAL) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 // One tile (lanes 16..63 shadow lanes 0..15), with everything the 64 x 64 leaf needs from a diagonal tile:
 // u = U (tile layout, upper, zero below the diagonal) for t = U'U, v = U^-1, vt = (U^-1)' (lower), and the first column
 // whose pivot was not positive (-1 if none).  Same single sweep as potrf16_inverse_x4: the leaf is one wave on the
 // latency chain of the fit, so the dependent chain counts.  S and S2: 16 x 17 doubles of LDS each.
+template <bool WAVE_LOCAL = false>
 __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S2, int lane, d4_t* u, d4_t* v,
                                              d4_t* vt, int* bad_col) {
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
   for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
   const int i = c;
   double row[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
   double myy = 1.0;
   int badc = -1;
   static_for<0, 16>([&](auto J) {
@@ -140,14 +163,14 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
     });
     static_for<0, j>([&](auto C) {
       constexpr int cc = decltype(C)::value;
-      fmac_bc16<j, false>(row[cc], row[cc], tm);
+      fmac_bc16_after_write<j>(row[cc], row[cc], tm);
     });
     row[j] = (i == j) ? 1.0 : tm;
   });
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
 #pragma unroll
   for (int r = 0; r < 4; ++r) (*u)[r] = S2[(g + 4 * r) * 17 + c];
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
   // lane i holds row i of W = L^-1 (after the scaling by 1 / L_ii): V = W' (lane b writes column b), VT = W
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -155,13 +178,13 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
     S[r * 17 + i] = w;
     S2[i * 17 + r] = w;
   }
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     (*v)[r] = S[(g + 4 * r) * 17 + c];
     (*vt)[r] = S2[(g + 4 * r) * 17 + c];
   }
-  __syncthreads();
+  tile_sync<WAVE_LOCAL>();
   *bad_col = badc;
 }
 
