@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the kriging / FFTGS hot path on MI355X.
 
-A "step" is one whole pass of BASELINE.json configs[1] on each GPU: Ordinary Kriging of 1 000
-scattered 3-D samples onto 10^6 domain points with a Matern-3/2 variogram (global neighbourhood) --
-fit (device factorisation of the 1001^2 system) + predict, with every input already resident in
-HBM when the timed region starts.  Multi-GPU is weak scaling: each rank owns its own block of 10^6
-domain points (independent given the factor, which every rank recomputes because that is cheaper
-than a broadcast at n = 1000; `--factor-broadcast` exercises the RCCL broadcast path instead).
+`python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no launcher environment the script starts N
+fresh ranks itself (`python -m torch.distributed.run ... bench.py`, one rank per GPU over RCCL) BEFORE anything
+touches the GPU, waits for them and exits with their status; under the driver's own `torch.distributed.run` it
+checks that the launcher's world size equals N.  Rank 0 prints ONE JSON line.
 
-Prints ONE JSON line on rank 0.  Extra keys: `roofline` (dominant kernel: the FP64-MFMA quadratic
-form), `cpu_baseline` (oracle C restatement, single thread like the reference's loop krig.jl:180,
-bounded sample) and `fftgs` (second headline metric, 512^3 realisations/s on this GPU).
+A "step" is one whole pass of BASELINE.json configs[1] on each GPU: Ordinary Kriging of 1 000 scattered 3-D samples
+onto 10^6 domain points with a Matern-3/2 variogram (global neighbourhood) -- fit (device factorisation of the
+1001^2 system) + predict, with every input already resident in HBM when the timed region starts.  Multi-GPU is weak
+scaling: each rank owns its own block of 10^6 domain points (independent given the factor, which every rank
+recomputes because that is cheaper than a broadcast at n = 1000; `--factor-broadcast` exercises the RCCL broadcast
+path instead).
+
+Extra keys of the line:
+  roofline      dominant kernel of the step (FP64-MFMA quadratic form), HIP-event timed inside this process
+  cpu_baseline  oracle C restatement, single thread like the reference's loop krig.jl:180, bounded sample (N = 1 only)
+  fftgs         second headline metric (BASELINE.json: "+ FFTGS 512^3 realisations/sec at 1/2/4/8"): configs[2],
+                realisations sharded over the ranks ((seed, r)-keyed noise), spectrum computed on rank 0 and broadcast
+  lugs          configs[3]: rank 0 runs the preprocess (lu.jl:76-169), broadcasts (L22, d2) over RCCL, every rank
+                realises its share (lu.jl:171-224)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,10 +33,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (public spec)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -41,32 +48,82 @@ def parse():
     ap.add_argument("--factor-broadcast", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=30000, help="points of the CPU baseline sample")
-    ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the extra leg)")
-    ap.add_argument("--fftgs-reals", type=int, default=8)
+    ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the leg)")
+    ap.add_argument("--fftgs-reals", type=int, default=64, help="FFTGS realisations per GPU in the timed region")
+    ap.add_argument("--lugs", type=int, default=128, help="LUGS grid edge, a quarter of the cells carry data "
+                                                         "(configs[3]: 128; 0 disables the leg)")
+    ap.add_argument("--lugs-reals", type=int, default=100, help="LUGS realisations in total (sharded over the ranks)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """Start `--gpus N` ranks as children of this (GPU-free) process; a process that has initialised the GPU is
+    never re-exec'd."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        sys.exit(launch_ranks(a))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}, but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gfx950 path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("GSS_BENCH_BACKEND", "nccl")
+    if local >= ndev:
+        # GSS_BENCH_BACKEND=gloo: rehearsal of the N-rank path on fewer GPUs (ranks share devices; RCCL cannot do that)
+        if backend == "nccl":
+            raise SystemExit(f"rank {rank}: local rank {local} but only {ndev} GPU(s) visible")
+        local = local % ndev
     torch.cuda.set_device(local)
-    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run: one rank per GPU
+    use_dist = launched
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {a.gpus}")
 
     import gss
-    from gss import _lib
+    from gss import _lib, parallel
     from gss.engine import KrigHandle, OK
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if use_dist:
+            if backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX)
+                t = c
+        return float(t.item())
 
     # ---- synthetic inputs (BASELINE.md section 3, config 2) ---------------------------------
     n, m = a.ndata, a.npoints
@@ -79,8 +136,7 @@ def main():
     def step():
         if a.factor_broadcast and use_dist:
             h = KrigHandle(vg, OK, x, z, factor=(rank == 0))
-            t = h.factor_tensor()
-            dist.broadcast(t, src=0)
+            parallel.broadcast_(h.factor_tensor(), 0)
             h.adopt_factor()
         else:
             h = KrigHandle(vg, OK, x, z)
@@ -110,10 +166,7 @@ def main():
     mu, var, st = keep[1]
     keep[0].close()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt)
     value = world * m * a.steps / dt
 
     # ---- roofline of the dominant kernel (quadratic form: (n+nc)^2 flop per point) ----------
@@ -132,11 +185,11 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the value is
     # the one measured for this exact configuration with tools/pmc_krig.sh + tools/pmc_traffic.py (separate --pmc
     # passes, gfx950 FETCH_SIZE correction) and committed under profiles/.
-    tfile = os.path.join(ROOT, "profiles", "r01_krig_cfg2_pmc_traffic.json")
-    if n == 1000 and m == 1_000_000 and os.path.exists(tfile):
+    tfile = _latest_profile("krig_cfg2_pmc_traffic.json")
+    if n == 1000 and m == 1_000_000 and tfile:
         tj = json.load(open(tfile))
         roofline["traffic"] = tj["hbm_bytes_per_step"] / max(q_n / a.steps, 1)
-        roofline["traffic_unit"] = "B per launch (rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE, profiles/r01_krig_cfg2_pmc_traffic.json)"
+        roofline["traffic_unit"] = "B per launch (rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE, profiles/%s)" % os.path.basename(tfile)
         roofline["algorithmic_bytes"] = 8.0 * N1 * m / max(q_n / a.steps, 1)   # R read once: 8 (n+nc) B per point
 
     line = {"metric": "kriged domain points/sec (OK, 1000 3-D data, Matern-3/2, global neighbourhood)",
@@ -173,8 +226,13 @@ def main():
                                               "first %d of the 10^6 points, %.1f s, single thread like the "
                                               "reference loop; host has %d cores" % (ns, cdt, os.cpu_count())}
 
-    if world == 1 and a.fftgs > 0:
-        line["fftgs"] = fftgs_leg(a, gss, _lib)
+    del x0_dev, mu, var, st, keep, out
+    ctx = dict(a=a, gss=gss, _lib=_lib, parallel=parallel, torch=torch, np=np, rank=rank, world=world,
+               barrier=barrier, max_over_ranks=max_over_ranks)
+    if a.fftgs > 0:
+        line["fftgs"] = fftgs_leg(ctx)
+    if a.lugs > 0:
+        line["lugs"] = lugs_leg(ctx)
 
     if rank == 0:
         print(json.dumps(line), flush=True)
@@ -182,38 +240,148 @@ def main():
         dist.destroy_process_group()
 
 
-def fftgs_leg(a, gss, _lib):
-    """Second headline metric: unconditional FFTGS realisations/s on an edge^3 grid (configs[2])."""
+def _latest_profile(suffix):
+    """Newest committed profiles/rNN_<suffix> (the round that last re-measured it)."""
+    d = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(d):
+        return None
+    c = sorted(f for f in os.listdir(d) if f.endswith(suffix) and f[:1] == "r")
+    return os.path.join(d, c[-1]) if c else None
+
+
+def fftgs_leg(c):
+    """Second headline metric: unconditional FFTGS realisations/s on an edge^3 grid (configs[2]).  Weak scaling:
+    every rank realises `--fftgs-reals` fields (rank k owns realisations k R .. (k+1) R - 1 of the ensemble; the
+    noise of realisation r depends on (seed, r) only).  fft.jl:62 runs on rank 0, the state is broadcast."""
+    a, gss, _lib, parallel, torch = c["a"], c["gss"], c["_lib"], c["parallel"], c["torch"]
+    rank, world = c["rank"], c["world"]
     from gss.engine import FFTGSHandle
-    e = a.fftgs
+    e, R = a.fftgs, a.fftgs_reals
+    vg = gss.ExponentialVariogram(range=50.0 * e / 512.0)
+    N = e ** 3
     try:
-        f = FFTGSHandle(gss.ExponentialVariogram(range=50.0 * e / 512.0), (e, e, e))
+        t0 = time.perf_counter()
+        f = FFTGSHandle(vg, (e, e, e))
+        torch.cuda.synchronize()
+        pre_cold = time.perf_counter() - t0            # first create of the process (code objects, twiddles, pool)
+        f.close()
+        c["barrier"]()
+        t0 = time.perf_counter()
+        f = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute))
+        c["barrier"]()
+        pre_warm = c["max_over_ranks"](time.perf_counter() - t0)   # rank 0 computes, peers adopt the broadcast
     except _lib.GSSError as err:
         return {"error": str(err)}
-    N = e ** 3
     out = torch.empty((1, N), dtype=torch.float64, device="cuda")
-    f.realize(4, 0, 1, out=out)
+    f.realize(4, rank * R, 1, out=out)
     torch.cuda.synchronize()
     _lib.profile_reset()
     _lib.profile_enable(True)
+    c["barrier"]()
     t0 = time.perf_counter()
-    for r in range(a.fftgs_reals):
-        f.realize(4, r, 1, out=out)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    for r in range(R):
+        f.realize(4, rank * R + r, 1, out=out)
+    c["barrier"]()
+    dt = c["max_over_ranks"](time.perf_counter() - t0)
     _lib.profile_enable(False)
-    parts = {k: _lib.profile_read(k) for k in ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", "fftgs_p1", "fftgs_p2", "fftgs_p3", "fftgs_p4",
-                                               "fftgs_p5")}
+    names = ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", "fftgs_p1", "fftgs_p2", "fftgs_p3", "fftgs_p4",
+             "fftgs_p5")
+    parts = {k: _lib.profile_read(k) for k in names}
+    kern_ms = sum(v[0] for v in parts.values()) / max(R, 1)
     zc = out[0]
-    res = {"metric": "FFTGS %d^3 realisations/sec" % e, "value": round(a.fftgs_reals / dt, 2), "unit": "realisations/s",
-           "ms_per_realisation": round(dt / a.fftgs_reals * 1e3, 3),
-           "roofline": {"bound": "hbm", "achieved": round(32.0 * N * a.fftgs_reals / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(32.0 * N * a.fftgs_reals / dt / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic": None},
+    svar = float((zc * zc).sum().item() / (N - 1))
+    # the per-GPU share of configs[2] end to end: preprocess (warm) + 32 realisations
+    c["barrier"]()
+    t0 = time.perf_counter()
+    f2 = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute))
+    for r in range(32):
+        f2.realize(4, rank * 32 + r, 1, out=out)
+    c["barrier"]()
+    dt32 = c["max_over_ranks"](time.perf_counter() - t0)
+    f2.close()
+    alg = 32.0 * N                                   # SURVEY.md section 8d: 32 N bytes per FP64 realisation
+    res = {"metric": "FFTGS %d^3 realisations/sec" % e, "value": round(world * R / dt, 2), "unit": "realisations/s",
+           "n_gpus": world, "scaling": "weak", "realisations_per_gpu": R,
+           "ms_per_realisation": round(dt / R * 1e3, 3),
+           "preprocess_s": {"cold": round(pre_cold, 4), "warm": round(pre_warm, 4),
+                            "note": "cold = first gss_fftgs_create of the process; warm = rank 0 creates, peers adopt "
+                                    "the RCCL broadcast of the state (N > 1) or a second create (N = 1)"},
+           "end_to_end_32_per_gpu": {"value": round(world * 32 / dt32, 2), "unit": "realisations/s",
+                                     "seconds": round(dt32, 4),
+                                     "note": "configs[2] share of one GPU: preprocess + 32 realisations"},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1) if kern_ms else 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_ms else 0.0,
+                        "traffic": None, "algorithmic_bytes": alg,
+                        "kernels": "the five passes of one realisation (HIP events, summed)",
+                        "avg_ms": round(kern_ms, 4)},
            "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items() if v[1]},
-           "sample_variance": float((zc * zc).sum().item() / (N - 1))}
+           "sample_variance": svar}
+    tfile = _latest_profile("fftgs_512_pmc_traffic.json")
+    if e == 512 and tfile:
+        tj = json.load(open(tfile))
+        res["roofline"]["traffic"] = tj["hbm_bytes_per_realisation"]
+        res["roofline"]["traffic_unit"] = "B per realisation (rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE, profiles/%s)" % os.path.basename(tfile)
     f.close()
     return res
+
+
+def lugs_leg(c):
+    """configs[3]: LUGS on a g x g grid with g^2/4 conditioning cells (128 -> 4 096 data, ns = 12 288), spherical
+    range 20, `--lugs-reals` realisations sharded over the ranks.  Preprocess (lu.jl:76-169, dense Cholesky on the
+    FP64 matrix cores) on rank 0 only, (L22, d2) broadcast over RCCL, lusim (lu.jl:198-224) on every rank."""
+    a, gss, _lib, parallel, torch, np = c["a"], c["gss"], c["_lib"], c["parallel"], c["torch"], c["np"]
+    rank, world = c["rank"], c["world"]
+    from gss.engine import LUGSHandle
+    g, Rtot = a.lugs, a.lugs_reals
+    N, nd = g * g, g * g // 4
+    cent = gss.CartesianGrid(g, g).centroids()
+    dlocs = np.sort(np.random.default_rng(5).permutation(N)[:nd])
+    z1 = np.random.default_rng(50).normal(size=nd)
+    vg = gss.SphericalVariogram(range=20.0)
+    ns = N - nd
+    try:
+        if rank == 0:                                   # warm the code objects and the buffer pool
+            LUGSHandle(vg, cent, dlocs, z1).close()
+        c["barrier"]()
+        t0 = time.perf_counter()
+        h = LUGSHandle(vg, cent, dlocs, z1, factor=(rank == 0))
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        c["barrier"]()
+        t0 = time.perf_counter()
+        parallel.broadcast_(h.state_tensor(), 0)
+        if rank != 0:
+            h.adopt_state()
+        c["barrier"]()
+        t_bc = c["max_over_ranks"](time.perf_counter() - t0)
+    except _lib.GSSError as err:
+        return {"error": str(err)}
+    t_pre0 = torch.tensor([t_pre if rank == 0 else 0.0], dtype=torch.float64)
+    parallel.broadcast_(t_pre0, 0)
+    t_pre = float(t_pre0.item())
+    lo, hi = parallel.shard_range(Rtot, rank, world)
+    h.realize(5, lo, max(hi - lo, 1), device=True)
+    c["barrier"]()
+    t0 = time.perf_counter()
+    y, _ = h.realize(5, lo, hi - lo, device=True)
+    c["barrier"]()
+    dt = c["max_over_ranks"](time.perf_counter() - t0)
+    ok = True
+    if hi > lo:
+        ok = bool(torch.equal(y[0, torch.as_tensor(dlocs, device="cuda")], torch.as_tensor(z1, device="cuda")))
+    h.close()
+    flops = nd ** 3 / 3 + nd * nd * ns + nd * ns * ns + ns ** 3 / 3
+    return {"config": "configs[3]: LUGS %dx%d grid, %d conditioning cells, ns = %d, spherical range 20, %d realisations "
+                      "over %d GPU(s)" % (g, g, nd, ns, Rtot, world),
+            "n_gpus": world, "preprocess_s": round(t_pre, 4),
+            "preprocess_roofline": {"bound": "mfma", "achieved": round(flops / t_pre / 1e12, 2),
+                                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(flops / t_pre / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)},
+            "state_bytes": 8 * (ns * ns + ns), "broadcast_s": round(t_bc, 4) if world > 1 else None,
+            "broadcast_GBps": round(8 * (ns * ns + ns) / t_bc / 1e9, 1) if world > 1 else None,
+            "realize_s": round(dt, 5), "value": round(Rtot / dt, 1), "unit": "realisations/s",
+            "hard_data_honoured": ok}
 
 
 if __name__ == "__main__":

@@ -54,6 +54,30 @@ static void prof_collect(ProfEntry& e) {
   e.stop.clear();
 }
 
+// ---- cross-stream ordering of the library's own work (see to_stream in gss_internal.h) ---------------
+static hipStream_t g_last_stream = nullptr;
+static bool g_have_last_stream = false;
+static hipEvent_t g_chain_event = nullptr;
+
+hipStream_t to_stream(void* sv) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(sv);
+  if (g_have_last_stream && s != g_last_stream) {
+    bool chained = false;
+    if (!g_chain_event && hipEventCreateWithFlags(&g_chain_event, hipEventDisableTiming) != hipSuccess)
+      g_chain_event = nullptr;
+    if (g_chain_event && hipEventRecord(g_chain_event, g_last_stream) == hipSuccess &&
+        hipStreamWaitEvent(s, g_chain_event, 0) == hipSuccess)
+      chained = true;
+    if (!chained) {  // e.g. the previous stream has been destroyed by its owner: fall back to a full barrier
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+    }
+  }
+  g_last_stream = s;
+  g_have_last_stream = true;
+  return s;
+}
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {
@@ -66,8 +90,9 @@ void set_error(const char* fmt, ...) {
 // Device allocations are recycled through a small exact-size free list: handles are created and destroyed once
 // per solve with identical sizes, and hipMalloc / hipFree cost 0.1-1 ms each (hipFree also synchronises the
 // device, which would stop the host from queueing the next solve behind the running one).  Re-use is ordered by
-// the stream the work is submitted on (one stream per process, handles are not thread-safe), so a block released
-// while a kernel still reads it cannot be overwritten before that kernel finishes.
+// submission: every entry point goes through to_stream(), which chains a call on a new stream behind the work
+// queued on the previous one, so a block released while a kernel still reads it cannot be overwritten before
+// that kernel finishes -- whichever streams the caller uses (handles are still not thread-safe).
 struct PoolBlock {
   void* p;
   size_t bytes;

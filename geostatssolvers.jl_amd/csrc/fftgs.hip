@@ -160,14 +160,16 @@ struct gss_fftgs {
   int ndim = 0;
   int64_t N = 0, NH = 0;
   double mean = 0.0;
+  // rocFFT pipeline (general grids): plans, work buffer, U and Xn are created on first use
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   DevBuf state;  // Fh (NH doubles) followed by scal[2]
-  DevBuf U, X, work, Z;
+  DevBuf U, Xn, work, Z;
+  bool ready = false;  // state holds a spectrum (computed here or adopted after a broadcast)
   // fused pipeline (power-of-two 3-D grids)
   bool fused = false;
   FusedGrid fg;
-  DevBuf tw1, tw2, tw3, Fh_tiled;
+  DevBuf X, tw1, tw2, tw3, Fh_tiled, covsrc;
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
   ~gss_fftgs() {
@@ -187,6 +189,30 @@ static int32_t fft_exec(gss_fftgs* h, rocfft_plan plan, void* in, void* out, hip
   void* ib[1] = {in};
   void* ob[1] = {out};
   GSS_FFT(rocfft_execute(plan, ib, ob, h->info));
+  return GSS_OK;
+}
+
+// rocFFT plans (run-time compiled: ~1.5 s the first time a size is seen), their work buffer and the natural-layout
+// buffers of the general pipeline; the fused pipeline never needs them
+static int32_t ensure_rocfft(gss_fftgs* h) {
+  if (h->fwd) return GSS_OK;
+  std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+  size_t lengths[3] = {(size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
+  GSS_FFT(rocfft_plan_create(&h->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                             rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
+  GSS_FFT(rocfft_plan_create(&h->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                             rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
+  size_t w1 = 0, w2 = 0;
+  GSS_FFT(rocfft_plan_get_work_buffer_size(h->fwd, &w1));
+  GSS_FFT(rocfft_plan_get_work_buffer_size(h->inv, &w2));
+  const size_t wb = w1 > w2 ? w1 : w2;
+  GSS_FFT(rocfft_execution_info_create(&h->info));
+  if (wb > 0) {
+    GSS_TRY(h->work.alloc(wb));
+    GSS_FFT(rocfft_execution_info_set_work_buffer(h->info, h->work.p, wb));
+  }
+  GSS_TRY(h->U.alloc(sizeof(double) * (size_t)h->N));
+  GSS_TRY(h->Xn.alloc(sizeof(double) * 2 * (size_t)h->NH));
   return GSS_OK;
 }
 
@@ -235,25 +261,87 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   GSS_TRY(upload_twiddles(h->tw3, f.n3, s));
   const int64_t nt = (int64_t)f.n2 * f.ntx * f.n3 * FF_TX;
   GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)nt));
-  hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
-  GSS_HIP(hipGetLastError());
   const int M = f.n1 / 2;
   const int lmax = f.n2 > f.n3 ? f.n2 : f.n3;
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ff_xfwd_lds(M)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_PHILOX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_ARRAY>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_COV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_xinv_lds(M)));
   // the half-spectrum buffer of the fused path has the padded row pitch; padding columns stay zero
   GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)f.nhp * f.n2 * f.n3));
-  GSS_HIP(hipMemsetAsync(h->X.p, 0, h->X.bytes, s));
+  GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_axis_lds(lmax)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_axis_lds(lmax)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_axis_lds(lmax)));
-  GSS_HIP(hipStreamSynchronize(s));
   h->fused = true;
+  return GSS_OK;
+}
+
+// launches of the forward passes shared by the realisations and the spectrum build
+static void launch_p1(gss_fftgs* h, int src, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  const int M = f.n1 / 2;
+  const int64_t nrows = (int64_t)f.n2 * f.n3;
+  const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
+  double2* X = h->X.as<double2>();
+  const CovSrc* cs = h->covsrc.as<CovSrc>();
+  if (src == FF_SRC_COV)
+    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_COV>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
+                       h->tw1.as<double2>(), seed, real, noise, X, cs);
+  else if (src == FF_SRC_ARRAY)
+    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_ARRAY>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
+                       h->tw1.as<double2>(), seed, real, noise, X, cs);
+  else
+    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_PHILOX>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
+                       h->tw1.as<double2>(), seed, real, noise, X, cs);
+}
+
+static void launch_p2(gss_fftgs* h, hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
+                     h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, h->X.as<double2>(), nullptr, 0.0);
+}
+
+// fft.jl:96-103 on the fused passes: covariance rows are produced inside P1 (no N-sized input array), then the y and
+// z forward passes; the amplitude kernel undoes the bit reversal while it writes the natural-order state.
+static int32_t fftgs_spectrum_fused(gss_fftgs* h, double* partial, hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  CovSrc cs;
+  cs.vg = h->vg;
+  cs.c1 = (int)h->g.c1; cs.c2 = (int)h->g.c2; cs.c3 = (int)h->g.c3;
+  cs.s1 = h->g.s1; cs.s2 = h->g.s2; cs.s3 = h->g.s3;
+  GSS_TRY(h->covsrc.alloc(sizeof(CovSrc)));
+  GSS_HIP(hipMemcpyAsync(h->covsrc.p, &cs, sizeof(CovSrc), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipStreamSynchronize(s));  // `cs` is a stack object
+  launch_p1(h, FF_SRC_COV, 0, 0, nullptr, s);
+  launch_p2(h, s);
+  hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n2 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n3), s, f, f.l3,
+                     h->tw3.as<double2>(), (int64_t)f.nhp, (int64_t)f.n2 * f.nhp, h->X.as<double2>(), nullptr, 0.0);
+  hipLaunchKernelGGL(ff_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, f, h->X.as<double2>(), h->Fh(), partial);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+// the state is complete (computed or adopted): derive what the realisation kernels read
+static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
+  double hs[2];
+  GSS_HIP(hipMemcpyAsync(hs, h->scal(), sizeof(hs), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  GSS_REQUIRE(hs[0] > 0.0 && std::isfinite(hs[1]) && hs[1] > 0.0, "degenerate spectrum (sum F^2 = %g)", hs[0]);
+  if (h->fused) {
+    const FusedGrid& f = h->fg;
+    const int64_t nt = (int64_t)f.n2 * f.ntx * f.n3 * FF_TX;
+    hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+    GSS_HIP(hipGetLastError());
+  }
+  h->ready = true;
   return GSS_OK;
 }
 
@@ -267,13 +355,11 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
   double2* X = h->X.as<double2>();
   {
     ProfScope ps("fftgs_p1", s);
-    hipLaunchKernelGGL(ff_x_fwd_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
-                       h->tw1.as<double2>(), seed, (uint32_t)real, noise, X);
+    launch_p1(h, noise ? FF_SRC_ARRAY : FF_SRC_PHILOX, seed, (uint32_t)real, noise, s);
   }
   {
     ProfScope ps("fftgs_p2", s);
-    hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
-                       h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, X, nullptr, 0.0);
+    launch_p2(h, s);
   }
   {
     ProfScope ps("fftgs_p3", s);
@@ -297,7 +383,6 @@ extern "C" {
 
 int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t ndim, const int64_t* dims,
                          const double* spacing, double mean, int32_t flags, void* stream) {
-  (void)flags;
   GSS_REQUIRE(out != nullptr, "gss_fftgs_create: out is NULL");
   *out = nullptr;
   GSS_REQUIRE(ndim >= 1 && ndim <= 3 && dims != nullptr, "FFTGS needs a 1-D, 2-D or 3-D Cartesian grid");
@@ -334,43 +419,34 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
   GSS_REQUIRE(h->N >= 2, "FFTGS needs at least two cells");
   hipStream_t s = to_stream(stream);
 
-  std::call_once(g_rocfft_once, [] { rocfft_setup(); });
-  size_t lengths[3] = {(size_t)d[0], (size_t)d[1], (size_t)d[2]};
-  GSS_FFT(rocfft_plan_create(&h->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                             rocfft_precision_double, (size_t)ndim, lengths, 1, nullptr));
-  GSS_FFT(rocfft_plan_create(&h->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                             rocfft_precision_double, (size_t)ndim, lengths, 1, nullptr));
-  size_t w1 = 0, w2 = 0;
-  GSS_FFT(rocfft_plan_get_work_buffer_size(h->fwd, &w1));
-  GSS_FFT(rocfft_plan_get_work_buffer_size(h->inv, &w2));
-  const size_t wb = w1 > w2 ? w1 : w2;
-  GSS_FFT(rocfft_execution_info_create(&h->info));
-  if (wb > 0) {
-    GSS_TRY(h->work.alloc(wb));
-    GSS_FFT(rocfft_execution_info_set_work_buffer(h->info, h->work.p, wb));
-  }
   GSS_TRY(h->state.alloc(sizeof(double) * (size_t)(h->NH + 2)));
-  GSS_TRY(h->U.alloc(sizeof(double) * (size_t)h->N));
-  GSS_TRY(h->X.alloc(sizeof(double) * 2 * (size_t)h->NH));
+  GSS_TRY(fftgs_setup_fused(h, s));  // decides the pipeline; allocates its buffers (no rocFFT plan on that path)
+  if (flags & GSS_FFTGS_NO_SPECTRUM) {  // the state arrives by broadcast (gss_fftgs_adopt_state)
+    GSS_HIP(hipStreamSynchronize(s));
+    guard.h = nullptr;
+    *out = h;
+    return GSS_OK;
+  }
 
-  // spectrum: C -> R2C -> sqrt|.| -> Parseval scale
+  // spectrum: C -> forward transform -> sqrt|.| -> Parseval scale
   DevBuf partial;
   GSS_TRY(partial.alloc(sizeof(double) * RED_BLOCKS));
-  hipLaunchKernelGGL(fftgs_cov_kernel, dim3(grid_blocks(h->N)), dim3(256), 0, s, h->vg, h->g, h->U.as<double>());
-  GSS_HIP(hipGetLastError());
-  GSS_TRY(fft_exec(h, h->fwd, h->U.p, h->X.p, s));
-  hipLaunchKernelGGL(fftgs_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->g, h->X.as<double2>(), h->Fh(),
-                     partial.as<double>());
+  if (h->fused) {
+    GSS_TRY(fftgs_spectrum_fused(h, partial.as<double>(), s));
+  } else {
+    GSS_TRY(ensure_rocfft(h));
+    hipLaunchKernelGGL(fftgs_cov_kernel, dim3(grid_blocks(h->N)), dim3(256), 0, s, h->vg, h->g, h->U.as<double>());
+    GSS_HIP(hipGetLastError());
+    GSS_TRY(fft_exec(h, h->fwd, h->U.p, h->Xn.p, s));
+    hipLaunchKernelGGL(fftgs_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->g, h->Xn.as<double2>(), h->Fh(),
+                       partial.as<double>());
+  }
   hipLaunchKernelGGL(fftgs_scale_kernel, dim3(1), dim3(64), 0, s, partial.as<double>(), RED_BLOCKS, h->vg.sill,
                      (double)h->N, h->scal());
   hipLaunchKernelGGL(fftgs_apply_scale_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->Fh(), h->NH,
                      h->scal());
   GSS_HIP(hipGetLastError());
-  GSS_HIP(hipStreamSynchronize(s));
-  double hs[2];
-  GSS_HIP(hipMemcpy(hs, h->scal(), sizeof(hs), hipMemcpyDeviceToHost));
-  GSS_REQUIRE(hs[0] > 0.0 && std::isfinite(hs[1]), "degenerate spectrum (sum F^2 = %g)", hs[0]);
-  GSS_TRY(fftgs_setup_fused(h, s));
+  GSS_TRY(fftgs_finish_state(h, s));
   guard.h = nullptr;
   *out = h;
   return GSS_OK;
@@ -383,6 +459,7 @@ int32_t gss_fftgs_destroy(gss_fftgs_t* h) {
 
 int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* stream) {
   GSS_REQUIRE(h != nullptr && f_out != nullptr, "gss_fftgs_spectrum: NULL argument");
+  GSS_REQUIRE(h->ready, "handle has no spectrum");
   hipStream_t s = to_stream(stream);
   Staged so;
   GSS_TRY(so.out(f_out, sizeof(double) * (size_t)h->N, mem));
@@ -399,11 +476,18 @@ int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes) {
   return GSS_OK;
 }
 
+int32_t gss_fftgs_adopt_state(gss_fftgs_t* h, void* stream) {
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  return fftgs_finish_state(h, to_stream(stream));
+}
+
 int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
                           const int64_t* inds, int64_t ninds, double* out, int32_t mem, void* stream) {
   GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_fftgs_realize: bad arguments");
+  GSS_REQUIRE(h->ready, "handle has no spectrum");
   if (nreals == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
+  if (!h->fused) GSS_TRY(ensure_rocfft(h));
   const int64_t N = h->N;
   const int64_t npts = inds ? ninds : N;
   Staged sn, si, so;
@@ -432,18 +516,18 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
     }
     {
       ProfScope ps("fftgs_fwd", s);
-      GSS_TRY(fft_exec(h, h->fwd, u, h->X.p, s));
+      GSS_TRY(fft_exec(h, h->fwd, u, h->Xn.p, s));
     }
     {
       ProfScope ps("fftgs_phase", s);
-      hipLaunchKernelGGL(fftgs_phase_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->X.as<double2>(), h->Fh(),
+      hipLaunchKernelGGL(fftgs_phase_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->Xn.as<double2>(), h->Fh(),
                          h->NH, h->mean);
       GSS_HIP(hipGetLastError());
     }
     double* z = inds ? h->Z.as<double>() : so.as<double>() + r * N;
     {
       ProfScope ps("fftgs_inv", s);
-      GSS_TRY(fft_exec(h, h->inv, h->X.p, z, s));
+      GSS_TRY(fft_exec(h, h->inv, h->Xn.p, z, s));
     }
     if (inds) {
       hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, z, si.as<int64_t>(),

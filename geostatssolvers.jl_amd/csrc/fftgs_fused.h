@@ -19,9 +19,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gss_internal.h"
 #include "philox.h"
 
 namespace gss {
+
+// source of the real input of P1
+enum { FF_SRC_PHILOX = 0,   // uniform noise generated in registers (fft.jl:163 `rand(rng, V, dims)`)
+       FF_SRC_ARRAY = 1,    // caller-supplied noise
+       FF_SRC_COV = 2 };    // covariance to the centre cell (fft.jl:96-99): the spectrum build runs on the same passes
+struct CovSrc {
+  VgDev vg;
+  int c1, c2, c3;     // 0-based centre cell
+  double s1, s2, s3;  // spacing
+};
 
 constexpr int FF_TX_LOG = 1;
 constexpr int FF_TX = 1 << FF_TX_LOG;  // lines per tile in the strided passes: 4 complex = 64 B per row; tiles 2u and
@@ -162,10 +173,11 @@ __device__ __forceinline__ void lds_fft_dit_inv(double2* buf, int logL, int pitc
 
 // ---- P1: noise -> half spectrum along x -------------------------------------------------------------
 // LDS: tw[n1/2] | Z[FF_ROWS][lds_line_pitch(n1/2)]
+template <int SRC>
 __global__ __launch_bounds__(FF_XTHREADS) void ff_x_fwd_kernel(FusedGrid g, const double2* __restrict__ tw1,
                                                               uint64_t seed, uint32_t real,
                                                               const double* __restrict__ noise,
-                                                              double2* __restrict__ X) {
+                                                              double2* __restrict__ X, const CovSrc* __restrict__ cs) {
   extern __shared__ __attribute__((aligned(16))) double2 sm[];
   const int M = g.n1 >> 1, logM = g.l1 - 1;
   const int MP = lds_line_pitch(M);
@@ -181,8 +193,18 @@ __global__ __launch_bounds__(FF_XTHREADS) void ff_x_fwd_kernel(FusedGrid g, cons
     double2 v = make_double2(0.0, 0.0);
     if (row < nrows) {
       const int64_t blk = row * M + nidx;  // elements 2 blk, 2 blk + 1 of the realisation
-      if (noise) v = reinterpret_cast<const double2*>(noise)[blk];
-      else philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)blk, v.x, v.y);
+      if (SRC == FF_SRC_ARRAY) {
+        v = reinterpret_cast<const double2*>(noise)[blk];
+      } else if (SRC == FF_SRC_COV) {
+        const int i2 = (int)(row % g.n2), i3 = (int)(row / g.n2);
+        const double zero[3] = {0.0, 0.0, 0.0};
+        double a[3] = {(double)(2 * nidx - cs->c1) * cs->s1, (double)(i2 - cs->c2) * cs->s2, (double)(i3 - cs->c3) * cs->s3};
+        v.x = cov_pair<3>(cs->vg, a, zero);
+        a[0] = (double)(2 * nidx + 1 - cs->c1) * cs->s1;
+        v.y = cov_pair<3>(cs->vg, a, zero);
+      } else {
+        philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)blk, v.x, v.y);
+      }
     }
     Z[r * MP + lphys(nidx)] = v;
   }
@@ -298,6 +320,34 @@ __global__ __launch_bounds__(FF_THREADS) void ff_axis_kernel(FusedGrid g, int lo
     const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
     base[(int64_t)j * lstride + c] = buf[c * LP + lphys(j)];
   }
+}
+
+// spectrum build on the fused passes: X holds the forward transform in the padded, (z, y) bit-reversed layout;
+// Fh[kz][ky][kx] = sqrt(|X[brev kz][brev ky][kx]|), DC = 0 (fft.jl:102-103); partial[b] = this block's share of
+// sum F^2 over the FULL spectrum (w = 2 for entries that stand for a conjugate pair)
+__global__ __launch_bounds__(256) void ff_amp_kernel(FusedGrid g, const double2* __restrict__ X, double* __restrict__ Fh,
+                                                     double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int64_t NH = (int64_t)g.nh * g.n2 * g.n3;
+  double acc = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
+    const int kx = (int)(idx % g.nh);
+    const int64_t r = idx / g.nh;
+    const int ky = (int)(r % g.n2), kz = (int)(r / g.n2);
+    const double2 x = X[((int64_t)brev_bits(kz, g.l3) * g.n2 + brev_bits(ky, g.l2)) * g.nhp + kx];
+    double f = sqrt(sqrt(x.x * x.x + x.y * x.y));
+    if (idx == 0) f = 0.0;
+    Fh[idx] = f;
+    const bool self = (kx == 0) || (2 * kx == g.n1);
+    acc += (self ? 1.0 : 2.0) * f * f;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
 // Fh (natural half spectrum [kz][ky][kx], nh fastest) -> tiled, bit-reversed order used by P3:

@@ -83,7 +83,11 @@ struct Staged {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Every C-ABI entry converts its `stream` argument here.  Scratch memory (the DevBuf pool, the kriging workspace) is
+// recycled without per-block events, which is only safe if everything the library queues is ordered; when a call
+// arrives on a different stream than the previous one, the new stream is made to wait for the work queued on the old
+// one (one event record + one stream wait, nothing when the process keeps to one stream).
+hipStream_t to_stream(void* s);
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
 // ---------------------------------------------------------------------------------------------

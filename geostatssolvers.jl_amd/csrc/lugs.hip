@@ -140,6 +140,12 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
   }
   GSS_HIP(hipMemsetAsync(h->d2(), 0, sizeof(double) * (size_t)ns, s));
 
+  if (flags & GSS_LUGS_NO_FACTOR) {  // the state arrives by broadcast (gss_lugs_adopt_state)
+    GSS_HIP(hipStreamSynchronize(s));
+    guard.h = nullptr;
+    *out = h;
+    return GSS_OK;
+  }
   if (ns > 0) {
     double* C22 = h->L22();
     GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
@@ -182,7 +188,6 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
   }
   GSS_HIP(hipStreamSynchronize(s));
   h->ready = true;
-  (void)flags;
   guard.h = nullptr;
   *out = h;
   return GSS_OK;

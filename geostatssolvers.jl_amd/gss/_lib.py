@@ -23,6 +23,8 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libgss_hip.so"))
 MEM_HOST, MEM_DEVICE = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ALLOC = range(7)
 KRIG_NO_FACTOR = 1
+FFTGS_NO_SPECTRUM = 1
+LUGS_NO_FACTOR = 1
 
 
 class GSSError(RuntimeError):
@@ -79,6 +81,7 @@ SIGNATURES = {
     "gss_fftgs_destroy": [_p],
     "gss_fftgs_spectrum": [_p, _p, _i32, _p],
     "gss_fftgs_state_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
+    "gss_fftgs_adopt_state": [_p, _p],
     "gss_fftgs_realize": [_p, _u64, _i64, _i64, _p, _p, _i64, _p, _i32, _p],
     "gss_lugs_create": [C.POINTER(_p), _VG, _p, _i64, _p, _p, _i64, _f64, _i32, _p],
     "gss_lugs_destroy": [_p],

@@ -71,6 +71,19 @@ def _prep_in(x, dtype=np.float64):
     return np.ascontiguousarray(x, dtype=dtype)
 
 
+def _alias_tensor(owner, dev_ptr, nbytes):
+    """CUDA float64 tensor aliasing `nbytes` of library-owned HBM at `dev_ptr` (for torch.distributed.broadcast over
+    RCCL); it keeps `owner` (the handle) alive."""
+    import torch
+
+    class _Alias:
+        __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (dev_ptr, False),
+                                    "version": 3, "strides": None}
+    t = torch.as_tensor(_Alias(), device=f"cuda:{torch.cuda.current_device()}")
+    t._gss_keepalive = owner
+    return t
+
+
 class KrigHandle:
     """gss_krig_t*: fitted kriging system living in HBM."""
 
@@ -100,19 +113,14 @@ class KrigHandle:
 
     def factor_tensor(self):
         """CUDA tensor aliasing the factor state (for torch.distributed.broadcast over RCCL)."""
-        import torch
         p, nb = C.c_void_p(), C.c_int64()
         check(self._l.gss_krig_factor_buffer(self._h, C.byref(p), C.byref(nb)))
-
-        class _Alias:
-            __cuda_array_interface__ = {"shape": (nb.value // 8,), "typestr": "<f8", "data": (p.value, False),
-                                        "version": 3, "strides": None}
-        t = torch.as_tensor(_Alias(), device=f"cuda:{torch.cuda.current_device()}")
-        t._gss_keepalive = self
-        return t
+        return _alias_tensor(self, p.value, nb.value)
 
     def adopt_factor(self):
         check(self._l.gss_krig_adopt_factor(self._h))
+
+    state_tensor, adopt_state = factor_tensor, adopt_factor      # the names parallel.replicate_state uses
 
     def predict_global(self, xdom, drift_dom=None):
         xdom = _prep_in(xdom)
@@ -163,7 +171,8 @@ class KrigHandle:
 class FFTGSHandle:
     """gss_fftgs_t*: spectral amplitude + rocFFT plans for one variable."""
 
-    def __init__(self, vg, dims, spacing=None, mean=0.0):
+    def __init__(self, vg, dims, spacing=None, mean=0.0, spectrum=True):
+        """`spectrum=False`: allocate the state only; it arrives by `state_tensor()` broadcast + `adopt_state()`."""
         self._l = _lib.lib()
         self.dims = tuple(int(d) for d in dims)
         nd = len(self.dims)
@@ -171,9 +180,19 @@ class FFTGSHandle:
         sp = (C.c_double * 3)(*([float(s) for s in (spacing if spacing is not None else [1.0] * nd)] + [1.0] * (3 - nd)))
         v = _vg_struct(vg, nd)
         h = C.c_void_p()
-        check(self._l.gss_fftgs_create(C.byref(h), C.byref(v), nd, d, sp, float(mean), 0, current_stream()))
+        check(self._l.gss_fftgs_create(C.byref(h), C.byref(v), nd, d, sp, float(mean),
+                                       0 if spectrum else _lib.FFTGS_NO_SPECTRUM, current_stream()))
         self._h = h
         self.N = int(np.prod(self.dims))
+
+    def state_tensor(self):
+        """CUDA tensor aliasing the spectral state (fft.jl:62-103 runs on one rank, the peers receive this)."""
+        p, nb = C.c_void_p(), C.c_int64()
+        check(self._l.gss_fftgs_state_buffer(self._h, C.byref(p), C.byref(nb)))
+        return _alias_tensor(self, p.value, nb.value)
+
+    def adopt_state(self):
+        check(self._l.gss_fftgs_adopt_state(self._h, current_stream()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -215,7 +234,8 @@ class FFTGSHandle:
 class LUGSHandle:
     """gss_lugs_t*: d2 and L22 in HBM for one variable."""
 
-    def __init__(self, vg, centroids, dlocs, z1, mean=0.0):
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True):
+        """`factor=False`: allocate the state only; it arrives by `state_tensor()` broadcast + `adopt_state()`."""
         self._l = _lib.lib()
         c = np.ascontiguousarray(centroids, dtype=np.float64)
         if c.ndim == 1:
@@ -226,10 +246,19 @@ class LUGSHandle:
         v = _vg_struct(vg, dim)
         h = C.c_void_p()
         check(self._l.gss_lugs_create(C.byref(h), C.byref(v), ptr(c), self.N, ptr(dl), ptr(zz), dl.size,
-                                      float(mean), 0, current_stream()))
+                                      float(mean), 0 if factor else _lib.LUGS_NO_FACTOR, current_stream()))
         self._h = h
         self.nd = int(dl.size)
         self.ns = self.N - self.nd
+
+    def state_tensor(self):
+        """CUDA tensor aliasing L22 and d2 (lu.jl:76-169 runs on one rank, the peers receive this)."""
+        p, nb = C.c_void_p(), C.c_int64()
+        check(self._l.gss_lugs_state_buffer(self._h, C.byref(p), C.byref(nb)))
+        return _alias_tensor(self, p.value, nb.value)
+
+    def adopt_state(self):
+        check(self._l.gss_lugs_adopt_state(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

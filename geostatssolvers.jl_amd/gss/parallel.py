@@ -1,12 +1,17 @@
 """Sharding of independent work over one-process-per-GPU ranks.
 
-Domain points (kriging) and realisations (FFTGS, LUGS) are independent given the factor /
-spectrum, so each rank takes a contiguous block and no data-path collective is needed.  The only
-collective is an optional broadcast of the factor state from rank 0 (RCCL over xGMI when the
-process group backend is `nccl`; `gloo` in the CPU tests)."""
+Domain points (kriging) and realisations (FFTGS, LUGS, SGS) are independent given the factor / spectrum, so each rank
+takes a contiguous block and the data path has no collective.  The reference makes the same cut: `preprocess` runs
+once and `solvesingle` is mapped over realisations (/root/reference/src/simulation/fft.jl:62,145, lu.jl:76,171).
+The one collective is the broadcast of the preprocess state from rank 0 (`replicate_state`): RCCL over xGMI when the
+process group backend is `nccl`, `gloo` in the CPU tests.  `all_gather_concat` (opt-in, `solve(..., gather=True)`)
+reassembles the full result on every rank for callers that want it.
+
+Collectives run on whichever device the process group serves: under an `nccl`-only group host arrays are staged
+through HBM, under `gloo` device tensors are staged through host memory."""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Callable, Tuple
 
 
 def world() -> Tuple[int, int]:
@@ -27,27 +32,101 @@ def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def _backend_map() -> dict:
+    """device type -> backend name of the default process group ("cpu:gloo,cuda:nccl" -> {cpu: gloo, cuda: nccl})."""
+    import torch.distributed as dist
+    cfg = str(dist.get_backend_config())
+    if ":" not in cfg:
+        return {"cpu": cfg, "cuda": cfg} if cfg == "gloo" else {"cuda": cfg}
+    return dict(part.split(":", 1) for part in cfg.split(","))
+
+
+def _collective_device(t):
+    """Device on which a collective over tensor `t` has to run for the default group."""
+    import torch
+    bm = _backend_map()
+    if t.is_cuda:
+        # gloo's device-tensor path is not relied upon on ROCm: stage through the host
+        return t.device if bm.get("cuda") == "nccl" else torch.device("cpu")
+    if "cpu" in bm:
+        return t.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def broadcast_(tensor, src: int = 0):
     """In-place broadcast of a state tensor from `src` (no-op for a single rank)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensor
+    dev = _collective_device(tensor)
+    if dev == tensor.device:
         dist.broadcast(tensor, src=src)
+    else:
+        staged = tensor.to(dev)
+        dist.broadcast(staged, src=src)
+        if dist.get_rank() != src:
+            tensor.copy_(staged)
     return tensor
 
 
+def replicate_state(make: Callable[[bool], object], share: str = "broadcast"):
+    """Preprocess once, realise everywhere (fft.jl:62,145; lu.jl:76,171).
+
+    `make(compute)` builds a handle; with `compute=False` it only allocates the state.  Rank 0 computes, the peers
+    receive `handle.state_tensor()` by broadcast and call `handle.adopt_state()`.  `share="recompute"` (or a single
+    rank, or an engine whose handles cannot alias their state) makes every rank compute instead.  A failure on rank 0
+    (e.g. a covariance that is not positive definite) is raised on every rank, not left as a hung broadcast."""
+    import torch
+    rank, ws = world()
+    if ws == 1 or share == "recompute":
+        return make(True)
+    if share != "broadcast":
+        raise ValueError(f"share={share!r}: 'broadcast' or 'recompute'")
+    flag = torch.zeros(1, dtype=torch.int32)
+    handle, err = None, None
+    if rank == 0:
+        try:
+            handle = make(True)
+            if not hasattr(handle, "state_tensor"):
+                flag[0] = 2                     # engine without aliasable state: everybody computes
+        except Exception as e:                  # noqa: BLE001 - re-raised below, after the peers have been told
+            err = e
+            flag[0] = 1
+    broadcast_(flag, 0)
+    code = int(flag.item())
+    if code == 1:
+        if err is not None:
+            raise err
+        raise RuntimeError("preprocess failed on rank 0")
+    if code == 2:
+        return handle if rank == 0 else make(True)
+    if rank != 0:
+        handle = make(False)
+    broadcast_(handle.state_tensor(), 0)
+    if rank != 0:
+        handle.adopt_state()
+    return handle
+
+
 def all_gather_concat(local, total: int):
-    """Gather contiguous shards back into the full array on every rank (numpy in, numpy out)."""
+    """Gather contiguous shards (axis 0) back into the full array on every rank.  numpy in -> numpy out, torch
+    tensor in -> torch tensor on the same device out."""
     import numpy as np
     import torch
     import torch.distributed as dist
     rank, ws = world()
     if ws == 1:
         return local
-    t = torch.as_tensor(np.ascontiguousarray(local))
+    is_np = not isinstance(local, torch.Tensor)
+    t = torch.as_tensor(np.ascontiguousarray(local)) if is_np else local.contiguous()
+    dev = _collective_device(t)
+    home = t.device
+    t = t.to(dev)
     sizes = [shard_range(total, r, ws) for r in range(ws)]
     maxlen = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((maxlen,) + tuple(t.shape[1:]), dtype=t.dtype)
+    pad = torch.zeros((maxlen,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
     pad[: t.shape[0]] = t
-    bufs = [torch.zeros_like(pad) for _ in range(ws)]
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad)
-    return np.concatenate([b[: hi - lo].numpy() for b, (lo, hi) in zip(bufs, sizes)], axis=0)
+    full = torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    return full.cpu().numpy() if is_np else full.to(home)

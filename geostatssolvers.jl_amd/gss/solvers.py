@@ -26,7 +26,7 @@ from .geo import Ensemble, GeoTable, PointSet, georef, parent, parentindices
 from .problems import EstimationProblem, SimulationProblem
 from .variograms import GaussianVariogram, MetricBall
 
-_GLOBAL_KEYS = {"rng", "threads", "init", "engine"}
+_GLOBAL_KEYS = {"rng", "threads", "init", "engine", "share"}
 
 
 class _Solver:
@@ -77,6 +77,11 @@ class _Solver:
     @property
     def engine(self):
         return self.globals.get("engine") or default_engine()
+
+    def _share(self, default):
+        """Multi-rank policy for the preprocess state: "broadcast" (rank 0 computes, RCCL broadcast to the peers) or
+        "recompute" (every rank computes its own copy) -- SURVEY.md section 8e offers both, picked by size."""
+        return self.globals.get("share") or default
 
 
 def _seed_from(rng) -> int:
@@ -176,8 +181,10 @@ class KrigingSolver(_Solver):
                             maxneighbors=p["maxneighbors"], nmax=nmax, searcher=kind, params=p)
         return pre
 
-    def solve(self, problem: EstimationProblem, gather: bool = True):
-        """krig.jl:130-164 with the domain points sharded over ranks (parallel.shard_range)."""
+    def solve(self, problem: EstimationProblem, gather: bool = False):
+        """krig.jl:130-164 with the domain points sharded over ranks (parallel.shard_range).  With several ranks each
+        one returns the estimates of its own block of domain points (no collective on the data path);
+        `gather=True` reassembles the full table on every rank."""
         pre = self.preprocess(problem)
         pdom = problem.domain
         xdom_all = pdom.centroids()
@@ -194,8 +201,11 @@ class KrigingSolver(_Solver):
                 drift_data = np.stack([[f(c) for f in p["drifts"]] for c in q["x"]]).astype(np.float64)
                 drift_dom = np.stack([[f(c) for f in p["drifts"]] for c in xdom]).astype(np.float64)
             exact = q["maxneighbors"] is None                          # krig.jl:151
-            h = self.engine.Krig(p["variogram"], q["variant"], q["x"], q["z"], mean=p["mean"], degree=p["degree"],
-                                 drift_data=drift_data, factor=exact)
+            mk = lambda compute: self.engine.Krig(p["variogram"], q["variant"], q["x"], q["z"], mean=p["mean"],  # noqa: E731
+                                                  degree=p["degree"], drift_data=drift_data, factor=compute)
+            # the fit (krig.jl:176) is replicated by default: below n ~ 2 000 recomputing the factor on every GPU is
+            # cheaper than any collective; share="broadcast" sends rank 0's factor instead
+            h = parallel.replicate_state(mk, self._share("recompute")) if exact else mk(False)
             try:
                 if hi > lo:
                     if exact:
@@ -256,7 +266,7 @@ class _NeighborEstimator(_Solver):
     def _estimate(self, p, x, z, xdom, nmax, radius, radii):
         raise NotImplementedError
 
-    def solve(self, problem: EstimationProblem, gather: bool = True):
+    def solve(self, problem: EstimationProblem, gather: bool = False):
         pdom = problem.domain
         coords = problem.data.domain.centroids()
         xdom_all = pdom.centroids()
@@ -347,7 +357,11 @@ class FFTGS(_Solver):
             vg = p["variogram"]
             if not vg.isstationary():
                 raise ValueError("variogram model must be stationary")              # fft.jl:91-93
-            h = self.engine.FFTGS(vg, pgrid.dims, pgrid.spacing, p["mean"])         # fft.jl:96-103
+            # fft.jl:96-103 on rank 0, state broadcast to the peers (preprocess once, realise many: fft.jl:62,145)
+            h = parallel.replicate_state(
+                lambda compute: self.engine.FFTGS(vg, pgrid.dims, pgrid.spacing, p["mean"],
+                                                  **({} if compute else {"spectrum": False})),
+                self._share("broadcast"))
             zbar = krig = dinds = cdev = None
             pdata = problem.data
             if pdata is not None and var in pdata.table:                             # fft.jl:106-135
@@ -386,9 +400,10 @@ class FFTGS(_Solver):
             pre[var] = dict(pre.get(var, {}), vg=vg, mean=p["mean"], handle=h, zbar=zbar, krig=krig, dinds=dinds)
         return pre
 
-    def solve(self, problem: SimulationProblem, gather: bool = True):
+    def solve(self, problem: SimulationProblem, gather: bool = False):
         """GeoStatsBase's realisation loop ([DEP]) batched: realisations are sharded
-        over ranks, each rank produces its block in one device call (fft.jl:145-198)."""
+        over ranks, each rank produces its block in one device call (fft.jl:145-198) and returns an Ensemble of its
+        own realisations (`gather=True`: of all of them, on every rank)."""
         pre = self.preprocess(problem)
         seed = _seed_from(self.globals.get("rng"))
         pdom = problem.domain
@@ -522,14 +537,17 @@ class LUGS(_Solver):
                 if p["mean"] is not None and dlocs.size > 0:
                     warnings.warn("mean can only be specified in unconditional simulation")   # lu.jl:142-144
                 mu = 0.0 if p["mean"] is None else float(p["mean"])                   # lu.jl:147
-                co[var] = self.engine.LUGS(vg, cent, dlocs, z1, mu)
+                # lu.jl:124-139 on rank 0, (L22, d2) broadcast to the peers (preprocess once: lu.jl:76,171)
+                co[var] = parallel.replicate_state(
+                    lambda compute: self.engine.LUGS(vg, cent, dlocs, z1, mu, **({} if compute else {"factor": False})),
+                    self._share("broadcast"))
             rho = None
             if len(conames) == 2:
                 rho = self.jparams[frozenset(conames)]["correlation"]                 # lu.jl:154-163
             pre[conames] = dict(handles=co, rho=rho)
         return pre
 
-    def solve(self, problem: SimulationProblem, gather: bool = True):
+    def solve(self, problem: SimulationProblem, gather: bool = False):
         pre = self.preprocess(problem)
         seed = _seed_from(self.globals.get("rng"))
         rank, ws = parallel.world()
@@ -601,7 +619,7 @@ class SGS(_Solver):
                                        p["minneighbors"], radius, radii)
         return pre
 
-    def solve(self, problem: SimulationProblem, gather: bool = True):
+    def solve(self, problem: SimulationProblem, gather: bool = False):
         pre = self.preprocess(problem)
         seed = _seed_from(self.globals.get("rng"))
         rank, ws = parallel.world()

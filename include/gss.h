@@ -18,7 +18,9 @@
  *   - `mem` says where the LARGE arrays of the call live: GSS_MEM_HOST (library copies through
  *     PCIe) or GSS_MEM_DEVICE (pointers are HBM addresses on the current device; nothing is
  *     copied and the call is asynchronous on `stream`).
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls may arrive on different streams:
+ *     the library recycles its scratch memory across calls, so a call on a new stream is ordered (event wait,
+ *     on the device) behind everything the library queued on the stream of the previous call.
  *   - handles are opaque, owned by the library, not thread-safe; the caller owns every buffer it
  *     passes and the library never returns memory it allocated.
  */
@@ -210,13 +212,17 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
  * centre cell, F = sqrt(|fft(fftshift(C))|), F[1] = 0.  dims[0] is the fastest axis (Julia
  * column-major), ndim in 1..3.
  */
+enum { GSS_FFTGS_NO_SPECTRUM = 1 /* the spectrum arrives by broadcast: allocate the state, compute nothing */ };
 int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t ndim, const int64_t* dims,
                          const double* spacing, double mean, int32_t flags, void* stream);
 int32_t gss_fftgs_destroy(gss_fftgs_t* h);
 /* full-size spectral amplitude F (prod(dims) doubles, element order) for parity checks */
 int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* stream);
-/* device address of the half-spectrum state for RCCL broadcast */
+/* device address + size of the state (rescaled half-spectrum amplitude, then sum F^2 and the rescale factor) so that
+ * rank 0's preprocess (fft.jl:62-103, run once) can be broadcast to the peer GPUs over RCCL, which then realise their
+ * share (fft.jl:145); after a broadcast into a handle created with GSS_FFTGS_NO_SPECTRUM call gss_fftgs_adopt_state. */
 int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes);
+int32_t gss_fftgs_adopt_state(gss_fftgs_t* h, void* stream);
 /* replaces solvesingle fft.jl:145-173 for realisations first_real .. first_real+nreals-1.
  * noise == NULL: Philox4x32-10 uniform noise keyed by (seed, realisation) generated on device;
  * else noise is nreals x N uniform values supplied by the caller (parity-test mode).
@@ -231,6 +237,7 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
  * L11, B12 = L11 \ C12, d2, L22 = chol(C22 - B12'B12).  centroids N x d point-major;
  * dlocs nd sorted 0-based data locations with values z1 (after initbuff, lu.jl:86,113-114).
  */
+enum { GSS_LUGS_NO_FACTOR = 1 /* L22 / d2 arrive by broadcast (lu.jl:76 runs on one rank): allocate, do not factorise */ };
 int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
                         const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
                         void* stream);
@@ -238,6 +245,8 @@ int32_t gss_lugs_destroy(gss_lugs_t* h);
 int32_t gss_lugs_info(const gss_lugs_t* h, int64_t* ns, int64_t* nd);
 /* copy out L22 (ns x ns, column-major, lower) and d2 (ns) for parity checks; either may be NULL */
 int32_t gss_lugs_factor(gss_lugs_t* h, double* l22, double* d2, int32_t mem, void* stream);
+/* device address + size of the state (L22 then d2) for the RCCL broadcast of SURVEY.md section 8e: rank 0 runs the
+ * preprocess, the peers create their handle with GSS_LUGS_NO_FACTOR, receive the state and call gss_lugs_adopt_state. */
 int32_t gss_lugs_state_buffer(gss_lugs_t* h, void** dev_ptr, int64_t* bytes);
 int32_t gss_lugs_adopt_state(gss_lugs_t* h);
 /* replaces solvesingle / lusim lu.jl:171-224: y2 = d2 + L22 * w  (w = rho*w1 + sqrt(1-rho^2)*w2

@@ -58,11 +58,34 @@ class _FFTGS:
 
 
 class _LUGS:
-    def __init__(self, vg, centroids, dlocs, z1, mean=0.0):
+    """`factor=False` + `state_tensor()` / `adopt_state()` mirror LUGSHandle so that the CPU-only multi-process test
+    drives parallel.replicate_state (rank 0 factorises, the peers receive L22 and d2 by broadcast)."""
+    ncomputed = 0          # class-wide count of factorisations actually carried out (the test reads it)
+
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True):
         c = np.asarray(centroids, dtype=np.float64)
         dl = np.asarray(dlocs, dtype=np.int64)
-        self.p = OL.preprocess(_ovg(vg), c, c[dl] if dl.size else None, np.asarray(z1) if dl.size else None, mean=mean)
+        if factor:
+            self.p = OL.preprocess(_ovg(vg), c, c[dl] if dl.size else None, np.asarray(z1) if dl.size else None,
+                                   mean=mean)
+            _LUGS.ncomputed += 1
+        else:
+            mask = np.zeros(c.shape[0], dtype=bool)
+            mask[dl] = True
+            ns = int((~mask).sum())
+            self.p = OL.LUGSParams(np.asarray(z1, dtype=np.float64), np.zeros(ns), np.zeros((ns, ns)),
+                                   0.0 if mean is None else float(mean), dl, np.flatnonzero(~mask))
         self.N, self.ns = c.shape[0], self.p.slocs.size
+        self._state = np.concatenate([self.p.L22.ravel(), self.p.d2])
+
+    def state_tensor(self):
+        import torch
+        return torch.from_numpy(self._state)       # aliases self._state: a broadcast writes into it
+
+    def adopt_state(self):
+        ns = self.ns
+        self.p.L22 = self._state[: ns * ns].reshape(ns, ns).copy()
+        self.p.d2 = self._state[ns * ns:].copy()
 
     def close(self):
         pass

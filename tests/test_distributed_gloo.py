@@ -32,6 +32,14 @@ def _problem_inputs():
     return xy, z, dom
 
 
+class _NotPosDef:
+    """Variogram stand-in whose covariance is not positive definite: makes rank 0's LUGS preprocess raise."""
+    kind, sill, nugget, range, nu, radii = "gaussian", 1.0, 0.0, 1e9, 1.0, None
+
+    def isstationary(self):
+        return True
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd"), HERE):
         if p not in sys.path:
@@ -49,27 +57,45 @@ def _worker(rank, world, port, q):
         prob = gss.EstimationProblem(gss.georef({"z": z}, xy), gss.PointSet(dom), "z")
         solver = gss.KrigingSolver(("z", dict(variogram=gss.ExponentialVariogram(range=20.0), maxneighbors=8)),
                                    engine=OracleEngine)
-        sol = gss.solve(prob, solver)
+        sol = gss.solve(prob, solver, gather=True)
         out["krig_mu"], out["krig_var"] = sol["z"], sol["z_variance"]
-        local = gss.solve(prob, solver, gather=False)
+        local = gss.solve(prob, solver)                   # default: every rank keeps its own block
         lo, hi = parallel.shard_range(101, rank, world)
         out["local_len"] = (len(local["z"]), hi - lo)
         # FFTGS / LUGS: realisations sharded; realisation r depends only on (seed, r)
         grid = gss.CartesianGrid(16, 12)
         s1 = gss.solve(gss.SimulationProblem(grid, ("z", float), 5),
-                       gss.FFTGS(("z", dict(variogram=gss.SphericalVariogram(range=5.0))), rng=9, engine=OracleEngine))
+                       gss.FFTGS(("z", dict(variogram=gss.SphericalVariogram(range=5.0))), rng=9, engine=OracleEngine),
+                       gather=True)
         out["fft"] = np.stack(s1["z"])
         S = gss.georef({"z": [0.0, 1.0]}, np.array([[2.0], [20.0]]))
+        from oracle_engine import _LUGS
+        before = _LUGS.ncomputed
         s2 = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
-                       gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine))
+                       gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine),
+                       gather=True)
         out["lu"] = np.stack(s2["z"])
+        # preprocess once (lu.jl:76): only rank 0 factorises, the peer adopts the broadcast state
+        out["lu_factorisations"] = _LUGS.ncomputed - before
+        s2r = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
+                        gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine,
+                                 share="recompute"))
+        lo_r, hi_r = parallel.shard_range(3, rank, world)
+        out["lu_local"] = (np.stack(s2r["z"]) if hi_r > lo_r else np.empty((0, 24)), lo_r, hi_r)
+        # a failure of rank 0's preprocess reaches every rank as an exception, not as a hung broadcast
+        try:
+            gss.solve(gss.SimulationProblem(gss.CartesianGrid(24), ("z", float), 2),
+                      gss.LUGS(("z", dict(variogram=_NotPosDef())), rng=9, engine=OracleEngine))
+            out["error_propagated"] = False
+        except Exception:                                   # noqa: BLE001
+            out["error_propagated"] = True
         # IDW / LWR shard estimation points, SGS shards realisations (section 8f rows)
-        si = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=6, exponent=2)), engine=OracleEngine))
-        sl = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9)), engine=OracleEngine))
+        si = gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=6, exponent=2)), engine=OracleEngine), gather=True)
+        sl = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=9)), engine=OracleEngine), gather=True)
         out["idw"], out["lwr"] = np.c_[si["z"], si["z_distance"]], np.c_[sl["z"], sl["z_variance"]]
         s3 = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
                        gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0), maxneighbors=5)), rng=9,
-                               engine=OracleEngine))
+                               engine=OracleEngine), gather=True)
         out["sgs"] = np.stack(s3["z"])
         # factor broadcast plumbing
         t = torch.arange(1000, dtype=torch.float64) * (1.0 if rank == 0 else -1.0)
@@ -137,6 +163,10 @@ def test_two_ranks_reproduce_single_process_results():
         assert out["local_len"][0] == out["local_len"][1]
         assert np.array_equal(out["fft"], np.stack(f["z"])) and np.array_equal(out["lu"], np.stack(l["z"]))
         assert out["bcast_ok"]
+        assert out["lu_factorisations"] == (1 if rank == 0 else 0)
+        got, lo_r, hi_r = out["lu_local"]
+        assert np.array_equal(got, np.stack(l["z"])[lo_r:hi_r])
+        assert out["error_propagated"]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -186,7 +216,30 @@ def _gpu_worker(rank, world, port, q):
     try:
         import gss
         torch.cuda.set_device(0)
-        out = {k: _as_array(gss.solve(prob, mk()), k) for k, (prob, mk) in _gpu_cases(gss).items()}
+        out = {k: _as_array(gss.solve(prob, mk(), gather=True), k) for k, (prob, mk) in _gpu_cases(gss).items()}
+        # the broadcast-adopt path spelled out on the C-ABI handles: the peer allocates only, cannot realise before
+        # the state has arrived, and afterwards produces rank 0's realisations
+        from gss import parallel
+        from gss._lib import GSSError
+        from gss.engine import FFTGSHandle, LUGSHandle
+        f = FFTGSHandle(gss.ExponentialVariogram(range=6.0), (32, 32, 16), spectrum=(rank == 0))
+        cent = gss.CartesianGrid(24, 16).centroids()
+        l = LUGSHandle(gss.SphericalVariogram(range=6.0), cent, [5, 77, 200], [0.5, -1.0, 2.0], factor=(rank == 0))
+        if rank != 0:
+            for h in (f, l):
+                try:
+                    h.realize(3, 0, 1)
+                    raise AssertionError("a handle without state must refuse to realise")
+                except GSSError:
+                    pass
+        for h in (f, l):
+            parallel.broadcast_(h.state_tensor(), 0)
+            if rank != 0:
+                h.adopt_state()
+        out["fft_adopt"] = f.realize(3, 0, 2)
+        out["lu_adopt"] = l.realize(3, 0, 2)[0]
+        f.close()
+        l.close()
         q.put((rank, out))
         dist.barrier()
     finally:
@@ -209,6 +262,12 @@ def test_two_ranks_on_one_gpu_reproduce_single_process_results():
         if pth not in sys.path:
             sys.path.insert(0, pth)
     import gss
+    from gss.engine import FFTGSHandle, LUGSHandle
+    f = FFTGSHandle(gss.ExponentialVariogram(range=6.0), (32, 32, 16))
+    l = LUGSHandle(gss.SphericalVariogram(range=6.0), gss.CartesianGrid(24, 16).centroids(), [5, 77, 200], [0.5, -1.0, 2.0])
+    fref, lref = f.realize(3, 0, 2), l.realize(3, 0, 2)[0]
+    for rank in (0, 1):
+        assert np.array_equal(results[rank]["fft_adopt"], fref) and np.array_equal(results[rank]["lu_adopt"], lref)
     for kind, (prob, mk) in _gpu_cases(gss).items():
         ref = _as_array(gss.solve(prob, mk()), kind)
         for rank in (0, 1):
