@@ -667,6 +667,10 @@ int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t 
 // Cholesky of a large block without its inverse, by panels (work: potrf_blocked_work_doubles(n) doubles).
 int64_t potrf_blocked_work_doubles(int64_t n);
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s);
+// lu.hip: A <- unit lower-triangular L of the partial-pivot LU P A = L U (`lu(A).L`, lu.jl:70); ipiv: n device ints,
+// *d_info (zeroed by the caller) = 1 + column of an exactly zero pivot.  mirror_lower: upper triangle <- lower'.
+int32_t getrf_unit_lower_f64(double* A, int64_t n, int64_t lda, int* ipiv, int* d_info, hipStream_t s);
+int32_t mirror_lower_f64(double* A, int64_t n, int64_t lda, hipStream_t s);
 // W = inv(L), lower, column-major; W's strict upper triangle must be zero on entry; T is scratch of
 // at least (n/2+64)^2 doubles; dinv (nullable) = cached leaf inverses from potrf_f64
 int32_t trtri_f64(const double* L, int64_t n, int64_t ldl, double* W, int64_t ldw, double* T, const double* dinv,

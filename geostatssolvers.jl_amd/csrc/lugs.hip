@@ -146,14 +146,18 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
     *out = h;
     return GSS_OK;
   }
+  const bool use_lu = (flags & GSS_LUGS_FACT_LU) != 0;                                           // lu.jl:107
+  GSS_TRY(dev_zero_bytes(info.p, sizeof(int), s));
   if (ns > 0) {
     double* C22 = h->L22();
     GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
     if (nd > 0) {
-      DevBuf C11, W11, C21, A21, w, scr, gwork;
+      DevBuf C11, W11, C21, A21, w, scr, gwork, ipiv;
+      GSS_TRY(ipiv.alloc(sizeof(int) * (size_t)nd));
       GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
       GSS_TRY(W11.alloc(sizeof(double) * (size_t)(nd * nd)));
-      GSS_TRY(scr.alloc(sizeof(double) * (size_t)(nd * nd)));
+      const int64_t tq = nd / 2 + 64;   // trtri_f64's scratch requirement
+      GSS_TRY(scr.alloc(sizeof(double) * (size_t)(nd * nd > tq * tq ? nd * nd : tq * tq)));
       GSS_TRY(C21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(A21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));
@@ -163,12 +167,20 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
       GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxd.as<double>(), nd, C11.as<double>(), nd, s));  // :131
       // row-major nd x ns == column-major ns x nd: C21                                                    // :132
       GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, C21.as<double>(), ns, s));
-      // L11 and W11 = inv(L11) together (lu.jl:134): the two solves below become products with W11
+      // L11 and W11 = inv(L11) (lu.jl:134): the two solves below become products with W11
       GSS_TRY(dev_zero_bytes(W11.p, W11.bytes, s));
-      GSS_TRY(potrf_inverse_f64(C11.as<double>(), nd, nd, W11.as<double>(), nd, scr.as<double>(), info.as<int>(), false,
-                                s));
-      GSS_TRY(check_info(info, "data covariance C11", s));
+      if (use_lu) {
+        GSS_TRY(getrf_unit_lower_f64(C11.as<double>(), nd, nd, ipiv.as<int>(), info.as<int>(), s));
+        GSS_TRY(check_info(info, "data covariance C11", s));
+        GSS_TRY(trtri_f64(C11.as<double>(), nd, nd, W11.as<double>(), nd, scr.as<double>(), nullptr, s));
+      } else {
+        GSS_TRY(potrf_inverse_f64(C11.as<double>(), nd, nd, W11.as<double>(), nd, scr.as<double>(), info.as<int>(),
+                                  false, s));
+        GSS_TRY(check_info(info, "data covariance C11", s));
+      }
       // A21 = C21 * inv(L11)'  (= B12', lu.jl:135)
+      // (with lu, W11 = inv(L11) of the pivoted factorisation: A21 * B12 is then no Schur complement, but it is what
+      //  lu.jl:135-139 computes)
       GSS_TRY(gemm_f64(ns, nd, nd, 1.0, C21.as<double>(), 1, ns, W11.as<double>(), nd, 1, 0.0, A21.as<double>(), 1, ns,
                        false, s, 1 /* W11' is upper triangular: half of the k-tiles are skipped */));
       // w = L11 \ z1 = W11 z1,  d2 = A21 w                                                               // :138
@@ -178,13 +190,21 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
       GSS_TRY(gemm_f64(ns, ns, nd, -1.0, A21.as<double>(), 1, ns, A21.as<double>(), ns, 1, 1.0, C22, 1, ns, true, s));
       GSS_HIP(hipStreamSynchronize(s));
     }
-    DevBuf work22;
-    GSS_TRY(work22.alloc(sizeof(double) * (size_t)potrf_blocked_work_doubles(ns)));
-    GSS_TRY(potrf_blocked_f64(C22, ns, ns, info.as<int>(), work22.as<double>(), s));                        // :128/:139
-    GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22", s));
-    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)ns), dim3(256), 0, s, C22, ns,
-                       ns);
-    GSS_HIP(hipGetLastError());
+    if (use_lu) {                                                                                           // :128/:139
+      if (nd > 0) GSS_TRY(mirror_lower_f64(C22, ns, ns, s));   // the update above wrote the lower tiles only
+      DevBuf ipiv2;
+      GSS_TRY(ipiv2.alloc(sizeof(int) * (size_t)ns));
+      GSS_TRY(getrf_unit_lower_f64(C22, ns, ns, ipiv2.as<int>(), info.as<int>(), s));
+      GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22", s));
+    } else {
+      DevBuf work22;
+      GSS_TRY(work22.alloc(sizeof(double) * (size_t)potrf_blocked_work_doubles(ns)));
+      GSS_TRY(potrf_blocked_f64(C22, ns, ns, info.as<int>(), work22.as<double>(), s));
+      GSS_TRY(check_info(info, nd > 0 ? "conditional covariance C22 - A21 B12" : "covariance C22", s));
+      hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)ns), dim3(256), 0, s, C22, ns,
+                         ns);
+      GSS_HIP(hipGetLastError());
+    }
   }
   GSS_HIP(hipStreamSynchronize(s));
   h->ready = true;

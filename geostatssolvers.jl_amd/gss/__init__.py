@@ -8,7 +8,7 @@ from .geo import (CartesianGrid, DomainView, Ensemble, GeoTable, PointSet, asarr
                   parentindices, view)
 from .problems import EstimationProblem, SimulationProblem
 from .solvers import (FFTGS, LUGS, SGS, ExpWeight, IDWSolver, KrigingSolver, LWRSolver, TricubeWeight, kriging_ui,
-                      searcher_ui, solve)
+                      searcher_ui, simulate_with_generic_loop, solve)
 from .variograms import (CubicVariogram, ExponentialVariogram, GaussianVariogram, MaternVariogram, MetricBall,
                          NestedVariogram, PentasphericalVariogram, PowerVariogram, SineHoleVariogram,
                          SphericalVariogram)

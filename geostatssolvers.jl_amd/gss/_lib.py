@@ -25,6 +25,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_AL
 KRIG_NO_FACTOR = 1
 FFTGS_NO_SPECTRUM = 1
 LUGS_NO_FACTOR = 1
+LUGS_FACT_LU = 2
 
 
 class GSSError(RuntimeError):
@@ -93,6 +94,7 @@ SIGNATURES = {
     "gss_philox_uniform": [_u64, _i64, _i64, _p, _i32, _p],
     "gss_philox_normal": [_u64, _i64, _i64, _p, _i32, _p],
     "gss_dev_potrf": [_p, _i64, _i64, _p],
+    "gss_dev_getrf_l": [_p, _i64, _i64, _p],
     "gss_dev_trtri": [_p, _i64, _i64, _p, _i64, _p],
     "gss_dev_gemm": [_i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _f64, _p, _i64, _i64, _i32, _p],
 }

@@ -234,8 +234,11 @@ class FFTGSHandle:
 class LUGSHandle:
     """gss_lugs_t*: d2 and L22 in HBM for one variable."""
 
-    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True):
-        """`factor=False`: allocate the state only; it arrives by `state_tensor()` broadcast + `adopt_state()`."""
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True, factorization="cholesky"):
+        """`factor=False`: allocate the state only; it arrives by `state_tensor()` broadcast + `adopt_state()`.
+        `factorization`: "cholesky" (default) or "lu" (lu.jl:70: the unit lower factor of a pivoted LU)."""
+        if factorization not in ("cholesky", "lu"):
+            raise ValueError(f"factorization={factorization!r}: 'cholesky' or 'lu'")
         self._l = _lib.lib()
         c = np.ascontiguousarray(centroids, dtype=np.float64)
         if c.ndim == 1:
@@ -246,7 +249,8 @@ class LUGSHandle:
         v = _vg_struct(vg, dim)
         h = C.c_void_p()
         check(self._l.gss_lugs_create(C.byref(h), C.byref(v), ptr(c), self.N, ptr(dl), ptr(zz), dl.size,
-                                      float(mean), 0 if factor else _lib.LUGS_NO_FACTOR, current_stream()))
+                                      float(mean), (0 if factor else _lib.LUGS_NO_FACTOR)
+                                      | (_lib.LUGS_FACT_LU if factorization == "lu" else 0), current_stream()))
         self._h = h
         self.nd = int(dl.size)
         self.ns = self.N - self.nd

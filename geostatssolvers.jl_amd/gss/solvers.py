@@ -93,6 +93,37 @@ def _seed_from(rng) -> int:
     return int(rng.integers(0, 2 ** 63 - 1))
 
 
+def _run_state(solver, problem):
+    """Realisation bookkeeping shared by `solve` (batched) and `solvesingle` (GeoStatsBase's loop calls it with four
+    positional arguments and NO realisation index -- test/dummy.jl:22, fft.jl:145, lu.jl:171, seq.jl:76): the seed is
+    drawn from `rng` once per preprocess and every covariable group counts its own calls, so the k-th call of the
+    loop produces realisation k - 1 -- exactly what `realize(seed, 0, nreals)` produces in one device call."""
+    return dict(seed=_seed_from(solver.globals.get("rng")), next={g: 0 for g in solver.covariables(problem)},
+                vindex={v: i for i, v in enumerate(problem.variables)})
+
+
+def _next_real(preproc, conames) -> int:
+    run = preproc["_run"]
+    r = run["next"][tuple(conames)]
+    run["next"][tuple(conames)] = r + 1
+    return r
+
+
+def simulate_with_generic_loop(problem, solver):
+    """[DEP] GeoStatsBase `solve(::SimulationProblem, ::SimulationSolver)` (SURVEY.md A.6) as the reference's solvers
+    are driven by it: `preprocess` once, then `solvesingle(problem, covars, solver, preproc)` nreals times per
+    covariable group, no index passed.  The product's `solve` batches the same realisations into one device call;
+    tests/test_gpu_generic_loop.py checks that both give the same ensemble."""
+    preproc = solver.preprocess(problem)
+    reals = {v: [] for v in problem.variables}
+    for conames in solver.covariables(problem):
+        for _ in range(problem.nreals):
+            out = solver.solvesingle(problem, conames, preproc)
+            for v in conames:
+                reals[v].append(out[v])
+    return Ensemble(problem.domain, reals)
+
+
 def _distance(p):
     """The search metric only matters without a neighbourhood (searcher_ui, ui.jl:25-31)."""
     from ._lib import metric_spec
@@ -397,57 +428,61 @@ class FFTGS(_Solver):
                 _, first = np.unique(found, return_index=True)
                 dinds = found[np.sort(first)]
                 pre[var] = dict(cent=cent, cdev=cdev)
-            pre[var] = dict(pre.get(var, {}), vg=vg, mean=p["mean"], handle=h, zbar=zbar, krig=krig, dinds=dinds)
+            pre[var] = dict(dict(cent=None, cdev=None), **pre.get(var, {}), vg=vg, mean=p["mean"], handle=h, zbar=zbar,
+                            krig=krig, dinds=dinds)
+        pre["_run"] = _run_state(self, problem)
         return pre
+
+    def _block(self, problem, pre, var, lo, count):
+        """Realisations lo .. lo+count-1 of `var` on the problem domain (fft.jl:145-198), shape (count, npts)."""
+        pdom = problem.domain
+        inds = parentindices(pdom)
+        q = pre[var]
+        seed = pre["_run"]["seed"] + pre["_run"]["vindex"][var]
+        if count <= 0:
+            return np.empty((0, pdom.nelements()))
+        cond = q["krig"] is not None
+        if cond and q["krig"].params(var)["maxneighbors"] is None and getattr(self.engine, "device_resident", False):
+            return self._condition_on_device(q, q["cent"], q["dinds"], seed, lo, count, inds)
+        zu = q["handle"].realize(seed, lo, count, inds=inds)
+        if not cond:
+            return zu
+        cent, dinds = q["cent"], q["dinds"]                                       # fft.jl:176-192
+        if q["krig"].params(var)["maxneighbors"] is None:
+            # one kriging system (same locations) serves every realisation: factor once, batch the data
+            h = self.engine.Krig(q["vg"], SK, cent[dinds], zu[0, dinds], mean=q["mean"])
+            try:
+                zbar_u = h.predict_global_batch(cent, np.ascontiguousarray(zu[:, dinds]))
+            finally:
+                h.close()
+            return q["zbar"][None, :] + (zu - zbar_u)                             # fft.jl:191
+        out = np.empty_like(zu)
+        for r in range(zu.shape[0]):
+            kdat = georef({var: zu[r, dinds]}, cent[dinds])
+            zbar_u = _solve_local(q["krig"], kdat, PointSet(cent), var)[var]
+            out[r] = q["zbar"] + (zu[r] - zbar_u)
+        return out
+
+    def solvesingle(self, problem: SimulationProblem, covars, preproc):
+        """fft.jl:145-198 with the reference's signature: one realisation per call, no index (see _run_state)."""
+        r = _next_real(preproc, covars)
+        return {var: self._block(problem, preproc, var, r, 1)[0] for var in covars}
 
     def solve(self, problem: SimulationProblem, gather: bool = False):
         """GeoStatsBase's realisation loop ([DEP]) batched: realisations are sharded
         over ranks, each rank produces its block in one device call (fft.jl:145-198) and returns an Ensemble of its
         own realisations (`gather=True`: of all of them, on every rank)."""
         pre = self.preprocess(problem)
-        seed = _seed_from(self.globals.get("rng"))
-        pdom = problem.domain
-        inds = parentindices(pdom)
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
         reals = {}
-        for vi, var in enumerate(problem.variables):
-            q = pre[var]
-            cond = q["krig"] is not None and hi > lo
-            on_device = (cond and q["krig"].params(var)["maxneighbors"] is None
-                         and getattr(self.engine, "device_resident", False))
-            if on_device:
-                zu = None
-            elif hi > lo:
-                zu = q["handle"].realize(seed + vi, lo, hi - lo, inds=inds)
-            else:
-                zu = np.empty((0, pdom.nelements()))
-            if cond:                                                                  # fft.jl:176-192
-                cent = q["cent"]
-                dinds = q["dinds"]
-                kp = q["krig"].params(var)
-                if on_device:
-                    zu = self._condition_on_device(q, cent, dinds, seed + vi, lo, hi - lo, inds)
-                elif kp["maxneighbors"] is None:
-                    # one kriging system (same locations) serves every realisation: factor once, batch the data
-                    h = self.engine.Krig(q["vg"], SK, cent[dinds], zu[0, dinds], mean=q["mean"])
-                    try:
-                        zbar_u = h.predict_global_batch(cent, np.ascontiguousarray(zu[:, dinds]))
-                    finally:
-                        h.close()
-                    zu = q["zbar"][None, :] + (zu - zbar_u)                           # fft.jl:191
-                else:
-                    out = np.empty_like(zu)
-                    for r in range(zu.shape[0]):
-                        kdat = georef({var: zu[r, dinds]}, cent[dinds])
-                        zbar_u = _solve_local(q["krig"], kdat, PointSet(cent), var)[var]
-                        out[r] = q["zbar"] + (zu[r] - zbar_u)
-                    zu = out
-            q["handle"].close()
+        for var in problem.variables:
+            zu = self._block(problem, pre, var, lo, hi - lo)
+            pre[var]["handle"].close()
             if gather and ws > 1:
                 zu = parallel.all_gather_concat(zu, problem.nreals)
             reals[var] = [zu[r] for r in range(zu.shape[0])]
-        return Ensemble(pdom, reals)
+        return Ensemble(problem.domain, reals)
 
 
 def _centroids_device(pdom):
@@ -517,10 +552,9 @@ class LUGS(_Solver):
                 p = self.params(var)
                 vg = p["variogram"]
                 assert vg.isstationary(), "variogram model must be stationary"      # lu.jl:110
-                if p["factorization"] != "cholesky":
-                    raise NotImplementedError(
-                        "factorization=lu: the reference uses only `.L` of a pivoted LU (lu.jl:128,134,139), "
-                        "which is not a square root of the covariance; the device path implements cholesky")
+                fact = p["factorization"]                                            # lu.jl:107
+                if fact not in ("cholesky", "lu"):
+                    raise ValueError(f"factorization={fact!r}: 'cholesky' or 'lu' (lu.jl:70)")
                 buff = np.zeros(N)
                 mask = np.zeros(N, dtype=bool)
                 pdata = problem.data
@@ -539,31 +573,42 @@ class LUGS(_Solver):
                 mu = 0.0 if p["mean"] is None else float(p["mean"])                   # lu.jl:147
                 # lu.jl:124-139 on rank 0, (L22, d2) broadcast to the peers (preprocess once: lu.jl:76,171)
                 co[var] = parallel.replicate_state(
-                    lambda compute: self.engine.LUGS(vg, cent, dlocs, z1, mu, **({} if compute else {"factor": False})),
+                    lambda compute: self.engine.LUGS(vg, cent, dlocs, z1, mu, **({} if compute else {"factor": False}),
+                                                     **({} if fact == "cholesky" else {"factorization": fact})),
                     self._share("broadcast"))
             rho = None
             if len(conames) == 2:
                 rho = self.jparams[frozenset(conames)]["correlation"]                 # lu.jl:154-163
             pre[conames] = dict(handles=co, rho=rho)
+        pre["_run"] = _run_state(self, problem)
         return pre
+
+    def _block(self, pre, conames, lo, count):
+        """lu.jl:171-196 for realisations lo .. lo+count-1 of one covariable group -> {var: (count, N)}."""
+        q = pre[conames]
+        run = pre["_run"]
+        v1 = conames[0]
+        y1, w1 = q["handles"][v1].realize(run["seed"] + run["vindex"][v1], lo, count)          # lu.jl:183-185
+        out = {v1: y1}
+        if len(conames) == 2:
+            v2 = conames[1]
+            y2, _ = q["handles"][v2].realize(run["seed"] + run["vindex"][v2], lo, count, rho=q["rho"], w1=w1)  # :188-193
+            out[v2] = y2
+        return out
+
+    def solvesingle(self, problem: SimulationProblem, covars, preproc):
+        """lu.jl:171-196 with the reference's signature: one realisation per call, no index (see _run_state)."""
+        r = _next_real(preproc, covars)
+        return {v: y[0] for v, y in self._block(preproc, tuple(covars), r, 1).items()}
 
     def solve(self, problem: SimulationProblem, gather: bool = False):
         pre = self.preprocess(problem)
-        seed = _seed_from(self.globals.get("rng"))
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
         reals = {}
-        vindex = {v: i for i, v in enumerate(problem.variables)}
-        for conames, q in pre.items():
-            v1 = conames[0]
-            y1, w1 = q["handles"][v1].realize(seed + vindex[v1], lo, hi - lo)          # lu.jl:183-185
-            out = {v1: y1}
-            if len(conames) == 2:
-                v2 = conames[1]
-                y2, _ = q["handles"][v2].realize(seed + vindex[v2], lo, hi - lo, rho=q["rho"], w1=w1)  # :188-193
-                out[v2] = y2
-            for v, y in out.items():
-                q["handles"][v].close()
+        for conames in self.covariables(problem):
+            for v, y in self._block(pre, conames, lo, hi - lo).items():
+                pre[conames]["handles"][v].close()
                 if gather and ws > 1:
                     y = parallel.all_gather_concat(y, problem.nreals)
                 reals[v] = [y[r] for r in range(y.shape[0])]
@@ -617,17 +662,25 @@ class SGS(_Solver):
             radius, radii = _ball(p["neighborhood"])
             pre[var] = self.engine.SGS(p["variogram"], cent, order, dlocs, zd, float(p["mean"]), nmax,
                                        p["minneighbors"], radius, radii)
+        pre["_run"] = _run_state(self, problem)
         return pre
+
+    def solvesingle(self, problem: SimulationProblem, covars, preproc):
+        """seq.jl:76-141 with the reference's signature: one realisation per call, no index (see _run_state)."""
+        r = _next_real(preproc, covars)
+        run = preproc["_run"]
+        return {var: preproc[var].realize(run["seed"] + run["vindex"][var], r, 1)[0] for var in covars}
 
     def solve(self, problem: SimulationProblem, gather: bool = False):
         pre = self.preprocess(problem)
-        seed = _seed_from(self.globals.get("rng"))
+        run = pre["_run"]
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
         reals = {}
-        for vi, var in enumerate(problem.variables):
+        for var in problem.variables:
             h = pre[var]
-            y = h.realize(seed + vi, lo, hi - lo) if hi > lo else np.empty((0, problem.domain.nelements()))
+            y = (h.realize(run["seed"] + run["vindex"][var], lo, hi - lo) if hi > lo
+                 else np.empty((0, problem.domain.nelements())))
             h.close()
             if gather and ws > 1:
                 y = parallel.all_gather_concat(y, problem.nreals)

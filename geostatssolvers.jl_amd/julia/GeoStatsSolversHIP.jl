@@ -8,7 +8,17 @@
 #
 # NOTE: there is no Julia toolchain in the build environment, so this file has never been executed;
 # the executable twin with identical logic is geostatssolvers.jl_amd/gss/solvers.py, which the test
-# suite drives through the same C-ABI.  Keep the two in step.
+# suite drives through the same C-ABI (tests/test_generic_loop.py replays GeoStatsBase's call sequence against
+# it).  Keep the two in step.
+#
+# Realisation indices.  GeoStatsBase's loop calls `solvesingle(problem, covars, solver, preproc)` with four
+# positional arguments and no realisation index (test/dummy.jl:22; fft.jl:145, lu.jl:171, seq.jl:76), while the
+# device noise is keyed on (seed, realisation).  `preprocess` therefore draws the seed from `solver.rng` once
+# (the reference consumes the same rng, fft.jl:147 / lu.jl:173) and creates one atomic call counter per
+# covariable group; the k-th `solvesingle` call of a group produces realisation k - 1.  `solve` is also
+# specialised for the three simulation solvers: it produces all realisations of a variable in ONE device call
+# (same indices, same fields) and frees the device state before returning.
+# Device handles live in this process: worker processes (`procs` other than `[myid()]`) are refused.
 module GeoStatsSolversHIP
 
 using Meshes
@@ -17,6 +27,9 @@ using Variography
 using GeoStatsBase
 using Tables
 using Random
+using Unitful
+using LinearAlgebra: cholesky, lu      # values of LUGS' `factorization` parameter (lu.jl:70)
+using Distributed: myid
 
 import GeoStatsBase: solve, preprocess, solvesingle
 
@@ -26,6 +39,65 @@ const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 
 const GSS_MEM_HOST = Int32(0)
 const GSS_KRIG_NO_FACTOR = Int32(1)
+const GSS_LUGS_FACT_LU = Int32(2)
+
+# ---- units (src/utils.jl:5-15): affine units are made absolute before the values are stripped for the device;
+#      estimates get the unit back, variances its square (krig.jl:94,160; idw.jl:109; lwr.jl:112,153) --------------
+elunit(x) = typeunit(nonmissingtype(eltype(x)))
+typeunit(::Type) = NoUnits
+typeunit(::Type{Q}) where {Q<:Quantity} = unit(Q)
+uadjust(x) = uadjust(elunit(x), x)
+uadjust(::Unitful.Units, x) = x
+uadjust(U::Unitful.AffineUnits, x) = map(v -> ismissing(v) ? missing : uconvert(absoluteunit(U), v), x)
+# (stripped Float64 values of the non-missing entries, unit to re-attach)
+function stripunits(vals)
+  z = uadjust(vals)
+  Float64.(ustrip.(collect(skipmissing(z)))), elunit(z)
+end
+
+# ---- device handles: owned by the library, destroyed by a finalizer (or explicitly at the end of `solve`) -------
+mutable struct Handle
+  ptr::Ptr{Cvoid}
+  kind::Symbol                     # :krig, :fftgs, :lugs, :sgs
+  function Handle(ptr, kind)
+    h = new(ptr, kind)
+    finalizer(destroy!, h)
+    h
+  end
+end
+function destroy!(h::Handle)
+  h.ptr == C_NULL && return nothing
+  if h.kind === :fftgs
+    ccall((:gss_fftgs_destroy, libgss), Int32, (Ptr{Cvoid},), h.ptr)
+  elseif h.kind === :lugs
+    ccall((:gss_lugs_destroy, libgss), Int32, (Ptr{Cvoid},), h.ptr)
+  elseif h.kind === :sgs
+    ccall((:gss_sgs_destroy, libgss), Int32, (Ptr{Cvoid},), h.ptr)
+  else
+    ccall((:gss_krig_destroy, libgss), Int32, (Ptr{Cvoid},), h.ptr)
+  end
+  h.ptr = C_NULL
+  nothing
+end
+Base.unsafe_convert(::Type{Ptr{Cvoid}}, h::Handle) = h.ptr
+
+# ---- realisation bookkeeping (see the header) ---------------------------------------------------------------------
+struct RunState
+  seed::UInt64
+  next::Dict{Any,Threads.Atomic{Int}}     # covars.names => number of solvesingle calls so far
+  vindex::Dict{Symbol,Int}                # variable => 0-based position among variables(problem)
+  owner::Int                              # process that owns the device handles
+end
+function RunState(problem, solver)
+  allcovars = covariables(problem, solver)
+  RunState(rand(solver.rng, UInt64), Dict{Any,Threads.Atomic{Int}}(c.names => Threads.Atomic{Int}(0) for c in allcovars),
+           Dict{Symbol,Int}(v => i - 1 for (i, v) in enumerate(keys(variables(problem)))), myid())
+end
+function nextreal!(run::RunState, conames)
+  run.owner == myid() || error("the device state of this preprocess lives in process $(run.owner); use procs=[myid()]")
+  Threads.atomic_add!(run.next[conames], 1)       # returns the value before the increment
+end
+varseed(run::RunState, var) = run.seed + UInt64(run.vindex[var])
 
 # ---- C structs ---------------------------------------------------------------------------
 struct GssVgExtra              # one additional nested structure of gss_variogram_t
@@ -148,7 +220,7 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
     zcol = Tables.getcolumn(Tables.columns(dtable), var)
     inds = findall(!ismissing, zcol)                                     # krig.jl:97
     isempty(inds) && throw(AssertionError("all samples of $var are missing, aborting..."))
-    z = Float64.(collect(skipmissing(zcol)))
+    z, u = stripunits(zcol)                                              # uadjust, krig.jl:94
     X = coordmatrix(view(ddomain, inds))
     n = length(z)
     # kriging_ui, ui.jl:40-50
@@ -161,7 +233,7 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
     elseif !isnothing(p.degree)
       variant, degree = Int32(2), Int32(p.degree)
     elseif !isnothing(p.mean)
-      variant, skmean = Int32(0), Float64(p.mean)
+      variant, skmean = Int32(0), (p.mean isa Quantity ? Float64(ustrip(u, p.mean)) : Float64(p.mean))
     end
     # searcher_ui, ui.jl:11-32
     exact = isnothing(p.maxneighbors)
@@ -203,8 +275,8 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
     end
     miss = status .!= 0                                                  # krig.jl:213-214
     inds = collect(traverse(pdomain, p.path))                            # results in traversal order, krig.jl:179-183
-    push!(μs, var => [miss[i] ? missing : μ[i] for i in inds])
-    push!(σs, Symbol(var, "_variance") => [miss[i] ? missing : σ²[i] for i in inds])
+    push!(μs, var => [miss[i] ? missing : μ[i] * u for i in inds])
+    push!(σs, Symbol(var, "_variance") => [miss[i] ? missing : σ²[i] * u^2 for i in inds])   # krig.jl:160
   end
   georef((; μs..., σs...), pdomain)                                      # krig.jl:163
 end
@@ -239,7 +311,7 @@ end
   @param path = LinearPath()
 end
 
-function neighbor_estimate(problem, solver, auxname, call)
+function neighbor_estimate(problem, solver, auxname, auxunit, call)
   pdata = data(problem)
   pdomain = domain(problem)
   dtable = values(pdata)
@@ -252,7 +324,7 @@ function neighbor_estimate(problem, solver, auxname, call)
     inds = findall(!ismissing, zcol)                                     # idw.jl:77, lwr.jl:80
     n = length(inds)
     @assert n > 0 "estimation requires data"
-    z = Float64.(ustrip.(collect(skipmissing(zcol))))                    # uadjust, idw.jl:109
+    z, u = stripunits(zcol)                                              # uadjust, idw.jl:109, lwr.jl:112
     X = coordmatrix(view(domain(pdata), inds))
     nmax = isnothing(p.maxneighbors) ? n : min(p.maxneighbors, n)        # idw.jl:93
     @assert p.minneighbors ≤ nmax "invalid min/max number of neighbors"
@@ -270,14 +342,14 @@ function neighbor_estimate(problem, solver, auxname, call)
     GC.@preserve X z X0 ir μ aux status check(call(p, X, z, n, d, X0, m, Int32(k), radius, ir, μ, aux, status))
     miss = status .!= 0                                                  # idw.jl:123-124
     inds = collect(traverse(pdomain, p.path))                            # results in traversal order, idw.jl:112-113
-    push!(μs, var => [miss[i] ? missing : μ[i] for i in inds])
-    push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] for i in inds])
+    push!(μs, var => [miss[i] ? missing : μ[i] * u for i in inds])
+    push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] * auxunit(u) for i in inds])
   end
   georef((; μs..., σs...), pdomain)
 end
 
 solve(problem::EstimationProblem, solver::IDWSolverHIP) =
-  neighbor_estimate(problem, solver, "_distance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
+  neighbor_estimate(problem, solver, "_distance", u -> NoUnits, (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
     @assert p.exponent > 0 "exponent must be positive"                   # idw.jl:96
     met, mpar = searchmetric(p)
     ccall((:gss_idw_predict, libgss), Int32,
@@ -288,7 +360,7 @@ solve(problem::EstimationProblem, solver::IDWSolverHIP) =
   end)
 
 solve(problem::EstimationProblem, solver::LWRSolverHIP) =
-  neighbor_estimate(problem, solver, "_variance", (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin
+  neighbor_estimate(problem, solver, "_variance", u -> u^2, (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin   # lwr.jl:153
     wk, wa, wp = weightspec(p.weightfun)
     met, mpar = searchmetric(p)
     ccall((:gss_lwr_predict, libgss), Int32,
@@ -298,6 +370,33 @@ solve(problem::EstimationProblem, solver::LWRSolverHIP) =
           GSS_MEM_HOST, C_NULL)
   end)
 
+# ---- simulation solvers: shared pieces ------------------------------------------------------------------------
+# Ensemble assembled as GeoStatsBase's loop does it (Dict(var => [Vector...]), SURVEY.md A.6; cookie.jl:82)
+function ensemble(problem, reals::Dict)
+  Ensemble(domain(problem), reals)
+end
+
+function ballspec(neighborhood)
+  radius, ir = -1.0, C_NULL
+  if !isnothing(neighborhood)
+    rs = ustrip.(radii(neighborhood))
+    length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
+  end
+  radius, ir
+end
+
+# nearest domain element of every point of X (d x n), 1-based: `search(point, KNearestSearch(pdomain, 1))`, fft.jl:129-132
+function nearest_elements(C::Matrix{Float64}, X::Matrix{Float64})
+  d, N = size(C)
+  n = size(X, 2)
+  idx = Vector{Int32}(undef, n); cnt = Vector{Int32}(undef, n)
+  GC.@preserve C X idx cnt check(ccall((:gss_knn_search, libgss), Int32,
+    (Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Float64, Ptr{Float64}, Int32, Float64, Ptr{Int32},
+     Ptr{Int32}, Int32, Ptr{Cvoid}), C, N, Int32(d), X, n, Int32(1), -1.0, C_NULL, Int32(0), 0.0, idx, cnt,
+    GSS_MEM_HOST, C_NULL))
+  Int.(idx) .+ 1
+end
+
 # ---- FFTGS ----------------------------------------------------------------------------------
 @simsolver FFTGSHIP begin
   @param variogram = GaussianVariogram()
@@ -306,50 +405,98 @@ solve(problem::EstimationProblem, solver::LWRSolverHIP) =
   @param maxneighbors = nothing
   @param neighborhood = nothing
   @param distance = Euclidean()
-  @global seed = rand(UInt64)
+  @global threads = Sys.CPU_THREADS    # accepted like fft.jl:58; there is no FFTW thread pool to configure
+  @global rng = Random.GLOBAL_RNG      # fft.jl:59: the Philox seed of a solve is `rand(rng, UInt64)`
 end
 
 function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
-  pgrid = parent(domain(problem))
+  pdata = data(problem)
+  pdomain = domain(problem)
+  pgrid = parent(pdomain)
   dims = Int64[size(pgrid)...]
   sp = Float64[ustrip.(spacing(pgrid))...]
-  preproc = Dict()
+  preproc = Dict{Any,Any}()
   for covars in covariables(problem, solver), var in covars.names
     p = covars.params[Set([var])]
-    vg = Ref(cvariogram(p.variogram, length(dims)))
+    γ, μ = p.variogram, p.mean
+    vg = Ref(cvariogram(γ, length(dims)))                                # throws ArgumentError if not stationary, fft.jl:91-93
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gss_fftgs_create, libgss), Int32,
                 (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Int32, Ptr{Int64}, Ptr{Float64}, Float64, Int32, Ptr{Cvoid}),
-                h, vg, Int32(length(dims)), dims, sp, Float64(p.mean), Int32(0), C_NULL))
-    preproc[var] = (handle=h[], μ=p.mean, γ=p.variogram)                # conditional extras: see solvers.py FFTGS
+                h, vg, Int32(length(dims)), dims, sp, Float64(μ), Int32(0), C_NULL))   # fft.jl:96-103
+    handle = Handle(h[], :fftgs)
+    # conditional simulation, fft.jl:105-135: krige the data, locate the data cells
+    z̄, krig, dinds = nothing, nothing, nothing
+    if !isnothing(pdata)
+      dtable = values(pdata)
+      ddomain = domain(pdata)
+      if var ∈ Tables.schema(dtable).names
+        kdat = georef(dtable, centroid.(ddomain))
+        kdom = PointSet(centroid.(pdomain))
+        prob = EstimationProblem(kdat, kdom, var)
+        krig = KrigingSolverHIP(var => (variogram=γ, mean=μ, minneighbors=p.minneighbors, maxneighbors=p.maxneighbors,
+                                        neighborhood=p.neighborhood, distance=p.distance))
+        z̄ = getproperty(solve(prob, krig), var)                          # fft.jl:125-126
+        found = nearest_elements(coordmatrix(pdomain), coordmatrix(ddomain))
+        dinds = unique(found)                                            # fft.jl:132
+      end
+    end
+    preproc[var] = (γ=γ, μ=μ, handle=handle, z̄=z̄, krig=krig, dinds=dinds)
   end
+  preproc[:_run] = RunState(problem, solver)
   preproc
 end
 
-function solvesingle(problem::SimulationProblem, covars::NamedTuple, solver::FFTGSHIP, preproc; real::Int=0)
+# realisations first .. first+count-1 of `var` on the problem domain, npts x count (fft.jl:163-173 for each)
+function fftgs_block(problem, preproc, var, first::Int, count::Int)
   pdomain = domain(problem)
-  inds = parentindices(pdomain)
   npts = nelements(pdomain)
-  varreal = map(collect(covars.names)) do var
-    h = preproc[var].handle
-    out = Vector{Float64}(undef, npts)
-    ii = Int64.(collect(inds) .- 1)                                      # 0-based on the C side
-    GC.@preserve out ii check(ccall((:gss_fftgs_realize, libgss), Int32,
-      (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}),
-      h, solver.seed, Int64(real), Int64(1), C_NULL, ii, Int64(npts), out, GSS_MEM_HOST, C_NULL))
-    var => out
+  ii = Int64.(collect(parentindices(pdomain)) .- 1)                      # 0-based on the C side, fft.jl:152,173
+  out = Matrix{Float64}(undef, npts, count)
+  count == 0 && return out
+  par = preproc[var]
+  GC.@preserve out ii check(ccall((:gss_fftgs_realize, libgss), Int32,
+    (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}),
+    par.handle, varseed(preproc[:_run], var), Int64(first), Int64(count), C_NULL, ii, Int64(npts), out, GSS_MEM_HOST,
+    C_NULL))
+  isnothing(par.krig) && return out
+  # conditioning, fft.jl:176-192: krige the unconditional values at the data cells, add the residual field
+  kdom = PointSet(centroid.(pdomain))
+  ddomain = view(pdomain, par.dinds)
+  for r in 1:count
+    zᵤ = view(out, :, r)
+    kdat = georef((; var => zᵤ[par.dinds]), centroid.(ddomain))
+    z̄ᵤ = getproperty(solve(EstimationProblem(kdat, kdom, var), par.krig), var)
+    zᵤ .= par.z̄ .+ (zᵤ .- z̄ᵤ)                                            # fft.jl:191
   end
-  Dict(varreal)
+  out
+end
+
+function solvesingle(problem::SimulationProblem, covars::NamedTuple, solver::FFTGSHIP, preproc)
+  r = nextreal!(preproc[:_run], covars.names)
+  Dict(var => fftgs_block(problem, preproc, var, r, 1)[:, 1] for var in covars.names)
+end
+
+function solve(problem::SimulationProblem, solver::FFTGSHIP; procs=[myid()])
+  procs == [myid()] || error("FFTGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  preproc = preprocess(problem, solver)
+  reals = Dict{Symbol,Vector{Vector{Float64}}}()
+  for covars in covariables(problem, solver), var in covars.names
+    Z = fftgs_block(problem, preproc, var, 0, nreals(problem))           # one device call for all realisations
+    reals[var] = [Z[:, r] for r in 1:nreals(problem)]
+    destroy!(preproc[var].handle)
+  end
+  ensemble(problem, reals)
 end
 
 # ---- LUGS -------------------------------------------------------------------------------------
 @simsolver LUGSHIP begin
   @param variogram = GaussianVariogram()
   @param mean = nothing
-  @param factorization = cholesky          # only cholesky is implemented on the device
+  @param factorization = cholesky
   @jparam correlation = 0.0
   @global init = NearestInit()
-  @global seed = rand(UInt64)
+  @global rng = Random.GLOBAL_RNG      # lu.jl:73
 end
 
 function preprocess(problem::SimulationProblem, solver::LUGSHIP)
@@ -357,53 +504,75 @@ function preprocess(problem::SimulationProblem, solver::LUGSHIP)
   buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # lu.jl:86
   C = coordmatrix(pdomain)
   d, N = size(C)
-  preproc = Dict()
+  preproc = Dict{Any,Any}()
   for covars in covariables(problem, solver)
     conames = covars.names
     @assert length(conames) ∈ (1, 2) "invalid number of covariables"                    # lu.jl:96
-    coparams = Dict()
+    coparams = Dict{Any,Any}()
     for var in conames
       p = covars.params[Set([var])]
       dlocs = Int64.(findall(mask[var]) .- 1)                                           # lu.jl:113
       z₁ = Float64.(buff[var][findall(mask[var])])
       !isnothing(p.mean) && !isempty(dlocs) && @warn "mean can only be specified in unconditional simulation"
       μ = isnothing(p.mean) ? 0.0 : Float64(p.mean)
+      flags = p.factorization === cholesky ? Int32(0) : GSS_LUGS_FACT_LU                # lu.jl:70,107
       vg = Ref(cvariogram(p.variogram, d))
       h = Ref{Ptr{Cvoid}}(C_NULL)
       GC.@preserve C dlocs z₁ check(ccall((:gss_lugs_create, libgss), Int32,
         (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Float64, Int32,
-         Ptr{Cvoid}), h, vg, C, N, dlocs, z₁, length(dlocs), μ, Int32(0), C_NULL))
-      coparams[Set([var])] = (handle=h[], N=N, ns=N - length(dlocs))
+         Ptr{Cvoid}), h, vg, C, N, dlocs, z₁, length(dlocs), μ, flags, C_NULL))
+      coparams[Set([var])] = (handle=Handle(h[], :lugs), N=N, ns=N - length(dlocs))
     end
     length(conames) == 2 && (coparams[conames] = covars.params[conames].correlation)    # lu.jl:154-163
     push!(preproc, conames => coparams)
   end
+  preproc[:_run] = RunState(problem, solver)
   preproc
 end
 
-function lusim_hip(par, seed, real, ρ=nothing, w₁=nothing)                               # lu.jl:198-224
-  y = Vector{Float64}(undef, par.N)
-  w₂ = Vector{Float64}(undef, par.ns)
-  GC.@preserve y w₂ w₁ check(ccall((:gss_lugs_realize, libgss), Int32,
+# lusim (lu.jl:198-224) for realisations first .. first+count-1: (N x count fields, ns x count normals used)
+function lusim_hip(par, seed, first::Int, count::Int, ρ=nothing, W₁=nothing)
+  Y = Matrix{Float64}(undef, par.N, count)
+  W₂ = Matrix{Float64}(undef, par.ns, count)
+  count == 0 && return Y, W₂
+  GC.@preserve Y W₂ W₁ check(ccall((:gss_lugs_realize, libgss), Int32,
     (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
-     Ptr{Cvoid}), par.handle, seed, Int64(real), Int64(1), C_NULL, isnothing(ρ) ? 0.0 : Float64(ρ),
-    isnothing(w₁) ? C_NULL : pointer(w₁), y, w₂, GSS_MEM_HOST, C_NULL))
-  y, w₂
+     Ptr{Cvoid}), par.handle, seed, Int64(first), Int64(count), C_NULL, isnothing(ρ) ? 0.0 : Float64(ρ),
+    isnothing(W₁) ? C_NULL : pointer(W₁), Y, W₂, GSS_MEM_HOST, C_NULL))
+  Y, W₂
 end
 
-function solvesingle(::SimulationProblem, covars::NamedTuple, solver::LUGSHIP, preproc; real::Int=0)
-  conames = covars.names
+function lugs_block(preproc, conames, first::Int, count::Int)                            # lu.jl:171-196
+  run = preproc[:_run]
   coparams = preproc[conames]
   vars = collect(conames)
-  v₁ = first(vars)
-  Y₁, w₁ = lusim_hip(coparams[Set([v₁])], solver.seed, real)
-  result = Dict(v₁ => Y₁)
+  v₁ = Base.first(vars)
+  Y₁, W₁ = lusim_hip(coparams[Set([v₁])], varseed(run, v₁), first, count)
+  result = Dict{Symbol,Matrix{Float64}}(v₁ => Y₁)
   if length(conames) == 2
     v₂ = last(vars)
-    Y₂, _ = lusim_hip(coparams[Set([v₂])], solver.seed + 1, real, coparams[conames], w₁)
-    push!(result, v₂ => Y₂)
+    Y₂, _ = lusim_hip(coparams[Set([v₂])], varseed(run, v₂), first, count, coparams[conames], W₁)
+    result[v₂] = Y₂
   end
   result
+end
+
+function solvesingle(::SimulationProblem, covars::NamedTuple, solver::LUGSHIP, preproc)
+  r = nextreal!(preproc[:_run], covars.names)
+  Dict(var => Y[:, 1] for (var, Y) in lugs_block(preproc, covars.names, r, 1))
+end
+
+function solve(problem::SimulationProblem, solver::LUGSHIP; procs=[myid()])
+  procs == [myid()] || error("LUGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  preproc = preprocess(problem, solver)
+  reals = Dict{Symbol,Vector{Vector{Float64}}}()
+  for covars in covariables(problem, solver)
+    for (var, Y) in lugs_block(preproc, covars.names, 0, nreals(problem))   # one GEMM L22 * W for all realisations
+      reals[var] = [Y[:, r] for r in 1:nreals(problem)]
+      destroy!(preproc[covars.names][Set([var])].handle)
+    end
+  end
+  ensemble(problem, reals)
 end
 
 # ---- SGS (sgs.jl:45-89 over seq.jl:42-141) -----------------------------------------------------
@@ -416,7 +585,7 @@ end
   @param neighborhood = nothing
   @param distance = Euclidean()
   @global init = NearestInit()
-  @global seed = rand(UInt64)
+  @global rng = Random.GLOBAL_RNG      # sgs.jl:54
 end
 
 function preprocess(problem::SimulationProblem, solver::SGSHIP)
@@ -424,10 +593,11 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
   buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # seq.jl:85
   C = coordmatrix(pdomain)
   d, N = size(C)
-  preproc = Dict()
+  preproc = Dict{Any,Any}()
   for covars in covariables(problem, solver), var in covars.names
     p = covars.params[Set([var])]
-    path = Int64.(collect(traverse(pdomain, p.path)) .- 1)               # one visiting order for all realisations
+    p.distance isa Euclidean || throw(ArgumentError("SGSHIP: only the Euclidean search distance is available"))
+    path = Int64.(collect(traverse(pdomain, p.path)) .- 1)               # one visiting order per preprocess
     dlocs = Int64.(findall(mask[var]) .- 1)
     zdata = Float64.(buff[var][mask[var]])
     k = p.maxneighbors
@@ -435,11 +605,7 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
       @warn "Invalid maximum number of neighbors. Adjusting to $N..."
       k = N
     end
-    radius, ir = -1.0, C_NULL
-    if !isnothing(p.neighborhood)
-      rs = ustrip.(radii(p.neighborhood))
-      length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
-    end
+    radius, ir = ballspec(p.neighborhood)
     vg = Ref(cvariogram(p.variogram, d))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve C path dlocs zdata ir check(ccall((:gss_sgs_create, libgss), Int32,
@@ -447,21 +613,37 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
        Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
       h, vg, Float64(p.mean), C, N, Int32(d), path, dlocs, zdata, length(dlocs), Int32(k), Int32(p.minneighbors),
       radius, ir, Int32(0), C_NULL))
-    preproc[var] = (handle=h[], N=N)
+    preproc[var] = (handle=Handle(h[], :sgs), N=N)
   end
+  preproc[:_run] = RunState(problem, solver)
   preproc
 end
 
-function solvesingle(::SimulationProblem, covars::NamedTuple, solver::SGSHIP, preproc; real::Int=0)
-  varreal = map(collect(covars.names)) do var
-    h, N = preproc[var]
-    out = Vector{Float64}(undef, N)
-    GC.@preserve out check(ccall((:gss_sgs_realize, libgss), Int32,
-      (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Cvoid}),
-      h, solver.seed, Int64(real), Int64(1), C_NULL, out, GSS_MEM_HOST, C_NULL))
-    var => out
+function sgs_block(preproc, var, first::Int, count::Int)
+  par = preproc[var]
+  out = Matrix{Float64}(undef, par.N, count)
+  count == 0 && return out
+  GC.@preserve out check(ccall((:gss_sgs_realize, libgss), Int32,
+    (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Cvoid}),
+    par.handle, varseed(preproc[:_run], var), Int64(first), Int64(count), C_NULL, out, GSS_MEM_HOST, C_NULL))
+  out
+end
+
+function solvesingle(::SimulationProblem, covars::NamedTuple, solver::SGSHIP, preproc)
+  r = nextreal!(preproc[:_run], covars.names)
+  Dict(var => sgs_block(preproc, var, r, 1)[:, 1] for var in covars.names)
+end
+
+function solve(problem::SimulationProblem, solver::SGSHIP; procs=[myid()])
+  procs == [myid()] || error("SGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  preproc = preprocess(problem, solver)
+  reals = Dict{Symbol,Vector{Vector{Float64}}}()
+  for covars in covariables(problem, solver), var in covars.names
+    Z = sgs_block(preproc, var, 0, nreals(problem))                      # lanes = realisations: one sweep for all
+    reals[var] = [Z[:, r] for r in 1:nreals(problem)]
+    destroy!(preproc[var].handle)
   end
-  Dict(varreal)
+  ensemble(problem, reals)
 end
 
 end # module

@@ -237,7 +237,12 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
  * L11, B12 = L11 \ C12, d2, L22 = chol(C22 - B12'B12).  centroids N x d point-major;
  * dlocs nd sorted 0-based data locations with values z1 (after initbuff, lu.jl:86,113-114).
  */
-enum { GSS_LUGS_NO_FACTOR = 1 /* L22 / d2 arrive by broadcast (lu.jl:76 runs on one rank): allocate, do not factorise */ };
+enum {
+  GSS_LUGS_NO_FACTOR = 1, /* L22 / d2 arrive by broadcast (lu.jl:76 runs on one rank): allocate, do not factorise */
+  GSS_LUGS_FACT_LU = 2    /* solver parameter `factorization = lu` (lu.jl:70,107): L11 and L22 are the unit lower
+                           * factors `lu(Symmetric(.)).L` of a partial-pivot LU, exactly as the reference takes them
+                           * (they are not square roots of the covariance); default is `cholesky` */
+};
 int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
                         const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
                         void* stream);
@@ -290,6 +295,8 @@ int32_t gss_philox_normal(uint64_t seed, int64_t real, int64_t n, double* out, i
  * column-major, lower triangle; potrf overwrites the lower triangle of a with L; trtri writes
  * inv(L) (lower) to w.  Device pointers only. */
 int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream);
+/* a (n x n, full) <- unit lower-triangular L of the partial-pivot LU P a = L U (LAPACK getrf pivoting rule) */
+int32_t gss_dev_getrf_l(double* a, int64_t n, int64_t lda, void* stream);
 int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_t ldw, void* stream);
 /* D = alpha * A * B + beta * D with arbitrary element strides (A is M x K, B is K x N) */
 int32_t gss_dev_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i,

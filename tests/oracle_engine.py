@@ -62,12 +62,12 @@ class _LUGS:
     drives parallel.replicate_state (rank 0 factorises, the peers receive L22 and d2 by broadcast)."""
     ncomputed = 0          # class-wide count of factorisations actually carried out (the test reads it)
 
-    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True):
+    def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True, factorization="cholesky"):
         c = np.asarray(centroids, dtype=np.float64)
         dl = np.asarray(dlocs, dtype=np.int64)
         if factor:
             self.p = OL.preprocess(_ovg(vg), c, c[dl] if dl.size else None, np.asarray(z1) if dl.size else None,
-                                   mean=mean)
+                                   mean=mean, factorization=factorization)
             _LUGS.ncomputed += 1
         else:
             mask = np.zeros(c.shape[0], dtype=bool)

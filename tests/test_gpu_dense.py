@@ -100,3 +100,20 @@ def test_potrf_reports_indefinite():
     dA = _t(A)
     code = l.gss_dev_potrf(_lib.ptr(dA), 100, 100, _lib.current_stream())
     assert code == _lib.ERR_NOT_POSDEF and "pivot at row 70" in _lib.last_error()
+
+
+@pytest.mark.parametrize("n", [1, 7, 32, 33, 100, 257, 1500])
+def test_getrf_unit_lower_matches_lapack(n):
+    """gss_dev_getrf_l: `lu(A).L` with LAPACK's pivoting rule (first row of maximal |a|), on matrices that do pivot."""
+    import scipy.linalg as sla
+    import torch
+    from gss import _lib
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)) + 0.5 * np.eye(n)
+    dA = _t(A.T)                                     # column-major image
+    _lib.check(_lib.lib().gss_dev_getrf_l(_lib.ptr(dA), n, n, _lib.current_stream()))
+    torch.cuda.synchronize()
+    L = dA.cpu().numpy().T
+    P, Lref, U = sla.lu(A)
+    assert not np.array_equal(P, np.eye(n)) or n < 3
+    assert np.max(np.abs(L - Lref)) < 1e-10 * max(1.0, np.max(np.abs(np.linalg.inv(U))) * 1e-3)

@@ -216,3 +216,44 @@ def test_fused_pipeline_512_cube_properties():
     ratio = A[sel] / F[sel]
     assert float((ratio.max() - ratio.min()) / ratio.mean()) < 1e-8
     h.close()
+
+
+@pytest.mark.parametrize("dims", POW2_GRIDS)
+def test_fused_spectrum_matches_oracle(dims):
+    """On power-of-two 3-D grids gss_fftgs_create builds F on the library's own passes (covariance rows generated
+    inside the x pass, y and z forward passes, amplitude kernel undoing the bit reversal) -- fft.jl:96-103.
+    Same 1e-12 (relative to max F) as the rocFFT build of the general grids."""
+    kw = dict(range=0.3 * dims[0], sill=1.7, nugget=0.2)
+    h = _handle("exponential", dims, (1.0, 2.0, 0.5), **kw)
+    F = h.spectrum()
+    h.close()
+    pre = O.preprocess(Variogram("exponential", **kw), dims, spacing=(1.0, 2.0, 0.5))
+    assert F[0] == 0.0
+    assert np.max(np.abs(F - pre.F.ravel())) < 1e-12 * pre.F.max()
+    ha = _handle("gaussian", dims, radii=(0.2 * dims[0], 5.0, 3.0))
+    Fa = ha.spectrum()
+    ha.close()
+    prea = O.preprocess(Variogram("gaussian", radii=(0.2 * dims[0], 5.0, 3.0)), dims)
+    assert np.max(np.abs(Fa - prea.F.ravel())) < 1e-6 * prea.F.max()
+
+
+@pytest.mark.parametrize("dims", [(64, 32, 16), (24, 20, 16), (100, 100)])
+def test_state_broadcast_adopt(dims):
+    """fft.jl:62 runs once: a handle created with GSS_FFTGS_NO_SPECTRUM refuses to realise, receives another
+    handle's state (what torch.distributed.broadcast does between ranks) and then reproduces its realisations."""
+    import gss
+    from gss._lib import GSSError
+    from gss.engine import FFTGSHandle
+    vg = gss.SphericalVariogram(range=0.3 * dims[0], sill=1.3, nugget=0.1)
+    a = FFTGSHandle(vg, dims, mean=0.25)
+    b = FFTGSHandle(vg, dims, mean=0.25, spectrum=False)
+    with pytest.raises(GSSError, match="no spectrum"):
+        b.realize(5, 0, 1)
+    ta, tb = a.state_tensor(), b.state_tensor()
+    assert ta.shape == tb.shape and ta.is_cuda and ta.data_ptr() != tb.data_ptr()
+    tb.copy_(ta)
+    b.adopt_state()
+    assert np.array_equal(a.realize(5, 3, 2), b.realize(5, 3, 2))
+    assert np.array_equal(a.spectrum(), b.spectrum())
+    a.close()
+    b.close()

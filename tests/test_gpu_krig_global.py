@@ -234,3 +234,35 @@ def test_nested_variograms_all_paths():
     L22, d2 = lh.factor()
     assert np.max(np.abs(L22 - p.L22)) < 1e-9 and np.max(np.abs(d2 - p.d2)) < 1e-9
 
+
+
+def test_calls_on_different_streams_are_ordered():
+    """The library recycles scratch memory (buffer pool, the R workspace of the quadratic form) across calls; a call
+    on another stream is chained behind the previous one on the device (gss.h, `stream`), so handles driven from
+    different torch streams give the results of sequential execution."""
+    import torch
+    import gss
+    from gss.engine import KrigHandle, OK
+    rng = np.random.default_rng(77)
+    xa, xb = rng.uniform(0, 100, (700, 3)), rng.uniform(0, 100, (900, 3))
+    za, zb = rng.normal(size=700), rng.normal(size=900)
+    x0 = torch.as_tensor(rng.uniform(0, 100, (200_000, 3)), device="cuda")
+    va, vb = gss.MaternVariogram(range=30.0, order=1.5), gss.ExponentialVariogram(range=25.0)
+    ha, hb = KrigHandle(va, OK, xa, za), KrigHandle(vb, OK, xb, zb)
+    ref_a = [t.clone() for t in ha.predict_global(x0)]
+    ref_b = [t.clone() for t in hb.predict_global(x0)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(3):
+        with torch.cuda.stream(s1):
+            oa = ha.predict_global(x0)
+        with torch.cuda.stream(s2):
+            ob = hb.predict_global(x0)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert all(torch.equal(p, q) for p, q in zip(oa, ref_a))
+        assert all(torch.equal(p, q) for p, q in zip(ob, ref_b))
+    ha.close()
+    hb.close()

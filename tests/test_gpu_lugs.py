@@ -106,10 +106,11 @@ def test_reference_cases_through_solve_api():
     sol = gss.solve(gss.SimulationProblem(gss.CartesianGrid(40, 40), ("z", float), 3),
                     gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(ball, nugget=1e-3))), rng=123))
     assert len(sol["z"]) == 3 and np.all(np.isfinite(sol["z"][2]))
-    # custom factorization (lu.jl:66-76): `lu` is documented as unsupported on the device
-    with pytest.raises(NotImplementedError):
-        gss.solve(gss.SimulationProblem(S, D, "z", 1),
-                  gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), factorization="lu")), rng=1))
+    # custom factorization (test/simulation/lu.jl:66-76): both run, as in the reference
+    for fact in ("lu", "cholesky"):
+        sol = gss.solve(gss.SimulationProblem(S, D, "z", 1),
+                        gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), factorization=fact)), rng=123))
+        assert np.all(np.isfinite(sol[0].z)) and np.allclose(sol[0].z[near], [0.0, 1.0, 0.0, 1.0, 0.0])
     with pytest.warns(UserWarning, match="mean can only be specified in unconditional simulation"):
         gss.solve(gss.SimulationProblem(S, D, "z", 1),
                   gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), mean=1.0)), rng=1))
@@ -186,3 +187,55 @@ def test_batched_means_more_vectors_than_one_pass_and_drifts(variant, okw, dim, 
     for b in sorted({0, 15, min(16, nb - 1), nb - 1}):
         ref, _ = K.exactsolve(kvar, ov, x, zb[b], x0, mean=okw.get("mean") or 0.0, degree=okw.get("degree"))
         assert np.max(np.abs(out[b] - ref)) < 1e-9
+
+
+def test_state_broadcast_adopt():
+    """lu.jl:76 runs once: a handle created with GSS_LUGS_NO_FACTOR refuses to realise, receives (L22, d2) from
+    another handle (what torch.distributed.broadcast does between ranks) and then reproduces its realisations."""
+    import gss
+    from gss._lib import GSSError
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids((30, 17))
+    dlocs = np.sort(np.random.default_rng(3).permutation(30 * 17)[:40])
+    z1 = np.random.default_rng(4).normal(size=40)
+    vg = gss.SphericalVariogram(range=9.0, nugget=0.05)
+    a = LUGSHandle(vg, cent, dlocs, z1)
+    b = LUGSHandle(vg, cent, dlocs, z1, factor=False)
+    with pytest.raises(GSSError, match="no factor"):
+        b.realize(1, 0, 1)
+    tb = b.state_tensor()
+    tb.copy_(a.state_tensor())
+    b.adopt_state()
+    ya, wa = a.realize(7, 2, 3)
+    yb, wb = b.realize(7, 2, 3)
+    assert np.array_equal(ya, yb) and np.array_equal(wa, wb)
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("dims,ndata", [((100,), 5), ((100,), 0), ((24, 18), 30), ((40, 33), 200)])
+def test_lu_factorization_matches_oracle(dims, ndata):
+    """`factorization = lu` (lu.jl:70,107): L11 and L22 are `lu(Symmetric(.)).L`, the unit lower factor of LAPACK's
+    partial-pivot LU with the permutation dropped -- reproduced as the reference computes it (oracle: scipy's getrf).
+    Same tolerance as the Cholesky path: factors and realisations 1e-9."""
+    from gss.engine import LUGSHandle
+    import gss
+    cent = offt.grid_centroids(dims)
+    N = cent.shape[0]
+    rng = np.random.default_rng(N + ndata)
+    dlocs = np.sort(rng.permutation(N)[:ndata])
+    z1 = rng.normal(size=ndata)
+    kw = dict(range=0.3 * dims[0], nugget=0.05)
+    h = LUGSHandle(gss.SphericalVariogram(**kw), cent, dlocs, z1, factorization="lu")
+    p = O.preprocess(Variogram("spherical", **kw), cent, cent[dlocs] if ndata else None, z1 if ndata else None,
+                     factorization="lu")
+    l22, d2 = h.factor()
+    assert np.allclose(np.diag(l22), 1.0) and np.max(np.abs(np.triu(l22, 1))) == 0.0
+    assert np.max(np.abs(l22 - p.L22)) < 1e-9 and np.max(np.abs(d2 - p.d2)) < 1e-9
+    ns = N - ndata
+    noise = np.random.default_rng(1).normal(size=(2, ns))
+    y, _ = h.realize(0, 0, 2, noise=noise)
+    for r in range(2):
+        ref, _ = O.lusim(p, noise[r])
+        assert np.max(np.abs(y[r] - ref)) < 1e-9
+    h.close()

@@ -116,9 +116,14 @@ def test_fftgs_and_lugs_through_solve_with_stand_in():
     sol = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(30), "z", 2),
                     gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=3, engine=OracleEngine))
     assert len(sol) == 2 and sol[0].z.shape == (30,)
-    with pytest.raises(NotImplementedError, match="factorization=lu"):
+    # custom factorization (test/simulation/lu.jl:66-76): `lu` and `cholesky` both run; anything else is refused
+    s_lu = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(30), "z", 1),
+                     gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0), factorization="lu")), rng=3,
+                              engine=OracleEngine))
+    assert np.all(np.isfinite(s_lu[0].z)) and not np.array_equal(s_lu[0].z, sol[0].z)
+    with pytest.raises(ValueError, match="factorization"):
         gss.solve(gss.SimulationProblem(gss.CartesianGrid(10), ("z", float), 1),
-                  gss.LUGS(("z", dict(factorization="lu")), engine=OracleEngine))
+                  gss.LUGS(("z", dict(factorization="qr")), engine=OracleEngine))
     with pytest.raises(AssertionError):                                                        # lu.jl:96
         l3 = gss.LUGS((("a", "b", "c"), {}), engine=OracleEngine)
         gss.solve(gss.SimulationProblem(gss.CartesianGrid(5), (("a", float), ("b", float), ("c", float)), 1), l3)
