@@ -170,6 +170,8 @@ struct gss_fftgs {
   bool fused = false;
   FusedGrid fg;
   DevBuf X, tw1, tw2, tw3, Fh_tiled, covsrc;
+  int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
+  int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
   ~gss_fftgs() {
@@ -238,6 +240,40 @@ static int32_t upload_twiddles(DevBuf& buf, int L, hipStream_t s) {
 }
 
 static size_t ff_axis_lds(int L) { return sizeof(double2) * (size_t)(L / 2 + FF_TX * lds_line_pitch(L)); }
+static size_t ff_axis2_lds(int L, int txlog) { return sizeof(double2) * (size_t)(L / 2 + (L << txlog) + FF2_PAD); }
+static int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
+// strided pass `mode` (0 forward, 1 inverse, 2 forward-phase-inverse) along y (axis 1) or z (axis 2)
+template <int MODE>
+static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  const int L = axis == 1 ? f.n2 : f.n3, logL = axis == 1 ? f.l2 : f.l3, nouter = axis == 1 ? f.n3 : f.n2;
+  const double2* tw = axis == 1 ? h->tw2.as<double2>() : h->tw3.as<double2>();
+  const int64_t ostride = axis == 1 ? (int64_t)f.n2 * f.nhp : (int64_t)f.nhp;
+  const int64_t lstride = axis == 1 ? (int64_t)f.nhp : (int64_t)f.n2 * f.nhp;
+  double2* X = h->X.as<double2>();
+  const double* fh = MODE == 2 ? h->Fh_tiled.as<double>() : nullptr;
+  const double mean = MODE == 2 ? h->mean : 0.0;
+  if (h->axis_gen == 1) {
+    hipLaunchKernelGGL(ff_axis_kernel<MODE>, dim3((unsigned)(nouter * f.ntx)), dim3(FF_THREADS), ff_axis_lds(L), s, f, logL,
+                       tw, ostride, lstride, X, fh, mean);
+  } else {
+    const int txlog = axis == 1 ? h->txy_log : h->txz_log;
+    const unsigned blocks = (unsigned)(nouter * (f.nhp >> txlog));
+    const size_t lds = ff_axis2_lds(L, txlog);
+    if (txlog == 3)
+      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride, X,
+                         fh, mean);
+    else
+      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 2, 256>), dim3(blocks), dim3(256), lds, s, f, logL, tw, ostride, lstride, X,
+                         fh, mean);
+  }
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
 static size_t ff_xfwd_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * lds_line_pitch(M)); }
 static size_t ff_xinv_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * (M + 1) + FF_ROWS * lds_line_pitch(M)); }
 
@@ -280,6 +316,19 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
                               (int)ff_axis_lds(lmax)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_axis_lds(lmax)));
+  // generation 2 of the strided passes: 8-column tiles (4 when a 1024-point line would not leave room in LDS);
+  // GSS_FFTGS_AXIS=1 / GSS_FFTGS_TXY / GSS_FFTGS_TXZ (log2 of the tile width) are A/B switches
+  h->axis_gen = env_int("GSS_FFTGS_AXIS", 2) == 1 ? 1 : 2;
+  h->txy_log = env_int("GSS_FFTGS_TXY", f.n2 > 512 ? 2 : 3) == 2 ? 2 : 3;
+  h->txz_log = env_int("GSS_FFTGS_TXZ", f.n3 > 512 ? 2 : 3) == 2 ? 2 : 3;
+#define GSS_A2_ATTR(MODE, TXL, NT)                                                                                  \
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_kernel<MODE, TXL, NT>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(lmax, TXL)))
+  if (h->txy_log == 3 || h->txz_log == 3) {
+    GSS_A2_ATTR(0, 3, 512); GSS_A2_ATTR(1, 3, 512); GSS_A2_ATTR(2, 3, 512);
+  }
+  GSS_A2_ATTR(0, 2, 256); GSS_A2_ATTR(1, 2, 256); GSS_A2_ATTR(2, 2, 256);
+#undef GSS_A2_ATTR
   h->fused = true;
   return GSS_OK;
 }
@@ -303,11 +352,7 @@ static void launch_p1(gss_fftgs* h, int src, uint64_t seed, uint32_t real, const
                        h->tw1.as<double2>(), seed, real, noise, X, cs);
 }
 
-static void launch_p2(gss_fftgs* h, hipStream_t s) {
-  const FusedGrid& f = h->fg;
-  hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
-                     h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, h->X.as<double2>(), nullptr, 0.0);
-}
+static void launch_p2(gss_fftgs* h, hipStream_t s) { (void)launch_axis_mode<0>(h, 1, s); }
 
 // fft.jl:96-103 on the fused passes: covariance rows are produced inside P1 (no N-sized input array), then the y and
 // z forward passes; the amplitude kernel undoes the bit reversal while it writes the natural-order state.
@@ -322,8 +367,7 @@ static int32_t fftgs_spectrum_fused(gss_fftgs* h, double* partial, hipStream_t s
   GSS_HIP(hipStreamSynchronize(s));  // `cs` is a stack object
   launch_p1(h, FF_SRC_COV, 0, 0, nullptr, s);
   launch_p2(h, s);
-  hipLaunchKernelGGL(ff_axis_kernel<0>, dim3((unsigned)(f.n2 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n3), s, f, f.l3,
-                     h->tw3.as<double2>(), (int64_t)f.nhp, (int64_t)f.n2 * f.nhp, h->X.as<double2>(), nullptr, 0.0);
+  GSS_TRY(launch_axis_mode<0>(h, 2, s));
   hipLaunchKernelGGL(ff_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, f, h->X.as<double2>(), h->Fh(), partial);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
@@ -338,7 +382,12 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
   if (h->fused) {
     const FusedGrid& f = h->fg;
     const int64_t nt = (int64_t)f.n2 * f.ntx * f.n3 * FF_TX;
-    hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+    if (h->axis_gen == 1)
+      hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+    else if (h->txz_log == 3)
+      hipLaunchKernelGGL(ff_tile_fh2_kernel<3>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+    else
+      hipLaunchKernelGGL(ff_tile_fh2_kernel<2>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
     GSS_HIP(hipGetLastError());
   }
   h->ready = true;
@@ -363,13 +412,11 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
   }
   {
     ProfScope ps("fftgs_p3", s);
-    hipLaunchKernelGGL(ff_axis_kernel<2>, dim3((unsigned)(f.n2 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n3), s, f, f.l3,
-                       h->tw3.as<double2>(), (int64_t)f.nhp, (int64_t)f.n2 * f.nhp, X, h->Fh_tiled.as<double>(), h->mean);
+    GSS_TRY(launch_axis_mode<2>(h, 2, s));
   }
   {
     ProfScope ps("fftgs_p4", s);
-    hipLaunchKernelGGL(ff_axis_kernel<1>, dim3((unsigned)(f.n3 * f.ntx)), dim3(FF_THREADS), ff_axis_lds(f.n2), s, f, f.l2,
-                       h->tw2.as<double2>(), (int64_t)f.n2 * f.nhp, (int64_t)f.nhp, X, nullptr, 0.0);
+    GSS_TRY(launch_axis_mode<1>(h, 1, s));
   }
   {
     ProfScope ps("fftgs_p5", s);

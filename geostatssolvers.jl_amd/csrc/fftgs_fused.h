@@ -350,6 +350,229 @@ __global__ __launch_bounds__(256) void ff_amp_kernel(FusedGrid g, const double2*
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// =====================================================================================================
+// Strided passes, second generation (ff_axis2_kernel).  Same mathematics and the same bit-reversed data order as
+// ff_axis_kernel above; what changes is where the data sit between the radix passes:
+//   * the FIRST pass of a transform takes its inputs straight from global memory into registers and the LAST pass
+//     stores its outputs straight from registers (a radix-R item holds R rows of one column; lanes run over the
+//     columns of a tile first, so every load / store instruction moves whole 16 * TX byte row pieces);
+//   * in P3 the last forward pass, the phase step (fft.jl:163) and the first inverse pass act on the same R
+//     consecutive line elements, so they run back to back in registers;
+//   * LDS only carries the exchanges between passes: 2 round trips and 2 barriers for a 512-point line where the
+//     first generation needs 4 and 5 (P3: 4 and 4 instead of 9 and 10).
+// Tiles are TX = 8 columns wide (128-B row pieces: whole cache lines, no reliance on two workgroups meeting in L2)
+// or 4; the LDS image is row-major [j][c] with the rows of each 16-slot window permuted (a2_phys) so that the
+// d = 1 pass (rows 8 r + q for consecutive r) and the unit-stride passes are both bank-conflict free for the lane
+// groups of ds_read/write_b128.
+// The inverse transform runs its remainder radix (log2 L mod 3 stages) FIRST, so that its first pass covers the
+// same elements as the last forward pass.
+constexpr int FF2_PAD = 0;
+
+// LDS slot (16-B units) of tile element (row j, column c): rows are permuted inside every aligned window of
+// 16 / TX rows (one window = 16 slots = all 64 banks) by XOR with bits of j >> 3, so that rows 8 r + q of
+// consecutive r -- the d = 1 pass -- fall on different bank groups while unit-stride row runs stay conflict free
+template <int TXLOG>
+__device__ __forceinline__ int a2_phys(int j, int c) {
+  if (TXLOG >= 4) return (j << TXLOG) + c;
+  constexpr int WL = 4 - TXLOG;            // log2 rows per window
+  constexpr int RW = 1 << WL;
+  return ((j >> WL) << 4) + ((((j ^ (j >> 3)) & (RW - 1)) << TXLOG) | c);
+}
+
+// forward DIF butterflies of stages s0 .. s0+NS-1 on the R = 2^NS elements e0 + q d of one column (d = 2^logd)
+template <int NS>
+__device__ __forceinline__ void a2_dif(double2 (&x)[1 << NS], int p, int logd, int s0, const double2* tw) {
+  constexpr int R = 1 << NS;
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int span = R >> (u + 1);
+    const int s = s0 + u;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      if ((q & span) == 0) {
+        const int pos = p + ((q & (span - 1)) << logd);
+        const double2 w = tw[pos << s];
+        const double2 a = x[q], c = x[q + span];
+        x[q] = make_double2(a.x + c.x, a.y + c.y);
+        x[q + span] = cmul(make_double2(a.x - c.x, a.y - c.y), w);
+      }
+    }
+  }
+}
+
+// inverse DIT butterflies of stages s0 .. s0+NS-1 (element spacing d = 2^s0)
+template <int NS>
+__device__ __forceinline__ void a2_dit(double2 (&x)[1 << NS], int p, int s0, int logL, const double2* tw) {
+  constexpr int R = 1 << NS;
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int span = 1 << u;
+    const int s = s0 + u;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      if ((q & span) == 0) {
+        const int pos = p + ((q & (span - 1)) << s0);
+        const double2 w = cconj(tw[pos << (logL - 1 - s)]);
+        const double2 a = x[q], c = cmul(x[q + span], w);
+        x[q] = make_double2(a.x + c.x, a.y + c.y);
+        x[q + span] = make_double2(a.x - c.x, a.y - c.y);
+      }
+    }
+  }
+}
+
+enum { A2_GLOBAL = 0, A2_LDS = 1, A2_PHASE = 2 };
+
+// One pass over the tile.  FWD: DIF stages s0..s0+NS-1, else DIT.  SRC: A2_GLOBAL | A2_LDS.
+// DST: A2_GLOBAL | A2_LDS | A2_PHASE (forward only: phase step, then the DIT stages 0..NS-1, result to LDS).
+template <int NS, bool FWD, int SRC, int DST, int TXLOG, int NT>
+__device__ __forceinline__ void a2_pass(double2* __restrict__ gbase, int64_t lstride, double2* buf, const double2* tw,
+                                        int logL, int s0, int tid, const double* __restrict__ fh, bool dc_tile,
+                                        double mean) {
+  constexpr int R = 1 << NS;
+  constexpr int TX = 1 << TXLOG;
+  const int logd = FWD ? (logL - s0 - NS) : s0;
+  const int d = 1 << logd;
+  const int nitems = (TX << logL) >> NS;
+  for (int it = tid; it < nitems; it += NT) {
+    const int c = it & (TX - 1);
+    const int r = it >> TXLOG;
+    const int p = r & (d - 1);
+    const int e0 = ((r >> logd) << (logd + NS)) + p;
+    double2 x[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int j = e0 + (q << logd);
+      x[q] = (SRC == A2_GLOBAL) ? gbase[(int64_t)j * lstride + c] : buf[a2_phys<TXLOG>(j, c)];
+    }
+    if (FWD) a2_dif<NS>(x, p, logd, s0, tw);
+    else a2_dit<NS>(x, p, s0, logL, tw);
+    if (DST == A2_PHASE) {
+      // last forward pass: logd = 0, the item holds line elements R r .. R r + R - 1 (frequency = their bit reversal);
+      // Fh_tiled is stored in exactly the order the items read it: fh[q * nitems + it]
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const double f = fh[(int64_t)q * nitems + it];
+        const double mag2 = x[q].x * x[q].x + x[q].y * x[q].y;
+        double2 pz;
+        if (mag2 > 0.0) {
+          const double inv = f / sqrt(mag2);
+          pz = make_double2(x[q].x * inv, x[q].y * inv);
+        } else {
+          pz = make_double2(f, 0.0);  // angle(0) = 0
+        }
+        if (dc_tile && it == 0 && q == 0) pz = make_double2(mean, 0.0);  // DC <- mean
+        x[q] = pz;
+      }
+      a2_dit<NS>(x, 0, 0, logL, tw);  // first inverse pass: same elements, spacing 1 (p = 0)
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int j = e0 + (q << logd);
+      if (DST == A2_GLOBAL) gbase[(int64_t)j * lstride + c] = x[q];
+      else buf[a2_phys<TXLOG>(j, c)] = x[q];
+    }
+  }
+}
+
+template <bool FWD, int SRC, int DST, int TXLOG, int NT>
+__device__ __forceinline__ void a2_pass_ns(int ns, double2* gbase, int64_t lstride, double2* buf, const double2* tw,
+                                           int logL, int s0, int tid, const double* fh, bool dc_tile, double mean) {
+  if (ns == 3) a2_pass<3, FWD, SRC, DST, TXLOG, NT>(gbase, lstride, buf, tw, logL, s0, tid, fh, dc_tile, mean);
+  else if (ns == 2) a2_pass<2, FWD, SRC, DST, TXLOG, NT>(gbase, lstride, buf, tw, logL, s0, tid, fh, dc_tile, mean);
+  else a2_pass<1, FWD, SRC, DST, TXLOG, NT>(gbase, lstride, buf, tw, logL, s0, tid, fh, dc_tile, mean);
+}
+
+// MODE 0: forward DIF in place.  MODE 1: inverse DIT in place.  MODE 2: forward, phase with Fh, inverse.
+// Needs log2 L >= 4 (at least two passes per transform).  LDS: tw[L/2] | buf[L * TX + FF2_PAD]
+template <int MODE, int TXLOG, int NT>
+__global__ __launch_bounds__(NT) void ff_axis2_kernel(FusedGrid g, int logL, const double2* __restrict__ twL,
+                                                      int64_t ostride, int64_t lstride, double2* __restrict__ X,
+                                                      const double* __restrict__ Fh_tiled, double mean) {
+  extern __shared__ __attribute__((aligned(16))) double2 sm[];
+  constexpr int TX = 1 << TXLOG;
+  const int L = 1 << logL;
+  double2* tw = sm;
+  double2* buf = sm + (L >> 1);
+  const int tid = threadIdx.x;
+  const int ntx = g.nhp >> TXLOG;
+  int tile = blockIdx.x;
+  if (TXLOG < 3) {  // tiles that share a 128-B line go to blocks b, b + 8, ... (same XCD, dispatched together)
+    constexpr int GL = 3 - (TXLOG < 3 ? TXLOG : 3);
+    const int bb = blockIdx.x;
+    tile = (bb & ~((8 << GL) - 1)) + ((bb & 7) << GL) + ((bb >> 3) & ((1 << GL) - 1));
+  }
+  const int t = tile % ntx;
+  const int o = tile / ntx;
+  double2* gbase = X + (int64_t)o * ostride + (int64_t)t * TX;
+  const int rem = logL % 3;
+  const int last_ns = rem ? rem : 3;   // radix of the last forward pass = radix of the first inverse pass
+  const int nitems_last = (TX << logL) >> last_ns;
+  const double* fh = (MODE == 2) ? Fh_tiled + (int64_t)tile * ((int64_t)L * TX) : nullptr;
+  (void)nitems_last;
+  for (int k = tid; k < (L >> 1); k += NT) tw[k] = twL[k];
+  __syncthreads();
+  if (MODE == 0 || MODE == 2) {
+    // first pass: radix-8 from global
+    a2_pass<3, true, A2_GLOBAL, A2_LDS, TXLOG, NT>(gbase, lstride, buf, tw, logL, 0, tid, nullptr, false, 0.0);
+    __syncthreads();
+    int s = 3;
+    for (; s + 3 <= logL - last_ns; s += 3) {
+      a2_pass<3, true, A2_LDS, A2_LDS, TXLOG, NT>(gbase, lstride, buf, tw, logL, s, tid, nullptr, false, 0.0);
+      __syncthreads();
+    }
+    // last forward pass (s == logL - last_ns)
+    if (MODE == 0) {
+      a2_pass_ns<true, A2_LDS, A2_GLOBAL, TXLOG, NT>(last_ns, gbase, lstride, buf, tw, logL, s, tid, nullptr, false, 0.0);
+    } else {
+      // the pass reads and writes the same LDS elements of its own items only: no barrier in between
+      a2_pass_ns<true, A2_LDS, A2_PHASE, TXLOG, NT>(last_ns, gbase, lstride, buf, tw, logL, s, tid, fh,
+                                                     o == 0 && t == 0, mean);
+      __syncthreads();
+    }
+  }
+  if (MODE == 1) {
+    a2_pass_ns<false, A2_GLOBAL, A2_LDS, TXLOG, NT>(last_ns, gbase, lstride, buf, tw, logL, 0, tid, nullptr, false, 0.0);
+    __syncthreads();
+  }
+  if (MODE == 1 || MODE == 2) {
+    int s = last_ns;
+    for (; s + 3 < logL; s += 3) {
+      a2_pass<3, false, A2_LDS, A2_LDS, TXLOG, NT>(gbase, lstride, buf, tw, logL, s, tid, nullptr, false, 0.0);
+      __syncthreads();
+    }
+    // last inverse pass: radix-8 (s + 3 == logL) to global
+    a2_pass<3, false, A2_LDS, A2_GLOBAL, TXLOG, NT>(gbase, lstride, buf, tw, logL, s, tid, nullptr, false, 0.0);
+  }
+}
+
+// Fh -> the order in which the items of ff_axis2_kernel<2> read it.  Tile (y', t) of TX columns; the last forward
+// pass has radix R = 2^last_ns and nitems = L TX / R items it = r TX + c holding line elements z' = R r + q:
+//   dst[tile * L * TX + q * nitems + it] = Fh[brev(z')][brev(y')][t * TX + c]   (0 beyond nh)
+template <int TXLOG>
+__global__ __launch_bounds__(256) void ff_tile_fh2_kernel(FusedGrid g, const double* __restrict__ Fh,
+                                                          double* __restrict__ dst) {
+  constexpr int TX = 1 << TXLOG;
+  const int ntx = g.nhp >> TXLOG;
+  const int L = g.n3;
+  const int rem = g.l3 % 3;
+  const int last_ns = rem ? rem : 3;
+  const int nitems = (TX << g.l3) >> last_ns;
+  const int64_t per_tile = (int64_t)L * TX;
+  const int64_t total = (int64_t)g.n2 * ntx * per_tile;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t tile = e / per_tile;
+    const int w = (int)(e - tile * per_tile);
+    const int q = w / nitems, it = w - q * nitems;
+    const int c = it & (TX - 1), r = it >> TXLOG;
+    const int zp = (r << last_ns) + q;
+    const int t = (int)(tile % ntx), yp = (int)(tile / ntx);
+    const int kx = t * TX + c;
+    const int kz = brev_bits(zp, g.l3), ky = brev_bits(yp, g.l2);
+    dst[e] = kx < g.nh ? Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx] : 0.0;
+  }
+}
+
 // Fh (natural half spectrum [kz][ky][kx], nh fastest) -> tiled, bit-reversed order used by P3:
 // dst[((y' * ntx + t) * n3 + z') * TX + c] = Fh[brev(z')][brev(y')][t * TX + c]   (0 beyond nh)
 __global__ __launch_bounds__(256) void ff_tile_fh_kernel(FusedGrid g, const double* __restrict__ Fh,
