@@ -170,6 +170,9 @@ struct gss_fftgs {
   bool fused = false;
   FusedGrid fg;
   DevBuf X, tw1, tw2, tw3, Fh_tiled, covsrc;
+  DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
+  int x_gen = 2;                // x passes: 2 = Stockham kernels (ff_x_fwd2 / ff_x_inv2), 1 = first generation
+  int x_rows = 8;               // x lines per workgroup of generation 2 (rows * M / 8 <= 256)
   int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
   double* Fh() const { return state.as<double>(); }
@@ -240,6 +243,40 @@ static int32_t upload_twiddles(DevBuf& buf, int L, hipStream_t s) {
 }
 
 static size_t ff_axis_lds(int L) { return sizeof(double2) * (size_t)(L / 2 + FF_TX * lds_line_pitch(L)); }
+static size_t ff_xfwd2_lds(int M, int logM, int rows) { return sizeof(double2) * (size_t)(M + x_table_len(logM) + rows * M); }
+static size_t ff_xinv2_lds(int M, int logM, int rows) { return sizeof(double2) * (size_t)(x_table_len(logM) + rows * M); }
+
+// per-pass twiddle tables of the Stockham x passes (forward sign; the inverse conjugates): middle passes
+// T[(r-1) Ns + k] = exp(-2 pi i r k / (8 Ns)), then the last pass exp(-2 pi i r k / M)
+static int32_t upload_x_tables(DevBuf& buf, int logM, hipStream_t s) {
+  const int M = 1 << logM;
+  const XPlan plan = x_plan(logM);
+  std::vector<double> t((size_t)(2 * x_table_len(logM)));
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  size_t o = 0;
+  int Ns = 8;
+  for (int m = 0; m < plan.nmid; ++m) {
+    for (int r = 1; r < 8; ++r)
+      for (int k = 0; k < Ns; ++k) {
+        const long double a = two_pi * (long double)(r * k) / (long double)(8 * Ns);
+        t[o++] = (double)cosl(a);
+        t[o++] = (double)(-sinl(a));
+      }
+    Ns <<= 3;
+  }
+  const int R = 1 << plan.ns_last;
+  for (int r = 1; r < R; ++r)
+    for (int k = 0; k < M / R; ++k) {
+      const long double a = two_pi * (long double)(r * k) / (long double)M;
+      t[o++] = (double)cosl(a);
+      t[o++] = (double)(-sinl(a));
+    }
+  GSS_TRY(buf.alloc(sizeof(double) * t.size()));
+  GSS_HIP(hipMemcpyAsync(buf.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
 static size_t ff_axis2_lds(int L, int txlog) { return sizeof(double2) * (size_t)(L / 2 + (L << txlog) + FF2_PAD); }
 static int env_int(const char* name, int dflt) {
   const char* e = std::getenv(name);
@@ -307,6 +344,24 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_xinv_lds(M)));
+  // generation 2 of the x passes (Stockham): as many lines per workgroup as give every thread one radix-8 item
+  h->x_gen = env_int("GSS_FFTGS_X", 2) == 1 ? 1 : 2;
+  h->x_rows = M <= 256 ? 8 : 4;
+  GSS_TRY(upload_x_tables(h->xtw, f.l1 - 1, s));
+#define GSS_X2_ATTR(ROWS)                                                                                             \
+  do {                                                                                                                \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_PHILOX, ROWS, 256>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_ARRAY, ROWS, 256>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_COV, ROWS, 256>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv2_kernel<ROWS, 256>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xinv2_lds(M, f.l1 - 1, ROWS)));  \
+  } while (0)
+  if (h->x_rows == 8) GSS_X2_ATTR(8);
+  else GSS_X2_ATTR(4);
+#undef GSS_X2_ATTR
   // the half-spectrum buffer of the fused path has the padded row pitch; padding columns stay zero
   GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)f.nhp * f.n2 * f.n3));
   GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));
@@ -334,22 +389,54 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
 }
 
 // launches of the forward passes shared by the realisations and the spectrum build
-static void launch_p1(gss_fftgs* h, int src, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
+template <int SRC>
+static void launch_p1_src(gss_fftgs* h, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
   const FusedGrid& f = h->fg;
   const int M = f.n1 / 2;
   const int64_t nrows = (int64_t)f.n2 * f.n3;
-  const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
   double2* X = h->X.as<double2>();
   const CovSrc* cs = h->covsrc.as<CovSrc>();
-  if (src == FF_SRC_COV)
-    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_COV>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
-                       h->tw1.as<double2>(), seed, real, noise, X, cs);
-  else if (src == FF_SRC_ARRAY)
-    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_ARRAY>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
-                       h->tw1.as<double2>(), seed, real, noise, X, cs);
+  if (h->x_gen == 1) {
+    const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
+    hipLaunchKernelGGL(ff_x_fwd_kernel<SRC>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f, h->tw1.as<double2>(), seed,
+                       real, noise, X, cs);
+    return;
+  }
+  const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
+  const size_t lds = ff_xfwd2_lds(M, f.l1 - 1, h->x_rows);
+  if (h->x_rows == 8)
+    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 8, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), seed, real, noise, X, cs);
   else
-    hipLaunchKernelGGL(ff_x_fwd_kernel<FF_SRC_PHILOX>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f,
-                       h->tw1.as<double2>(), seed, real, noise, X, cs);
+    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 4, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), seed, real, noise, X, cs);
+}
+
+// launches of the forward passes shared by the realisations and the spectrum build
+static void launch_p1(gss_fftgs* h, int src, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
+  if (src == FF_SRC_COV) launch_p1_src<FF_SRC_COV>(h, seed, real, noise, s);
+  else if (src == FF_SRC_ARRAY) launch_p1_src<FF_SRC_ARRAY>(h, seed, real, noise, s);
+  else launch_p1_src<FF_SRC_PHILOX>(h, seed, real, noise, s);
+}
+
+static void launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
+  const FusedGrid& f = h->fg;
+  const int M = f.n1 / 2;
+  const int64_t nrows = (int64_t)f.n2 * f.n3;
+  const double2* X = h->X.as<double2>();
+  if (h->x_gen == 1) {
+    const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
+    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
+    return;
+  }
+  const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
+  const size_t lds = ff_xinv2_lds(M, f.l1 - 1, h->x_rows);
+  if (h->x_rows == 8)
+    hipLaunchKernelGGL((ff_x_inv2_kernel<8, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), X, z);
+  else
+    hipLaunchKernelGGL((ff_x_inv2_kernel<4, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), X, z);
 }
 
 static void launch_p2(gss_fftgs* h, hipStream_t s) { (void)launch_axis_mode<0>(h, 1, s); }
@@ -397,11 +484,6 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
 // one realisation through the fused pipeline; `noise` (N uniforms) may be NULL; z receives N doubles
 static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z,
                                hipStream_t s) {
-  const FusedGrid& f = h->fg;
-  const int M = f.n1 / 2;
-  const int64_t nrows = (int64_t)f.n2 * f.n3;
-  const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
-  double2* X = h->X.as<double2>();
   {
     ProfScope ps("fftgs_p1", s);
     launch_p1(h, noise ? FF_SRC_ARRAY : FF_SRC_PHILOX, seed, (uint32_t)real, noise, s);
@@ -420,7 +502,7 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
   }
   {
     ProfScope ps("fftgs_p5", s);
-    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
+    launch_p5(h, z, s);
   }
   GSS_HIP(hipGetLastError());
   return GSS_OK;

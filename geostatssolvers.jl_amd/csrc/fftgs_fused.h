@@ -264,6 +264,339 @@ __global__ __launch_bounds__(FF_XTHREADS) void ff_x_inv_kernel(FusedGrid g, cons
   }
 }
 
+// =====================================================================================================
+// x passes, second generation (ff_x_fwd2_kernel / ff_x_inv2_kernel): Stockham autosort passes.
+// Every pass reads its R inputs at stride M / R and writes its outputs at stride Ns (the product of the radices
+// done so far), so natural order goes in and natural order comes out: no bit reversal, the first pass takes its
+// inputs straight from their source into registers (Philox pairs / the supplied noise / covariance rows for P1,
+// the half spectrum with the real-inverse pre-processing applied on the fly for P5) and the last pass of P5
+// stores the realisation straight from registers.  LDS round trips per 256-point line: P1 3 (5 before),
+// P5 2 (5 before).  Radices: 8, 8, ..., then 2^(log2 M mod 3); first-pass twiddles are all one; the other passes
+// read theirs from per-pass tables T_p[(r - 1) Ns + k] = exp(-2 pi i r k / (Ns R)) (contiguous in k, so the LDS
+// reads of a pass are unit stride) built once per handle.  In-register DFTs of 2, 4 and 8 points use the
+// constant twiddles +-i and (+-1 +- i) / sqrt 2.
+// LDS image of a line: element i at i ^ ((i >> 3) & 7): the stride-8 stores of the first pass and the
+// unit-stride accesses of the others both spread over the banks.
+__device__ __forceinline__ int xs_phys(int i) { return i ^ ((i >> 3) & 7); }
+
+template <bool INV>
+__device__ __forceinline__ double2 mul_mi(double2 a) {   // forward: a * (-i); inverse: a * (+i)
+  return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+template <bool INV>
+__device__ __forceinline__ void x_dft4(double2& a0, double2& a1, double2& a2, double2& a3) {
+  const double2 s0 = make_double2(a0.x + a2.x, a0.y + a2.y), s1 = make_double2(a0.x - a2.x, a0.y - a2.y);
+  const double2 s2 = make_double2(a1.x + a3.x, a1.y + a3.y);
+  const double2 s3 = mul_mi<INV>(make_double2(a1.x - a3.x, a1.y - a3.y));
+  a0 = make_double2(s0.x + s2.x, s0.y + s2.y);
+  a2 = make_double2(s0.x - s2.x, s0.y - s2.y);
+  a1 = make_double2(s1.x + s3.x, s1.y + s3.y);
+  a3 = make_double2(s1.x - s3.x, s1.y - s3.y);
+}
+
+// v <- DFT_R(v), R = 2^NS, outputs in natural order
+template <int NS, bool INV>
+__device__ __forceinline__ void x_dft(double2 (&v)[1 << NS]) {
+  if (NS == 1) {
+    const double2 a = v[0], b = v[1];
+    v[0] = make_double2(a.x + b.x, a.y + b.y);
+    v[1] = make_double2(a.x - b.x, a.y - b.y);
+  } else if (NS == 2) {
+    x_dft4<INV>(v[0], v[1], v[2], v[3]);
+  } else {
+    const double h = 0.70710678118654752440;
+    double2 t0 = make_double2(v[0].x + v[4].x, v[0].y + v[4].y), u0 = make_double2(v[0].x - v[4].x, v[0].y - v[4].y);
+    double2 t1 = make_double2(v[1].x + v[5].x, v[1].y + v[5].y), u1 = make_double2(v[1].x - v[5].x, v[1].y - v[5].y);
+    double2 t2 = make_double2(v[2].x + v[6].x, v[2].y + v[6].y), u2 = make_double2(v[2].x - v[6].x, v[2].y - v[6].y);
+    double2 t3 = make_double2(v[3].x + v[7].x, v[3].y + v[7].y), u3 = make_double2(v[3].x - v[7].x, v[3].y - v[7].y);
+    // u_q *= W8^q (forward: exp(-i pi q / 4); inverse: conjugate)
+    if (INV) {
+      u1 = make_double2((u1.x - u1.y) * h, (u1.x + u1.y) * h);
+      u3 = make_double2((-u3.x - u3.y) * h, (u3.x - u3.y) * h);
+    } else {
+      u1 = make_double2((u1.x + u1.y) * h, (u1.y - u1.x) * h);
+      u3 = make_double2((u3.y - u3.x) * h, (-u3.x - u3.y) * h);
+    }
+    u2 = mul_mi<INV>(u2);
+    x_dft4<INV>(t0, t1, t2, t3);   // -> V0, V2, V4, V6
+    x_dft4<INV>(u0, u1, u2, u3);   // -> V1, V3, V5, V7
+    v[0] = t0; v[2] = t1; v[4] = t2; v[6] = t3;
+    v[1] = u0; v[3] = u1; v[5] = u2; v[7] = u3;
+  }
+}
+
+// twiddle multiply of inputs 1 .. R-1 by T[(r-1) Ns + k] (conjugated for the inverse)
+template <int NS, bool INV>
+__device__ __forceinline__ void x_twiddle(double2 (&v)[1 << NS], const double2* T, int Ns, int k) {
+#pragma unroll
+  for (int r = 1; r < (1 << NS); ++r) {
+    double2 w = T[(r - 1) * Ns + k];
+    if (INV) w.y = -w.y;
+    v[r] = cmul(v[r], w);
+  }
+}
+
+// middle pass (LDS -> LDS, in place) of `rows` lines of length M: radix 8.  One item per thread (the host picks
+// the rows per workgroup so that rows * M / 8 <= NT): every read of the tile is done before the first write.
+template <bool INV, int NT>
+__device__ __forceinline__ void x_middle_pass(double2* buf, int M, int rows, const double2* T, int Ns, int logNs,
+                                              int tid) {
+  const int ipr = M >> 3;                 // items per row
+  const bool on = tid < rows * ipr;
+  double2 v[8];
+  int row = 0, j = 0;
+  if (on) {
+    row = tid / ipr;
+    j = tid - row * ipr;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[row * M + xs_phys(j + r * ipr)];
+  }
+  __syncthreads();
+  if (on) {
+    const int k = j & (Ns - 1);
+    x_twiddle<3, INV>(v, T, Ns, k);
+    x_dft<3, INV>(v);
+    const int j0 = ((j >> logNs) << (logNs + 3)) + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[row * M + xs_phys(j0 + (r << logNs))] = v[r];
+  }
+  __syncthreads();
+}
+
+// last pass of P1 (LDS -> LDS, in place): radix R = 2^NS, at most 8 / R items per thread, outputs in natural order
+template <int NS, int NT>
+__device__ __forceinline__ void x_last_pass_lds(double2* buf, int M, int rows, const double2* T, int tid) {
+  constexpr int R = 1 << NS;
+  constexpr int IPT = 8 / R;
+  const int ipr = M >> NS;
+  const int nitems = rows * ipr;
+  double2 v[IPT][R];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int it = tid + i * NT;
+    if (it < nitems) {
+      const int row = it / ipr, j = it - row * ipr;
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[i][r] = buf[row * M + xs_phys(j + r * ipr)];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int it = tid + i * NT;
+    if (it < nitems) {
+      const int row = it / ipr, j = it - row * ipr;
+      x_twiddle<NS, false>(v[i], T, ipr, j);
+      x_dft<NS, false>(v[i]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[row * M + xs_phys(j + r * ipr)] = v[i][r];
+    }
+  }
+  __syncthreads();
+}
+
+struct XPlan {       // radix plan of a length-M line: passes = 1 (radix 8) + nmid (radix 8) + 1 (radix 2^ns_last)
+  int nmid;
+  int ns_last;
+  int off_last;      // offset of the last pass's table in the per-pass twiddle table (middle passes precede it)
+};
+__host__ __device__ inline XPlan x_plan(int logM) {
+  XPlan p;
+  const int rem = logM % 3;
+  p.ns_last = rem ? rem : 3;
+  p.nmid = (logM - 3 - p.ns_last) / 3;
+  int off = 0, Ns = 8;
+  for (int m = 0; m < p.nmid; ++m) {
+    off += 7 * Ns;
+    Ns <<= 3;
+  }
+  p.off_last = off;
+  return p;
+}
+__host__ __device__ inline int x_table_len(int logM) {
+  const XPlan p = x_plan(logM);
+  return p.off_last + ((1 << p.ns_last) - 1) * ((1 << logM) >> p.ns_last);
+}
+
+// ---- P1, second generation.  LDS: tw[M] | T[tlen] | buf[ROWS * M]; needs ROWS * M / 8 <= NT --------------------
+template <int SRC, int ROWS, int NT>
+__global__ __launch_bounds__(NT) void ff_x_fwd2_kernel(FusedGrid g, const double2* __restrict__ tw1,
+                                                       const double2* __restrict__ xtw, uint64_t seed, uint32_t real,
+                                                       const double* __restrict__ noise, double2* __restrict__ X,
+                                                       const CovSrc* __restrict__ cs) {
+  extern __shared__ __attribute__((aligned(16))) double2 sm[];
+  const int M = g.n1 >> 1, logM = g.l1 - 1;
+  const XPlan plan = x_plan(logM);
+  const int tlen = x_table_len(logM);
+  double2* tw = sm;
+  double2* T = sm + M;
+  double2* buf = T + tlen;
+  const int tid = threadIdx.x;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  for (int k = tid; k < M; k += NT) tw[k] = tw1[k];
+  for (int k = tid; k < tlen; k += NT) T[k] = xtw[k];
+  // pass 1: radix 8 straight from the source, no twiddles (Ns = 1), outputs at 8 j + r
+  {
+    const int ipr = M >> 3;
+    for (int it = tid; it < ROWS * ipr; it += NT) {
+      const int row = it / ipr, j = it - row * ipr;
+      const int64_t grow = row0 + row;
+      double2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = j + r * ipr;
+        double2 x = make_double2(0.0, 0.0);
+        if (grow < nrows) {
+          const int64_t blk = grow * M + n;  // elements 2 blk, 2 blk + 1 of the realisation
+          if (SRC == FF_SRC_ARRAY) {
+            x = reinterpret_cast<const double2*>(noise)[blk];
+          } else if (SRC == FF_SRC_COV) {
+            const int i2 = (int)(grow % g.n2), i3 = (int)(grow / g.n2);
+            const double zero[3] = {0.0, 0.0, 0.0};
+            double a[3] = {(double)(2 * n - cs->c1) * cs->s1, (double)(i2 - cs->c2) * cs->s2, (double)(i3 - cs->c3) * cs->s3};
+            x.x = cov_pair<3>(cs->vg, a, zero);
+            a[0] = (double)(2 * n + 1 - cs->c1) * cs->s1;
+            x.y = cov_pair<3>(cs->vg, a, zero);
+          } else {
+            philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)blk, x.x, x.y);
+          }
+        }
+        v[r] = x;
+      }
+      x_dft<3, false>(v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[row * M + xs_phys(8 * j + r)] = v[r];
+    }
+  }
+  __syncthreads();
+  int Ns = 8, logNs = 3;
+  const double2* Tp = T;
+  for (int m = 0; m < plan.nmid; ++m) {
+    x_middle_pass<false, NT>(buf, M, ROWS, Tp, Ns, logNs, tid);
+    Tp += 7 * Ns;
+    Ns <<= 3;
+    logNs += 3;
+  }
+  // last pass: radix 2^ns_last, Ns = M / R, outputs Z[k] at k = j + r Ns: natural order, in place
+  if (plan.ns_last == 3) x_last_pass_lds<3, NT>(buf, M, ROWS, Tp, tid);
+  else if (plan.ns_last == 2) x_last_pass_lds<2, NT>(buf, M, ROWS, Tp, tid);
+  else x_last_pass_lds<1, NT>(buf, M, ROWS, Tp, tid);
+  const double2* Z = buf;
+  // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2, k = 0 .. M
+  for (int e = tid; e < ROWS * (M + 1); e += NT) {
+    const int row = e / (M + 1), k = e - row * (M + 1);
+    const int64_t grow = row0 + row;
+    if (grow >= nrows) continue;
+    const double2* z = Z + row * M;
+    const double2 a = z[xs_phys(k & (M - 1))];
+    const double2 b = cconj(z[xs_phys((M - k) & (M - 1))]);
+    const double2 w = (k < M) ? tw[k] : make_double2(-1.0, 0.0);
+    const double2 d = cmul(make_double2(a.x - b.x, a.y - b.y), w);  // w^k (a - b); -i * d = (d.y, -d.x)
+    X[grow * g.nhp + k] = make_double2(0.5 * (a.x + b.x + d.y), 0.5 * (a.y + b.y - d.x));
+  }
+}
+
+// ---- P5, second generation.  LDS: T[tlen] | buf[ROWS * M]; needs ROWS * M / 8 <= NT -----------------------------
+template <int ROWS, int NT>
+__global__ __launch_bounds__(NT) void ff_x_inv2_kernel(FusedGrid g, const double2* __restrict__ tw1,
+                                                       const double2* __restrict__ xtw, const double2* __restrict__ X,
+                                                       double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double2 sm[];
+  const int M = g.n1 >> 1, logM = g.l1 - 1;
+  const XPlan plan = x_plan(logM);
+  const int tlen = x_table_len(logM);
+  double2* T = sm;
+  double2* buf = sm + tlen;
+  const int tid = threadIdx.x;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  for (int k = tid; k < tlen; k += NT) T[k] = xtw[k];
+  // pass 1: Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})) formed in registers from the half
+  // spectrum (k and its mirror: two unit-stride runs per load instruction), radix 8 without twiddles
+  {
+    const int ipr = M >> 3;
+    for (int it = tid; it < ROWS * ipr; it += NT) {
+      const int row = it / ipr, j = it - row * ipr;
+      const int64_t grow = row0 + row;
+      double2 v[8];
+      if (grow < nrows) {
+        const double2* xr = X + grow * g.nhp;
+        double2 a[8], b[8], w[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int k = j + r * ipr;
+          a[r] = xr[k];
+          b[r] = xr[M - k];
+          w[r] = tw1[k];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const double2 bb = cconj(b[r]);
+          const double2 d = cmul(make_double2(a[r].x - bb.x, a[r].y - bb.y), cconj(w[r]));  // i * d = (-d.y, d.x)
+          v[r] = make_double2(a[r].x + bb.x - d.y, a[r].y + bb.y + d.x);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_double2(0.0, 0.0);
+      }
+      x_dft<3, true>(v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[row * M + xs_phys(8 * j + r)] = v[r];
+    }
+  }
+  __syncthreads();
+  int Ns = 8, logNs = 3;
+  const double2* Tp = T;
+  for (int m = 0; m < plan.nmid; ++m) {
+    x_middle_pass<true, NT>(buf, M, ROWS, Tp, Ns, logNs, tid);
+    Tp += 7 * Ns;
+    Ns <<= 3;
+    logNs += 3;
+  }
+  // last pass: outputs z[n], n = j + r M / R, are (u[2n], u[2n+1]) of the realisation: stored from registers
+  {
+    const int ipr = M >> plan.ns_last;
+    double2* o2 = reinterpret_cast<double2*>(out);
+    for (int it = tid; it < ROWS * ipr; it += NT) {
+      const int row = it / ipr, j = it - row * ipr;
+      const int64_t grow = row0 + row;
+      if (plan.ns_last == 3) {
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = buf[row * M + xs_phys(j + r * ipr)];
+        x_twiddle<3, true>(v, Tp, ipr, j);
+        x_dft<3, true>(v);
+        if (grow < nrows) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) o2[grow * M + j + r * ipr] = v[r];
+        }
+      } else if (plan.ns_last == 2) {
+        double2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = buf[row * M + xs_phys(j + r * ipr)];
+        x_twiddle<2, true>(v, Tp, ipr, j);
+        x_dft<2, true>(v);
+        if (grow < nrows) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o2[grow * M + j + r * ipr] = v[r];
+        }
+      } else {
+        double2 v[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) v[r] = buf[row * M + xs_phys(j + r * ipr)];
+        x_twiddle<1, true>(v, Tp, ipr, j);
+        x_dft<1, true>(v);
+        if (grow < nrows) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) o2[grow * M + j + r * ipr] = v[r];
+        }
+      }
+    }
+  }
+}
+
 // ---- P2 / P4 / P3: strided lines, tiles of FF_TX consecutive kx -----------------------------------------
 // A tile is (outer index o, kx tile t): line element j of lane-column c sits at X[base(o) + j * lstride + t*TX + c].
 // MODE 0: forward DIF in place.  MODE 1: inverse DIT in place.  MODE 2: forward, phase with Fh, inverse.

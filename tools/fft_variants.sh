@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage: fft_variants.sh  (runs the FFTGS leg of bench.py under the A/B switches of the strided passes)
-for v in "GSS_FFTGS_AXIS=1" "GSS_FFTGS_AXIS=2" "GSS_FFTGS_TXY=2" "GSS_FFTGS_TXY=2 GSS_FFTGS_TXZ=2" "GSS_FFTGS_TXZ=2"; do
+# usage: tools/fft_variants.sh ["ENV=.. ENV=.." ...]  -- FFTGS leg of bench.py under A/B switches of the fused passes
+if [ $# -eq 0 ]; then set -- "GSS_FFTGS_X=1 GSS_FFTGS_AXIS=1" "GSS_FFTGS_X=1" "GSS_FFTGS_X=2"; fi
+for v in "$@"; do
   echo "== $v"
   env $v python bench.py --steps 1 --warmup 0 --no-cpu-baseline --lugs 0 --npoints 100000 2>/dev/null | python -c "
 import sys, json
