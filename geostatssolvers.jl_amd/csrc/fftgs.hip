@@ -170,6 +170,13 @@ struct gss_fftgs {
   bool fused = false;
   FusedGrid fg;
   DevBuf X, tw1, tw2, tw3, Fh_tiled, covsrc;
+  // realisation pipeline: P1 (instruction-issue bound) of realisation r+1 runs on a helper stream beside P2..P5
+  // (HBM bound) of realisation r; two half-spectrum buffers alternate
+  DevBuf X2;
+  double2* Xcur = nullptr;      // buffer the launch helpers work on
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p5[2] = {nullptr, nullptr}, ev_in = nullptr;
+  int overlap = 1;
   DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
   int x_gen = 2;                // x passes: 2 = Stockham kernels (ff_x_fwd2 / ff_x_inv2), 1 = first generation
   int x_rows = 8;               // x lines per workgroup of generation 2 (rows * M / 8 <= 256)
@@ -178,6 +185,15 @@ struct gss_fftgs {
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
   ~gss_fftgs() {
+    if (s2) {
+      (void)hipStreamSynchronize(s2);
+      (void)hipStreamDestroy(s2);
+    }
+    for (int b = 0; b < 2; ++b) {
+      if (ev_p1[b]) (void)hipEventDestroy(ev_p1[b]);
+      if (ev_p5[b]) (void)hipEventDestroy(ev_p5[b]);
+    }
+    if (ev_in) (void)hipEventDestroy(ev_in);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
     if (info) rocfft_execution_info_destroy(info);
@@ -291,7 +307,7 @@ static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s) {
   const double2* tw = axis == 1 ? h->tw2.as<double2>() : h->tw3.as<double2>();
   const int64_t ostride = axis == 1 ? (int64_t)f.n2 * f.nhp : (int64_t)f.nhp;
   const int64_t lstride = axis == 1 ? (int64_t)f.nhp : (int64_t)f.n2 * f.nhp;
-  double2* X = h->X.as<double2>();
+  double2* X = h->Xcur;
   const double* fh = MODE == 2 ? h->Fh_tiled.as<double>() : nullptr;
   const double mean = MODE == 2 ? h->mean : 0.0;
   if (h->axis_gen == 1) {
@@ -348,23 +364,29 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   h->x_gen = env_int("GSS_FFTGS_X", 2) == 1 ? 1 : 2;
   h->x_rows = M <= 256 ? 8 : 4;
   GSS_TRY(upload_x_tables(h->xtw, f.l1 - 1, s));
-#define GSS_X2_ATTR(ROWS)                                                                                             \
+#define GSS_X2_ATTR(ROWS, LOGM)                                                                                       \
   do {                                                                                                                \
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_PHILOX, ROWS, 256>),            \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_PHILOX, ROWS, 256, LOGM>),      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_ARRAY, ROWS, 256>),             \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_ARRAY, ROWS, 256, LOGM>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_COV, ROWS, 256>),               \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd2_kernel<FF_SRC_COV, ROWS, 256, LOGM>),         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd2_lds(M, f.l1 - 1, ROWS)));  \
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv2_kernel<ROWS, 256>),                          \
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv2_kernel<ROWS, 256, LOGM>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xinv2_lds(M, f.l1 - 1, ROWS)));  \
   } while (0)
-  if (h->x_rows == 8) GSS_X2_ATTR(8);
-  else GSS_X2_ATTR(4);
+  // 512-cell lines (M = 256) have their own instantiation with the length fixed at compile time
+  if (f.l1 == 9) GSS_X2_ATTR(8, 8);
+  else if (h->x_rows == 8) GSS_X2_ATTR(8, -1);
+  else GSS_X2_ATTR(4, -1);
 #undef GSS_X2_ATTR
   // the half-spectrum buffer of the fused path has the padded row pitch; padding columns stay zero
   GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)f.nhp * f.n2 * f.n3));
   GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));
+  h->Xcur = h->X.as<double2>();
+  // measured (profiles/r02_fftgs_overlap.txt): the two-stream pipeline changes nothing at 512^3 (2.378 against
+  // 2.367 ms per realisation) -- the passes fill the chip and the queues take turns; kept as an A/B switch, off
+  h->overlap = env_int("GSS_FFTGS_OVERLAP", 0) != 0;
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)ff_axis_lds(lmax)));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -394,7 +416,7 @@ static void launch_p1_src(gss_fftgs* h, uint64_t seed, uint32_t real, const doub
   const FusedGrid& f = h->fg;
   const int M = f.n1 / 2;
   const int64_t nrows = (int64_t)f.n2 * f.n3;
-  double2* X = h->X.as<double2>();
+  double2* X = h->Xcur;
   const CovSrc* cs = h->covsrc.as<CovSrc>();
   if (h->x_gen == 1) {
     const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
@@ -404,11 +426,14 @@ static void launch_p1_src(gss_fftgs* h, uint64_t seed, uint32_t real, const doub
   }
   const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
   const size_t lds = ff_xfwd2_lds(M, f.l1 - 1, h->x_rows);
-  if (h->x_rows == 8)
-    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 8, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+  if (f.l1 == 9)
+    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 8, 256, 8>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), seed, real, noise, X, cs);
+  else if (h->x_rows == 8)
+    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 8, 256, -1>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
                        h->xtw.as<double2>(), seed, real, noise, X, cs);
   else
-    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 4, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+    hipLaunchKernelGGL((ff_x_fwd2_kernel<SRC, 4, 256, -1>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
                        h->xtw.as<double2>(), seed, real, noise, X, cs);
 }
 
@@ -423,7 +448,7 @@ static void launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
   const FusedGrid& f = h->fg;
   const int M = f.n1 / 2;
   const int64_t nrows = (int64_t)f.n2 * f.n3;
-  const double2* X = h->X.as<double2>();
+  const double2* X = h->Xcur;
   if (h->x_gen == 1) {
     const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
     hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
@@ -431,11 +456,14 @@ static void launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
   }
   const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
   const size_t lds = ff_xinv2_lds(M, f.l1 - 1, h->x_rows);
-  if (h->x_rows == 8)
-    hipLaunchKernelGGL((ff_x_inv2_kernel<8, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+  if (f.l1 == 9)
+    hipLaunchKernelGGL((ff_x_inv2_kernel<8, 256, 8>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+                       h->xtw.as<double2>(), X, z);
+  else if (h->x_rows == 8)
+    hipLaunchKernelGGL((ff_x_inv2_kernel<8, 256, -1>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
                        h->xtw.as<double2>(), X, z);
   else
-    hipLaunchKernelGGL((ff_x_inv2_kernel<4, 256>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
+    hipLaunchKernelGGL((ff_x_inv2_kernel<4, 256, -1>), dim3(gx), dim3(256), lds, s, f, h->tw1.as<double2>(),
                        h->xtw.as<double2>(), X, z);
 }
 
@@ -455,7 +483,7 @@ static int32_t fftgs_spectrum_fused(gss_fftgs* h, double* partial, hipStream_t s
   launch_p1(h, FF_SRC_COV, 0, 0, nullptr, s);
   launch_p2(h, s);
   GSS_TRY(launch_axis_mode<0>(h, 2, s));
-  hipLaunchKernelGGL(ff_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, f, h->X.as<double2>(), h->Fh(), partial);
+  hipLaunchKernelGGL(ff_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, f, h->Xcur, h->Fh(), partial);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
@@ -482,12 +510,14 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
 }
 
 // one realisation through the fused pipeline; `noise` (N uniforms) may be NULL; z receives N doubles
-static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z,
-                               hipStream_t s) {
-  {
-    ProfScope ps("fftgs_p1", s);
-    launch_p1(h, noise ? FF_SRC_ARRAY : FF_SRC_PHILOX, seed, (uint32_t)real, noise, s);
-  }
+static int32_t fftgs_fused_p1(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, hipStream_t s) {
+  ProfScope ps("fftgs_p1", s);
+  launch_p1(h, noise ? FF_SRC_ARRAY : FF_SRC_PHILOX, seed, (uint32_t)real, noise, s);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
   {
     ProfScope ps("fftgs_p2", s);
     launch_p2(h, s);
@@ -505,6 +535,21 @@ static int32_t fftgs_fused_one(gss_fftgs* h, uint64_t seed, int64_t real, const 
     launch_p5(h, z, s);
   }
   GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+// helper stream, events and the second half-spectrum buffer of the realisation pipeline (first multi-realisation call)
+static int32_t fftgs_pipeline_setup(gss_fftgs* h, hipStream_t s) {
+  if (h->s2) return GSS_OK;
+  const FusedGrid& f = h->fg;
+  GSS_TRY(h->X2.alloc(sizeof(double2) * (size_t)f.nhp * f.n2 * f.n3));
+  GSS_TRY(dev_zero_bytes(h->X2.p, h->X2.bytes, s));   // padding columns stay zero, as in X
+  GSS_HIP(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    GSS_HIP(hipEventCreateWithFlags(&h->ev_p1[b], hipEventDisableTiming));
+    GSS_HIP(hipEventCreateWithFlags(&h->ev_p5[b], hipEventDisableTiming));
+  }
+  GSS_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
   return GSS_OK;
 }
 
@@ -625,10 +670,31 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
   GSS_TRY(so.out(out, sizeof(double) * (size_t)(nreals * npts), mem));
   if (inds && h->Z.bytes < sizeof(double) * (size_t)N) GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N));
 
+  // fused pipeline with more than one realisation: P1 of realisation r+1 on the helper stream beside P2..P5 of r
+  const bool piped = h->fused && h->overlap && nreals > 1;
+  if (piped) {
+    GSS_TRY(fftgs_pipeline_setup(h, s));
+    GSS_HIP(hipEventRecord(h->ev_in, s));               // everything queued so far (inputs, earlier calls) ...
+    GSS_HIP(hipStreamWaitEvent(h->s2, h->ev_in, 0));    // ... precedes the helper stream's first kernel
+  }
   for (int64_t r = 0; r < nreals; ++r) {
     if (h->fused) {
       double* zf = inds ? h->Z.as<double>() : so.as<double>() + r * N;
-      GSS_TRY(fftgs_fused_one(h, seed, first_real + r, noise ? sn.as<double>() + r * N : nullptr, zf, s));
+      const double* nz = noise ? sn.as<double>() + r * N : nullptr;
+      if (piped) {
+        const int b = (int)(r & 1);
+        h->Xcur = b ? h->X2.as<double2>() : h->X.as<double2>();
+        if (r >= 2) GSS_HIP(hipStreamWaitEvent(h->s2, h->ev_p5[b], 0));   // buffer b is free again
+        GSS_TRY(fftgs_fused_p1(h, seed, first_real + r, nz, h->s2));
+        GSS_HIP(hipEventRecord(h->ev_p1[b], h->s2));
+        GSS_HIP(hipStreamWaitEvent(s, h->ev_p1[b], 0));
+        GSS_TRY(fftgs_fused_rest(h, zf, s));
+        GSS_HIP(hipEventRecord(h->ev_p5[b], s));
+      } else {
+        h->Xcur = h->X.as<double2>();
+        GSS_TRY(fftgs_fused_p1(h, seed, first_real + r, nz, s));
+        GSS_TRY(fftgs_fused_rest(h, zf, s));
+      }
       if (inds) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
                            ninds, so.as<double>() + r * ninds);

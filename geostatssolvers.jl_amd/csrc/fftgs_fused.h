@@ -420,13 +420,15 @@ __host__ __device__ inline int x_table_len(int logM) {
 }
 
 // ---- P1, second generation.  LDS: tw[M] | T[tlen] | buf[ROWS * M]; needs ROWS * M / 8 <= NT --------------------
-template <int SRC, int ROWS, int NT>
+// LOGM >= 0: line length fixed at compile time (index arithmetic folds into immediates); -1: any length
+template <int SRC, int ROWS, int NT, int LOGM>
 __global__ __launch_bounds__(NT) void ff_x_fwd2_kernel(FusedGrid g, const double2* __restrict__ tw1,
                                                        const double2* __restrict__ xtw, uint64_t seed, uint32_t real,
                                                        const double* __restrict__ noise, double2* __restrict__ X,
                                                        const CovSrc* __restrict__ cs) {
   extern __shared__ __attribute__((aligned(16))) double2 sm[];
-  const int M = g.n1 >> 1, logM = g.l1 - 1;
+  const int logM = LOGM >= 0 ? LOGM : g.l1 - 1;
+  const int M = 1 << logM;
   const XPlan plan = x_plan(logM);
   const int tlen = x_table_len(logM);
   double2* tw = sm;
@@ -484,27 +486,42 @@ __global__ __launch_bounds__(NT) void ff_x_fwd2_kernel(FusedGrid g, const double
   else if (plan.ns_last == 2) x_last_pass_lds<2, NT>(buf, M, ROWS, Tp, tid);
   else x_last_pass_lds<1, NT>(buf, M, ROWS, Tp, tid);
   const double2* Z = buf;
-  // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2, k = 0 .. M
-  for (int e = tid; e < ROWS * (M + 1); e += NT) {
-    const int row = e / (M + 1), k = e - row * (M + 1);
+  // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2, k = 0 .. M.  Outputs k and M - k share
+  // s = Zk + conj(Z_{M-k}) and p = w^k (Zk - conj(Z_{M-k})) (w^{M-k} = -conj(w^k)):
+  //   X[k] = (s.x + p.y, s.y - p.x) / 2,   X[M-k] = (s.x - p.y, -s.y - p.x) / 2
+  // (k = 0 gives X[0] and X[M]; k = M / 2 gives X[M/2] twice)
+  const int half = M >> 1;
+  for (int t = tid; t < ROWS * half + ROWS; t += NT) {
+    int row, k;
+    if (t < ROWS * half) {
+      row = t >> (logM - 1);
+      k = t & (half - 1);
+    } else {
+      row = t - ROWS * half;
+      k = half;
+    }
     const int64_t grow = row0 + row;
     if (grow >= nrows) continue;
     const double2* z = Z + row * M;
-    const double2 a = z[xs_phys(k & (M - 1))];
+    const double2 a = z[xs_phys(k)];
     const double2 b = cconj(z[xs_phys((M - k) & (M - 1))]);
-    const double2 w = (k < M) ? tw[k] : make_double2(-1.0, 0.0);
-    const double2 d = cmul(make_double2(a.x - b.x, a.y - b.y), w);  // w^k (a - b); -i * d = (d.y, -d.x)
-    X[grow * g.nhp + k] = make_double2(0.5 * (a.x + b.x + d.y), 0.5 * (a.y + b.y - d.x));
+    const double2 w = tw[k];
+    const double2 sm2 = make_double2(a.x + b.x, a.y + b.y);
+    const double2 pp = cmul(make_double2(a.x - b.x, a.y - b.y), w);
+    double2* xr = X + grow * g.nhp;
+    xr[k] = make_double2(0.5 * (sm2.x + pp.y), 0.5 * (sm2.y - pp.x));
+    if (k != M - k) xr[M - k] = make_double2(0.5 * (sm2.x - pp.y), 0.5 * (-sm2.y - pp.x));
   }
 }
 
 // ---- P5, second generation.  LDS: T[tlen] | buf[ROWS * M]; needs ROWS * M / 8 <= NT -----------------------------
-template <int ROWS, int NT>
+template <int ROWS, int NT, int LOGM>
 __global__ __launch_bounds__(NT) void ff_x_inv2_kernel(FusedGrid g, const double2* __restrict__ tw1,
                                                        const double2* __restrict__ xtw, const double2* __restrict__ X,
                                                        double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double2 sm[];
-  const int M = g.n1 >> 1, logM = g.l1 - 1;
+  const int logM = LOGM >= 0 ? LOGM : g.l1 - 1;
+  const int M = 1 << logM;
   const XPlan plan = x_plan(logM);
   const int tlen = x_table_len(logM);
   double2* T = sm;

@@ -23,7 +23,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     const uint64_t p1 = (uint64_t)PHILOX_M1 * (uint64_t)c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    // three-input xor in one instruction (v_bitop3_b32, truth table 0x96)
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n1 = lo1;
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96), n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += PHILOX_W0;
     k1 += PHILOX_W1;
