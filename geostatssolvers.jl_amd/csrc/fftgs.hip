@@ -180,6 +180,7 @@ struct gss_fftgs {
   DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
   int x_gen = 2;                // x passes: 2 = Stockham kernels (ff_x_fwd2 / ff_x_inv2), 1 = first generation
   int x_rows = 8;               // x lines per workgroup of generation 2 (rows * M / 8 <= 256)
+  int axis_fast = 1;            // 512-point lines: the pass-by-pass kernel with all loads issued up front
   int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
   double* Fh() const { return state.as<double>(); }
@@ -317,12 +318,18 @@ static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s) {
     const int txlog = axis == 1 ? h->txy_log : h->txz_log;
     const unsigned blocks = (unsigned)(nouter * (f.nhp >> txlog));
     const size_t lds = ff_axis2_lds(L, txlog);
-    if (txlog == 3)
-      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride, X,
-                         fh, mean);
+    if (txlog == 3 && logL == 9 && h->axis_fast)
+      hipLaunchKernelGGL((ff_axis2_fast_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, tw, ostride, lstride,
+                         X, fh, mean);
+    else if (txlog == 3 && logL == 9)
+      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride,
+                         X, fh, mean);
+    else if (txlog == 3)
+      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512, -1>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride,
+                         X, fh, mean);
     else
-      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 2, 256>), dim3(blocks), dim3(256), lds, s, f, logL, tw, ostride, lstride, X,
-                         fh, mean);
+      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 2, 256, -1>), dim3(blocks), dim3(256), lds, s, f, logL, tw, ostride, lstride,
+                         X, fh, mean);
   }
   GSS_HIP(hipGetLastError());
   return GSS_OK;
@@ -396,15 +403,25 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   // generation 2 of the strided passes: 8-column tiles (4 when a 1024-point line would not leave room in LDS);
   // GSS_FFTGS_AXIS=1 / GSS_FFTGS_TXY / GSS_FFTGS_TXZ (log2 of the tile width) are A/B switches
   h->axis_gen = env_int("GSS_FFTGS_AXIS", 2) == 1 ? 1 : 2;
+  h->axis_fast = env_int("GSS_FFTGS_AXIS_FAST", 1) != 0;
   h->txy_log = env_int("GSS_FFTGS_TXY", f.n2 > 512 ? 2 : 3) == 2 ? 2 : 3;
   h->txz_log = env_int("GSS_FFTGS_TXZ", f.n3 > 512 ? 2 : 3) == 2 ? 2 : 3;
-#define GSS_A2_ATTR(MODE, TXL, NT)                                                                                  \
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_kernel<MODE, TXL, NT>),                        \
+#define GSS_A2_ATTR(MODE, TXL, NT, LOGL)                                                                            \
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_kernel<MODE, TXL, NT, LOGL>),                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(lmax, TXL)))
   if (h->txy_log == 3 || h->txz_log == 3) {
-    GSS_A2_ATTR(0, 3, 512); GSS_A2_ATTR(1, 3, 512); GSS_A2_ATTR(2, 3, 512);
+    GSS_A2_ATTR(0, 3, 512, -1); GSS_A2_ATTR(1, 3, 512, -1); GSS_A2_ATTR(2, 3, 512, -1);
+    if (lmax >= 512) {  // 512-point lines have their own instantiation (length fixed at compile time)
+      GSS_A2_ATTR(0, 3, 512, 9); GSS_A2_ATTR(1, 3, 512, 9); GSS_A2_ATTR(2, 3, 512, 9);
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_fast_kernel<0, 3, 512, 9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(512, 3)));
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_fast_kernel<1, 3, 512, 9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(512, 3)));
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_fast_kernel<2, 3, 512, 9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(512, 3)));
+    }
   }
-  GSS_A2_ATTR(0, 2, 256); GSS_A2_ATTR(1, 2, 256); GSS_A2_ATTR(2, 2, 256);
+  GSS_A2_ATTR(0, 2, 256, -1); GSS_A2_ATTR(1, 2, 256, -1); GSS_A2_ATTR(2, 2, 256, -1);
 #undef GSS_A2_ATTR
   h->fused = true;
   return GSS_OK;
