@@ -50,8 +50,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=30000, help="points of the CPU baseline sample")
     ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the leg)")
     ap.add_argument("--fftgs-reals", type=int, default=64, help="FFTGS realisations per GPU in the timed region")
-    ap.add_argument("--fftgs-batch", type=int, default=8, help="realisations per gss_fftgs_realize call (the library "
-                    "pipelines the realisations of one call: noise / x pass of r+1 beside the strided passes of r)")
+    ap.add_argument("--fftgs-batch", type=int, default=8, help="realisations per gss_fftgs_realize call")
     ap.add_argument("--lugs", type=int, default=128, help="LUGS grid edge, a quarter of the cells carry data "
                                                          "(configs[3]: 128; 0 disables the leg)")
     ap.add_argument("--lugs-reals", type=int, default=100, help="LUGS realisations in total (sharded over the ranks)")
@@ -330,7 +329,7 @@ def fftgs_leg(c):
                         "frac": round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_ms else 0.0,
                         "traffic": None, "algorithmic_bytes": alg,
                         "kernels": "the five passes of one realisation; avg_ms = HIP events on the launch stream around "
-                                   "the timed region / realisations (%d per call, pipelined inside the library)" % B,
+                                   "the timed region / realisations (%d per gss_fftgs_realize call)" % B,
                         "avg_ms": round(kern_ms, 4), "sequential_ms": round(seq_ms, 4)},
            "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in parts.items() if v[1]},
            "sample_variance": svar}
