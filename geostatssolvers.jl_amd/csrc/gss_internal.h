@@ -710,7 +710,13 @@ constexpr int64_t KNN_DEVICE_BUILD_MIN = 16384;
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s,
                            const int* rank = nullptr, const int* qrank = nullptr, const int* bminrank = nullptr,
-                           int metric = 0 /* Euclidean, Cityblock or Chebyshev */);
+                           int metric = 0 /* Euclidean, Cityblock or Chebyshev */, const double* lowd = nullptr,
+                           const int* lowi = nullptr /* per-query lower bound of the accepted keys */);
+// any k <= n: passes of 64 neighbours, each bounded below by the last key of the pass before (idx is m x k);
+// xdata = the samples in their original order (device)
+int32_t knn_search_indexed_any(const KnnIndex& ix, const double* xdata, const double* centers, int64_t m, int k,
+                               double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
+                               int metric = 0);
 // Haversine: exhaustive kernel (no box bounds for that key); non-Euclidean metrics do not combine with balls
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,

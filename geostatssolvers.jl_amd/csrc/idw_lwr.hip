@@ -535,6 +535,104 @@ __global__ __launch_bounds__(256) void lwr_all_fast_kernel(double wa, const doub
   status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64 < k < n: one thread per estimation point walks its neighbour list (m x k, ascending key, written by the
+// passes of the search).  Same sums, in the same (ascending-distance) order, as est_knn_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double* __restrict__ xdata,
+                                                       const double* __restrict__ z, const double* __restrict__ x0,
+                                                       int64_t m, int k, int minneighbors, const int* __restrict__ idx,
+                                                       const int* __restrict__ count, int aniso, double ir0, double ir1,
+                                                       double ir2, double* __restrict__ mean_out,
+                                                       double* __restrict__ aux_out, uint8_t* __restrict__ status_out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= m) return;
+  const double ir[3] = {ir0, ir1, ir2};
+  const double NaN = __builtin_nan("");
+  constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
+  double qc[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) qc[a] = x0[p * DIM + a];
+  const int cnt = count[p];
+  const int* nb = idx + p * k;
+  if (cnt < minneighbors || cnt < 1) {
+    mean_out[p] = NaN;
+    aux_out[p] = NaN;
+    status_out[p] = GSS_PT_MISSING;
+    return;
+  }
+  if (sp.method == 0) {
+    double sw = 0.0, swz = 0.0, dmin2 = __builtin_huge_val();
+    for (int j = 0; j < cnt; ++j) {
+      const int nj = nb[j];
+      double xj[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
+      const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
+      if (d2 == 0.0) {  // neighbours are sorted: the first zero distance is the first neighbour (idw.jl:131-134)
+        mean_out[p] = z[nj];
+        aux_out[p] = 0.0;
+        status_out[p] = GSS_PT_OK;
+        return;
+      }
+      dmin2 = d2 < dmin2 ? d2 : dmin2;
+      const double dd = metric_dist(sp.metric, d2, sp.mparam);
+      const double w = idw_weight(dd, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : dd * dd, sp.exponent);
+      sw += w;
+      swz += w * z[nj];
+    }
+    mean_out[p] = swz / sw;
+    aux_out[p] = metric_dist(sp.metric, dmin2, sp.mparam);
+    status_out[p] = GSS_PT_OK;
+    return;
+  }
+  // LWR: delta = d / d_max with d_max the distance of the last (farthest) neighbour (lwr.jl:132)
+  double dmax2 = 0.0;
+  {
+    const int nl = nb[cnt - 1];
+    double xl[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) xl[a] = xdata[(int64_t)nl * DIM + a];
+    dmax2 = est_key<DIM>(sp.metric, xl, qc, ir, aniso != 0);
+  }
+  const double dmax = metric_dist(sp.metric, dmax2, sp.mparam);
+  double S1[NT], S2[NT], b[NP];
+#pragma unroll
+  for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < NP; ++e) b[e] = 0.0;
+  for (int j = 0; j < cnt; ++j) {
+    const int nj = nb[j];
+    double xj[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
+    const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
+    const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
+    double u[NP];
+    u[0] = 1.0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) u[a + 1] = xj[a] - qc[a];
+    const double zj = z[nj];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      const double wu = w * u[r];
+      b[r] += wu * zj;
+#pragma unroll
+      for (int q = 0; q <= r; ++q) {
+        const double t = wu * u[q];
+        S1[r * (r + 1) / 2 + q] += t;
+        S2[r * (r + 1) / 2 + q] += w * t;
+      }
+    }
+  }
+  double mu, var;
+  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  mean_out[p] = ok ? mu : NaN;
+  aux_out[p] = ok ? var : NaN;
+  status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+}
+
 static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int dim,
                              const double* x0, int64_t m, int k, int minneighbors, double radius,
                              const double* inv_radii_host, double* mean, double* aux, uint8_t* status,
@@ -547,9 +645,40 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
     for (int a = 0; a < dim; ++a) ir[a] = inv_radii_host[a];
   const char* pname = sp.method == 0 ? "idw" : "lwr";
 
+  if (k > 64 && (int64_t)k < n) {
+    // 65 .. n - 1 neighbours (ui.jl:16-23 accepts any count): the search runs in passes of 64, the estimator walks
+    // the lists with one thread per point
+    GSS_REQUIRE(sp.metric != GSS_METRIC_HAVERSINE,
+                "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
+    const int64_t chunk = k > 512 ? (1 << 16) : (1 << 19);
+    KnnIndex ix;
+    GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
+    DevBuf idx_s, cnt_s;
+    GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
+    GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
+    for (int64_t off = 0; off < m; off += chunk) {
+      const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
+      {
+        ProfScope ps("knn", s);
+        GSS_TRY(knn_search_indexed_any(ix, xdata, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                                       cnt_s.as<int>(), s, sp.metric));
+      }
+      ProfScope pl(pname, s);
+      const dim3 grid((unsigned)((mv + 255) / 256));
+#define GSS_EST_LIST_ARGS sp, xdata, z, x0 + off * dim, mv, k, minneighbors, idx_s.as<int>(), cnt_s.as<int>(), aniso, \
+                          ir[0], ir[1], ir[2], mean + off, aux + off, status + off
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
+        case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
+        default: hipLaunchKernelGGL((est_list_kernel<3>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
+      }
+#undef GSS_EST_LIST_ARGS
+      GSS_HIP(hipGetLastError());
+    }
+    GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return
+    return GSS_OK;
+  }
   if (k > 64) {
-    GSS_REQUIRE((int64_t)k == n, "maxneighbors = %d: the neighbour kernels hold at most 64 neighbours; beyond that "
-                                 "only maxneighbors = nothing (all %lld samples) is available", k, (long long)n);
     ProfScope ps(pname, s);
     dim3 grid((unsigned)((m + 255) / 256));
     if (sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && (sp.exponent == 1.0 || sp.exponent == 2.0) &&

@@ -364,11 +364,17 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
                                                          double ir2, const int* __restrict__ rank,
                                                          const int* __restrict__ qrank,
                                                          const int* __restrict__ bminrank, int* __restrict__ idx_out,
-                                                         int* __restrict__ count_out) {
+                                                         int* __restrict__ count_out,
+                                                         const double* __restrict__ lowd,
+                                                         const int* __restrict__ lowi) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= m) return;  // whole wave
   const int myrank = MASKED ? qrank[p] : 0;
+  // more than 64 neighbours are found 64 at a time: a later pass only accepts keys above the last key of the pass
+  // before it (keys are >= 0, so (-1, -1) accepts everything)
+  const double my_lowd = lowd ? lowd[p] : -1.0;
+  const int my_lowi = lowd ? lowi[p] : -1;
   const double ir[3] = {ir0, ir1, ir2};
   double qc[DIM];
 #pragma unroll
@@ -428,7 +434,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
         for (int a = 0; a < DIM; ++a) c[a] = valid ? xs[(int64_t)j * DIM + a] : 0.0;
         const int oidx = valid ? perm[j] : INT_MAX;
         const double d2 = metric_key<DIM, METRIC>(c, qc, ir, aniso != 0);
-        bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i);
+        bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, oidx, tau_d, tau_i) &&
+                    key_less(my_lowd, my_lowi, d2, oidx);
         if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
         unsigned long long qm = __ballot(qual);
         if (k >= KNN_SORT_MIN_K && __popcll(qm) >= KNN_SORT_MIN) {
@@ -470,9 +477,9 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
 
 int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m, int k, double radius,
                            const double* inv_radii_host, int* idx, int* count, hipStream_t s, const int* rank,
-                           const int* qrank, const int* bminrank, int metric) {
-  GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
-                                 "(use the global neighbourhood beyond that)", k);
+                           const int* qrank, const int* bminrank, int metric, const double* lowd, const int* lowi) {
+  GSS_REQUIRE(k >= 1 && k <= 64, "knn_search_indexed: one pass finds at most 64 neighbours (got k = %d); "
+                                 "knn_search_indexed_any runs the passes for more", k);
   if (m <= 0) return GSS_OK;
   const int use_ball = (radius >= 0.0 || inv_radii_host != nullptr) ? 1 : 0;
   const int aniso = inv_radii_host != nullptr ? 1 : 0;
@@ -483,7 +490,7 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
   dim3 grid((unsigned)((m + 3) / 4));
 #define GSS_KNN_ARGS ix.xs.as<double>(), ix.perm.as<int>(), ix.lo.as<double>(), ix.hi.as<double>(), \
                      ix.lo1.as<double>(), ix.hi1.as<double>(), (int)ix.n, ix.nb, ix.nb1, \
-                     centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count
+                     centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count, lowd, lowi
   GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV,
               "the indexed search has box bounds for the Euclidean, Cityblock and Chebyshev keys only");
   if (rank) {
@@ -515,6 +522,94 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
   }
 #undef GSS_KNN_ARGS
   GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+// ---- more than 64 neighbours (ui.jl:16-23 accepts any maxneighbors <= n): passes of 64 -----------------------------
+__global__ __launch_bounds__(256) void knn_any_init_kernel(int64_t m, int* __restrict__ count, double* __restrict__ lowd,
+                                                           int* __restrict__ lowi) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < m) {
+    count[p] = 0;
+    lowd[p] = -1.0;
+    lowi[p] = -1;
+  }
+}
+
+// appends pass results (m x kk) to the full lists (m x k) at column `base`; the key of the last neighbour found
+// becomes the lower bound of the next pass (recomputed with the rounding of the search key itself); a pass that
+// came back short has exhausted the candidates: the bound goes to +inf
+template <int DIM>
+__global__ __launch_bounds__(256) void knn_any_append_kernel(const double* __restrict__ xdata,
+                                                             const double* __restrict__ centers, int64_t m, int k,
+                                                             int base, int kk, const int* __restrict__ tidx,
+                                                             const int* __restrict__ tcnt, int metric, int aniso,
+                                                             double ir0, double ir1, double ir2, int* __restrict__ idx,
+                                                             int* __restrict__ count, double* __restrict__ lowd,
+                                                             int* __restrict__ lowi) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= m) return;
+  const int c = tcnt[p];
+  for (int j = 0; j < kk; ++j) idx[p * k + base + j] = j < c ? tidx[p * kk + j] : -1;
+  count[p] += c;
+  if (c < kk) {
+    lowd[p] = __builtin_huge_val();
+    lowi[p] = INT_MAX;
+    return;
+  }
+  const int last = tidx[p * kk + c - 1];
+  const double ir[3] = {ir0, ir1, ir2};
+  double q[DIM], x[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) {
+    q[a] = centers[p * DIM + a];
+    x[a] = xdata[(int64_t)last * DIM + a];
+  }
+  double key;
+  if (metric == GSS_METRIC_CITYBLOCK) key = metric_key<DIM, GSS_METRIC_CITYBLOCK>(x, q, ir, false);
+  else if (metric == GSS_METRIC_CHEBYSHEV) key = metric_key<DIM, GSS_METRIC_CHEBYSHEV>(x, q, ir, false);
+  else key = metric_key<DIM, GSS_METRIC_EUCLIDEAN>(x, q, ir, aniso != 0);
+  lowd[p] = key;
+  lowi[p] = last;
+}
+
+int32_t knn_search_indexed_any(const KnnIndex& ix, const double* xdata, const double* centers, int64_t m, int k,
+                               double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
+                               int metric) {
+  if (k <= 64) return knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s, nullptr, nullptr,
+                                         nullptr, metric);
+  if (m <= 0) return GSS_OK;
+  DevBuf tidx, tcnt, lowd, lowi, cnt_own;
+  GSS_TRY(tidx.alloc(sizeof(int) * (size_t)(m * 64)));
+  GSS_TRY(tcnt.alloc(sizeof(int) * (size_t)m));
+  GSS_TRY(lowd.alloc(sizeof(double) * (size_t)m));
+  GSS_TRY(lowi.alloc(sizeof(int) * (size_t)m));
+  if (!count) {
+    GSS_TRY(cnt_own.alloc(sizeof(int) * (size_t)m));
+    count = cnt_own.as<int>();
+  }
+  const int aniso = inv_radii_host != nullptr ? 1 : 0;
+  double ir[3] = {1.0, 1.0, 1.0};
+  if (aniso)
+    for (int a = 0; a < ix.dim; ++a) ir[a] = inv_radii_host[a];
+  const dim3 grid((unsigned)((m + 255) / 256));
+  hipLaunchKernelGGL(knn_any_init_kernel, grid, dim3(256), 0, s, m, count, lowd.as<double>(), lowi.as<int>());
+  for (int base = 0; base < k; base += 64) {
+    const int kk = (k - base) < 64 ? (k - base) : 64;
+    GSS_TRY(knn_search_indexed(ix, centers, m, kk, radius, inv_radii_host, tidx.as<int>(), tcnt.as<int>(), s, nullptr,
+                               nullptr, nullptr, metric, lowd.as<double>(), lowi.as<int>()));
+#define GSS_APPEND(D)                                                                                                  \
+  hipLaunchKernelGGL(knn_any_append_kernel<D>, grid, dim3(256), 0, s, xdata, centers, m, k, base, kk, tidx.as<int>(),  \
+                     tcnt.as<int>(), metric, aniso, ir[0], ir[1], ir[2], idx, count, lowd.as<double>(), lowi.as<int>())
+    switch (ix.dim) {
+      case 1: GSS_APPEND(1); break;
+      case 2: GSS_APPEND(2); break;
+      default: GSS_APPEND(3); break;
+    }
+#undef GSS_APPEND
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_HIP(hipStreamSynchronize(s));  // the pass buffers are released on return
   return GSS_OK;
 }
 
@@ -560,18 +655,19 @@ static void launch_brute_metric(int metric, dim3 grid, hipStream_t s, const doub
 // Euclidean: pruned search (exhaustive kernel with GSS_KNN_BRUTE=1, kept for A/B checks); other metrics: exhaustive
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s, int metric) {
-  GSS_REQUIRE(k >= 1 && k <= 64, "maxneighbors = %d: the moving-neighbourhood kernels hold at most 64 neighbours "
-                                 "(use the global neighbourhood beyond that)", k);
+  GSS_REQUIRE(k >= 1, "maxneighbors = %d", k);
+  GSS_REQUIRE(k <= 64 || metric != GSS_METRIC_HAVERSINE,
+              "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
   GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3, "knn: bad sizes");
   if (m <= 0) return GSS_OK;
   const char* e = std::getenv("GSS_KNN_BRUTE");
   // few queries into a large set (e.g. the data -> grid-cell lookup of conditional simulation, fft.jl:129-132):
   // one brute-force sweep of the set costs less than ordering it on the host for the index
-  const bool few_queries = m <= 4096 && n >= 32768;
-  if (metric != GSS_METRIC_HAVERSINE && !(e && e[0] == '1') && !few_queries) {
+  const bool few_queries = m <= 4096 && n >= 32768 && k <= 64;
+  if (k > 64 || (metric != GSS_METRIC_HAVERSINE && !(e && e[0] == '1') && !few_queries)) {
     KnnIndex ix;
     GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
-    GSS_TRY(knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s, nullptr, nullptr, nullptr, metric));
+    GSS_TRY(knn_search_indexed_any(ix, xdata, centers, m, k, radius, inv_radii_host, idx, count, s, metric));
     GSS_HIP(hipStreamSynchronize(s));  // the index is released on return
     return GSS_OK;
   }

@@ -271,6 +271,212 @@ __global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, 
 
 
 // ---------------------------------------------------------------------------------------------
+// More than 64 neighbours (maxneighbors in 65 .. n - 1; krig.jl:201-210 and ui.jl:16-23 accept any count).
+// One workgroup of 256 threads per estimation point, same mathematics as krig_local_kernel above with the
+// right-hand sides [c0 | z | F] appended to the covariance block as extra ROWS: a root-free Cholesky sweep over the
+// (k' + nrhs) x k' array leaves A(i, c) = L(i, c) sqrt(d_c) in the triangle and, in the extra rows, the forward-
+// substituted right-hand sides in the same scaling, so that every dot product of the block elimination is
+// sum_j A(r, j) A(s, j) / d_j.  Inner products skip the square roots (one barrier per column instead of two).
+// The array lives in LDS while it fits (k' + nrhs up to ~180 rows), otherwise in a per-workgroup slab of HBM
+// (L2-resident for a few hundred neighbours): the same code runs on either through a generic pointer.
+// This is the functional path for large neighbourhoods, not a tuned one.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIG_NT = 256;
+constexpr int BIG_LDS_DOUBLES = 17408;   // 136 KiB of matrix in LDS
+constexpr int BIG_MAX_K = 4096;
+
+template <int DIM>
+__global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
+                                                                const double* __restrict__ z,
+                                                                const double* __restrict__ drift_data,
+                                                                const double* __restrict__ x0,
+                                                                const double* __restrict__ drift_dom, int64_t m, int k,
+                                                                int minneighbors, const int* __restrict__ idx,
+                                                                const int* __restrict__ count,
+                                                                double* __restrict__ mean_out,
+                                                                double* __restrict__ var_out,
+                                                                uint8_t* __restrict__ status_out,
+                                                                double* __restrict__ scratch, int64_t slab,
+                                                                int use_lds) {
+  extern __shared__ double big_sm[];
+  __shared__ double G[LMAX_RHS][LMAX_RHS];
+  __shared__ double Ssm[LMAX_NC][LMAX_NC + 1];
+  __shared__ double rv[LMAX_NC], tv[LMAX_NC];
+  __shared__ int bad_flag;
+  const int tid = threadIdx.x;
+  const int nc = sp.nc;
+  const int nrhs = 2 + nc;
+  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
+  for (int64_t p = blockIdx.x; p < m; p += gridDim.x) {
+    const int cnt = count[p];
+    __syncthreads();  // the previous point's results have been read
+    if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
+      if (tid == 0) {
+        mean_out[p] = NaN;
+        var_out[p] = NaN;
+        status_out[p] = GSS_PT_MISSING;
+      }
+      continue;
+    }
+    const int K1 = cnt;
+    const int RT = K1 + nrhs;
+    const int64_t ntri = (int64_t)K1 * (K1 + 1) / 2;
+    double* M = use_lds ? big_sm : scratch + (int64_t)blockIdx.x * slab;
+    double* invd = M + ntri + (int64_t)nrhs * K1;
+    const int* nb = idx + p * k;
+    double c0[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
+    if (tid == 0) bad_flag = 0;
+    // ---- assembly: covariance triangle (entries dealt round-robin), then the extra rows
+    for (int64_t e = tid; e < ntri; e += BIG_NT) {
+      int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+      while ((int64_t)(i + 1) * (i + 2) / 2 <= e) ++i;
+      while ((int64_t)i * (i + 1) / 2 > e) --i;
+      const int c = (int)(e - (int64_t)i * (i + 1) / 2);
+      const int ni = nb[i], ncl = nb[c];
+      double xi[DIM], xc[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        xi[a] = xdata[(int64_t)ni * DIM + a];
+        xc[a] = xdata[(int64_t)ncl * DIM + a];
+      }
+      M[e] = cov_pair<DIM>(vg, xi, xc);
+    }
+    for (int j = tid; j < K1; j += BIG_NT) {
+      const int nj = nb[j];
+      double xj[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
+      M[ntri + j] = cov_pair<DIM>(vg, xj, c0);
+      double zz = z[nj];
+      if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
+      M[ntri + K1 + j] = zz;
+      for (int c = 0; c < nc; ++c) {
+        double f = 1.0;
+        if (sp.variant == GSS_KRIG_UNIVERSAL) {
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) {
+            const double u = (xj[a] - c0[a]) * sp.inv_scale;
+            for (int q = 0; q < sp.e[c][a]; ++q) f *= u;
+          }
+        } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
+          f = drift_data[(int64_t)nj * nc + c];
+        }
+        M[ntri + (int64_t)(2 + c) * K1 + j] = f;
+      }
+    }
+    __syncthreads();
+    // ---- root-free Cholesky sweep by columns: row i of the array is owned by thread i mod 256
+    for (int j = 0; j < K1; ++j) {
+      const double* rowj = M + (int64_t)j * (j + 1) / 2;
+      for (int i = j + tid; i < RT; i += BIG_NT) {
+        double* rowi = i < K1 ? M + (int64_t)i * (i + 1) / 2 : M + ntri + (int64_t)(i - K1) * K1;
+        double a0 = rowi[j], a1 = 0.0;
+        int c = 0;
+        for (; c + 2 <= j; c += 2) {
+          a0 = fma(-rowi[c] * invd[c], rowj[c], a0);
+          a1 = fma(-rowi[c + 1] * invd[c + 1], rowj[c + 1], a1);
+        }
+        for (; c < j; ++c) a0 = fma(-rowi[c] * invd[c], rowj[c], a0);
+        const double acc = a0 + a1;
+        rowi[j] = acc;
+        if (i == j) {
+          if (!(acc > 0.0)) bad_flag = 1;
+          invd[j] = 1.0 / acc;
+        }
+      }
+      __syncthreads();
+      if (bad_flag) break;
+    }
+    if (bad_flag) {
+      if (tid == 0) {
+        mean_out[p] = NaN;
+        var_out[p] = NaN;
+        status_out[p] = GSS_PT_SINGULAR;
+      }
+      continue;
+    }
+    // ---- Gram matrix of the forward-substituted right-hand sides: one (r, s) pair per wave slot
+    {
+      const int lane = tid & 63, wave = tid >> 6;
+      const int npairs = nrhs * (nrhs + 1) / 2;
+      for (int pr = wave; pr < npairs; pr += BIG_NT / 64) {
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= pr) ++r;
+        const int sidx = pr - r * (r + 1) / 2;
+        const double* yr = M + ntri + (int64_t)r * K1;
+        const double* ys = M + ntri + (int64_t)sidx * K1;
+        double acc = 0.0;
+        for (int j = lane; j < K1; j += 64) acc = fma(yr[j] * invd[j], ys[j], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          G[r][sidx] = acc;
+          G[sidx][r] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double qf = G[0][0], af = G[1][0];
+      double rsr = 0.0, tsr = 0.0;
+      int okS = 1;
+      if (nc > 0) {
+        for (int c = 0; c < nc; ++c) {
+          double f0 = 1.0;
+          if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (sp.e[c][0] + sp.e[c][1] + sp.e[c][2]) == 0 ? 1.0 : 0.0;
+          else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + c];
+          rv[c] = G[2 + c][0] - f0;
+          tv[c] = G[2 + c][1];
+          for (int c2 = 0; c2 <= c; ++c2) Ssm[c][c2] = G[2 + c][2 + c2];
+        }
+        for (int j = 0; j < nc && okS; ++j) {
+          double d = Ssm[j][j];
+          for (int c = 0; c < j; ++c) d -= Ssm[j][c] * Ssm[j][c];
+          if (!(d > 0.0)) {
+            okS = 0;
+            break;
+          }
+          const double sq = sqrt(d);
+          Ssm[j][j] = sq;
+          for (int i = j + 1; i < nc; ++i) {
+            double v = Ssm[i][j];
+            for (int c = 0; c < j; ++c) v -= Ssm[i][c] * Ssm[j][c];
+            Ssm[i][j] = v / sq;
+          }
+        }
+        if (okS) {
+          for (int i = 0; i < nc; ++i) {
+            double u = rv[i], v = tv[i];
+            for (int c = 0; c < i; ++c) {
+              u -= Ssm[i][c] * rv[c];
+              v -= Ssm[i][c] * tv[c];
+            }
+            u /= Ssm[i][i];
+            v /= Ssm[i][i];
+            rv[i] = u;
+            tv[i] = v;
+            rsr += u * u;
+            tsr += u * v;
+          }
+        }
+      }
+      if (!okS) {
+        mean_out[p] = NaN;
+        var_out[p] = NaN;
+        status_out[p] = GSS_PT_SINGULAR;
+      } else {
+        const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
+        const double v = vg.sill - qf + rsr;
+        mean_out[p] = mu;
+        var_out[p] = v > 0.0 ? v : 0.0;
+        status_out[p] = GSS_PT_OK;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K5, MFMA-tiled variant (default).  Same mathematics as krig_local_kernel above, but the k x k system is held in
 // registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r <-> element
 // (row (l >> 4) + 4 r, column l & 15)) and factorised as A = U'U by tiles:
@@ -559,8 +765,9 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
                        int* count_out, hipStream_t s, int metric) {
   GSS_REQUIRE(nc <= LMAX_NC, "moving-neighbourhood kriging supports at most %d drift terms (got %d)", LMAX_NC, nc);
-  GSS_REQUIRE(k >= 1 && k <= LMAX_K, "maxneighbors = %d: the moving-neighbourhood kernels hold at most %d "
-                                     "neighbours (use the global neighbourhood beyond that)", k, LMAX_K);
+  GSS_REQUIRE(k >= 1 && k <= BIG_MAX_K, "maxneighbors = %d: moving neighbourhoods hold at most %d neighbours "
+                                        "(use the global neighbourhood beyond that)", k, BIG_MAX_K);
+  const bool big = k > LMAX_K;   // 65 .. 4096 neighbours: passes of the search, one workgroup per point
   LocalSpec sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.variant = variant;
@@ -571,10 +778,12 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   sp.inv_scale = inv_scale;
   sp.sk_mean = sk_mean;
 
-  const int64_t chunk = 1 << 20;
+  const int64_t chunk = big ? (k > 512 ? (1 << 14) : (1 << 17)) : (1 << 20);
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
-  const bool use_index = metric != GSS_METRIC_HAVERSINE && !(brute && brute[0] == '1');
+  const bool use_index = big || (metric != GSS_METRIC_HAVERSINE && !(brute && brute[0] == '1'));
+  GSS_REQUIRE(!big || metric != GSS_METRIC_HAVERSINE,
+              "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
   const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
   const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
@@ -590,12 +799,43 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     {
       ProfScope ps("knn", s);
       if (use_index)
-        GSS_TRY(knn_search_indexed(ix, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, nullptr, nullptr, nullptr,
-                                   metric));
+        GSS_TRY(knn_search_indexed_any(ix, xdata, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, metric));
       else GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx, cnt, s, metric));
     }
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
     ProfScope pl("krig_local", s);
+    if (big) {
+      const int64_t rows = (int64_t)k + 2 + nc;
+      const int64_t need = (int64_t)k * (k + 1) / 2 + (int64_t)(2 + nc) * k + k;
+      const bool in_lds = need <= BIG_LDS_DOUBLES;
+      const size_t lds = in_lds ? sizeof(double) * (size_t)BIG_LDS_DOUBLES : 0;
+      // in LDS one workgroup per CU is resident; through HBM slabs as many as 8 GiB of slabs allow (>= 64)
+      int64_t blocks = in_lds ? 256 * 4 : (int64_t)((size_t)8 << 30) / (int64_t)(sizeof(double) * (size_t)need);
+      if (blocks > 2048) blocks = 2048;
+      if (blocks < 64) blocks = 64;
+      if (blocks > mv) blocks = mv;
+      DevBuf slab;
+      if (!in_lds) GSS_TRY(slab.alloc(sizeof(double) * (size_t)(need * blocks)));
+      (void)rows;
+#define GSS_BIG_LAUNCH(D)                                                                                             \
+  do {                                                                                                                \
+    if (in_lds)                                                                                                       \
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_local_big_kernel<D>),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    hipLaunchKernelGGL((krig_local_big_kernel<D>), dim3((unsigned)blocks), dim3(BIG_NT), lds, s, vg, sp, xdata, z,    \
+                       drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st,     \
+                       slab.as<double>(), need, in_lds ? 1 : 0);                                                      \
+  } while (0)
+      switch (dim) {
+        case 1: GSS_BIG_LAUNCH(1); break;
+        case 2: GSS_BIG_LAUNCH(2); break;
+        default: GSS_BIG_LAUNCH(3); break;
+      }
+#undef GSS_BIG_LAUNCH
+      GSS_HIP(hipGetLastError());
+      GSS_HIP(hipStreamSynchronize(s));   // the slab is released at the end of this iteration
+      continue;
+    }
     if (use_mfma) {
 #define GSS_K5_ARGS vg, sp, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, \
                     var + off, st

@@ -167,7 +167,8 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
                                 double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
 
 /* moving neighbourhood: replaces approxsolve krig.jl:188-234 (search + fit + predictprob per point).
- * k = maxneighbors (already clamped by searcher_ui), radius / inv_radii / metric as gss_knn_search
+ * k = maxneighbors (already clamped by searcher_ui; 1..4096: up to 64 on the MFMA-tile kernel, beyond that the
+ * search runs in passes of 64 and one workgroup solves each point's system), radius / inv_radii / metric as gss_knn_search
  * (the metric only ranks neighbours; covariances keep the variogram's own distance).
  * idx_out (m x k int32) and count_out (m) may be NULL. */
 int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
@@ -190,8 +191,9 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
  *   (stored under `<var>_variance` exactly as lwr.jl:145,154 does).
  *   weight(h) = exp(-weight_a * h^weight_p) for GSS_WEIGHT_EXP (reference default a = 3, p = 2,
  *   lwr.jl:58) or (1 - h^3)^3 for GSS_WEIGHT_TRICUBE.
- * k = number of neighbours the searcher returns (ui.jl:16-23): 1..64, or k == n for
- * `maxneighbors = nothing` (every sample, no search).  radius / inv_radii / metric as gss_knn_search;
+ * k = number of neighbours the searcher returns (ui.jl:16-23): 1..n; k == n is `maxneighbors = nothing` (every
+ * sample, no search); beyond 64 the search runs in passes of 64 (haversine: at most 64).  radius / inv_radii /
+ * metric as gss_knn_search;
  * the weights use the distances of that metric (searchdists!, idw.jl:120).
  * status: GSS_PT_MISSING when fewer than minneighbors were found (idw.jl:123, lwr.jl:126),
  * GSS_PT_SINGULAR when the LWR normal equations are not positive definite (the reference throws).

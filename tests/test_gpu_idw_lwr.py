@@ -106,9 +106,9 @@ def test_solvers_through_solve_and_argument_errors():
     sol = gss.solve(prob, gss.LWRSolver())
     rmu, rvar, _ = E.lwr(xs[keep], zs[keep], grid)
     assert sol.names() == ["z", "z_variance"] and _close(sol["z"], rmu, 1e-9) and _close(sol["z_variance"], rvar, 1e-9)
-    with pytest.raises(_lib.GSSError, match="at most 64"):
-        from gss.engine import HipEngine
-        HipEngine.idw(rng.uniform(size=(200, 2)), rng.uniform(size=200), grid, 100)
+    from gss.engine import HipEngine
+    with pytest.raises(_lib.GSSError, match="at most 64"):      # only the exhaustive (haversine) search is limited
+        HipEngine.idw(rng.uniform(size=(200, 2)), rng.uniform(size=200), grid, 100, distance=("haversine", 1.0))
     with pytest.raises(_lib.GSSError, match="exponent must be positive"):
         HipEngine.idw(xs[keep], zs[keep], grid, 5, 1, 0.0)
 

@@ -1,0 +1,122 @@
+"""maxneighbors between 65 and n - 1.  The reference accepts any count (src/ui.jl:16-23 clamps only above n;
+src/estimation/krig.jl:201-210 sizes its buffer by it); on the device the search runs in passes of 64 (each pass
+bounded below by the last key of the pass before) and the estimators switch to their any-k kernels (one workgroup per
+point for kriging, one thread per point walking the list for IDW / LWR).  Same bars as the k <= 64 paths: neighbour
+indices bit-exact, estimates 1e-9 against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import idw_lwr as E, kriging as K
+from oracle.variogram import Variogram
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,m,dim,k,ball", [(300, 200, 2, 65, None), (1000, 150, 3, 128, None), (700, 100, 1, 130, None),
+                                            (2500, 120, 3, 200, None), (2000, 150, 2, 150, 9.0),
+                                            (400, 50, 3, 399, None)])
+def test_knn_any_k_indices_bit_exact(n, m, dim, k, ball):
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(n + k)
+    x = rng.uniform(0, 100, (n, dim))
+    x[50:60] = x[:10]                                   # exact duplicates: ties broken by index across pass boundaries
+    c = rng.uniform(0, 100, (m, dim))
+    c[:3] = x[:3]
+    kw = {} if ball is None else dict(radius=ball)
+    idx, cnt = HipEngine.knn_search(x, c, k, **kw)
+    ridx, rcnt = K.knn_search(x, c, k, **kw)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx)
+    if ball is not None:
+        assert cnt.min() < k           # the ball cuts some lists short (a pass comes back short, the next finds nothing)
+
+
+CASES = [(K.OK, {}, "matern", dict(range=30.0, nu=1.5)),
+         (K.SK, dict(mean=0.3), "exponential", dict(range=25.0, sill=2.0, nugget=0.1)),
+         (K.UK, dict(degree=1), "spherical", dict(range=40.0, nugget=0.05)),
+         (K.UK, dict(degree=2), "matern", dict(range=35.0, nu=2.5, nugget=0.02))]
+
+
+@pytest.mark.parametrize("variant,okw,kind,vkw", CASES)
+@pytest.mark.parametrize("n,m,dim,k", [(500, 120, 3, 65), (900, 100, 3, 128), (1500, 60, 2, 170), (1200, 40, 3, 260)])
+def test_local_kriging_with_more_than_64_neighbours(variant, okw, kind, vkw, n, m, dim, k):
+    """k' + constraints up to ~180 rows: system in LDS; beyond: per-workgroup slab in HBM (k = 260 here)."""
+    import gss
+    from gss.engine import KrigHandle
+    ctor = dict(exponential=gss.ExponentialVariogram, spherical=gss.SphericalVariogram, matern=gss.MaternVariogram)[kind]
+    gkw = dict(vkw)
+    if "nu" in gkw:
+        gkw["order"] = gkw.pop("nu")
+    gvg, ovg = ctor(**gkw), Variogram(kind, **vkw)
+    rng = np.random.default_rng(n * 3 + k)
+    x = rng.uniform(0, 100, (n, dim))
+    z = rng.normal(size=n) + 0.02 * x[:, 0]
+    x0 = rng.uniform(0, 100, (m, dim))
+    x0[:2] = x[:2]
+    h = KrigHandle(gvg, variant, x, z, mean=okw.get("mean"), degree=okw.get("degree"), factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, k, return_idx=True)
+    h.close()
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(variant, ovg, x, z, x0, k, mean=okw.get("mean") or 0.0,
+                                               degree=okw.get("degree"), return_idx=True)
+    assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt) and np.array_equal(st, rst) and not st.any()
+    assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu)))
+    assert np.max(np.abs(var - rvar)) < 1e-9
+    assert np.allclose(mu[:2], z[:2], atol=1e-9) or vkw.get("nugget", 0) > 0
+
+
+def test_ball_limited_large_neighbourhood_and_missing_points():
+    """KBallSearch semantics with k > 64: neighbour counts vary from 0 to k inside one launch."""
+    import gss
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, 100, (3000, 2))
+    z = rng.normal(size=3000)
+    x0 = np.concatenate([rng.uniform(0, 100, (150, 2)), rng.uniform(300, 400, (10, 2))])
+    h = KrigHandle(gss.ExponentialVariogram(range=20.0, nugget=0.05), K.OK, x, z, factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, 100, minneighbors=3, radius=9.0, return_idx=True)
+    h.close()
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(K.OK, Variogram("exponential", range=20.0, nugget=0.05), x, z, x0, 100, 3,
+                                               radius=9.0, return_idx=True)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and np.array_equal(st, rst)
+    assert cnt.max() > 64 and st[-10:].all() and cnt[-10:].max() == 0
+    ok = st == 0
+    assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-9 and np.max(np.abs(var[ok] - rvar[ok])) < 1e-9
+
+
+def test_k_just_below_n_approaches_global_and_solve_api():
+    """maxneighbors = n - 1 through the solver front-end (krig.jl:151-157 takes the approxsolve branch)."""
+    import gss
+    rng = np.random.default_rng(21)
+    xy = rng.uniform(0, 50, (90, 2))
+    z = rng.normal(size=90)
+    dom = gss.PointSet(rng.uniform(0, 50, (40, 2)))
+    prob = gss.EstimationProblem(gss.georef({"z": z}, xy), dom, "z")
+    vg = gss.SphericalVariogram(range=20.0, nugget=0.1)
+    sol = gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=89))))
+    rmu, rvar, rst = K.approxsolve(K.OK, Variogram("spherical", range=20.0, nugget=0.1), xy, z, dom.coords, 89)
+    assert np.max(np.abs(sol["z"] - rmu)) < 1e-9 and np.max(np.abs(sol["z_variance"] - rvar)) < 1e-9
+
+
+@pytest.mark.parametrize("n,m,dim,k", [(500, 300, 2, 65), (3000, 200, 3, 150), (400, 100, 1, 300)])
+def test_idw_lwr_with_more_than_64_neighbours(n, m, dim, k):
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(n + dim)
+    x = rng.uniform(0, 100, (n, dim))
+    z = np.sin(x[:, 0] / 17.0) + 0.01 * x.sum(axis=1) + 0.1 * rng.normal(size=n)
+    c = rng.uniform(-5, 105, (m, dim))
+    c[:4] = x[:4]
+    for exponent in (1, 2.5):
+        mu, sd, st = HipEngine.idw(x, z, c, k, 1, exponent)
+        rmu, rsd, rst = E.idw(x, z, c, k, 1, exponent)
+        assert np.array_equal(st, rst) and np.max(np.abs(mu - rmu)) < 1e-10 and np.max(np.abs(sd - rsd)) < 1e-10
+        assert np.array_equal(mu[:4], z[:4]) and np.all(sd[:4] == 0.0)
+    for spec, wf in (((0, 3.0, 2.0), E.default_weightfun), ((1, 0.0, 0.0), E.tricube)):
+        mu, var, st = HipEngine.lwr(x, z, c, k, 1, spec)
+        rmu, rvar, rst = E.lwr(x, z, c, k, 1, wf)
+        assert np.array_equal(st, rst) and not st.any()
+        assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var - rvar)) < 1e-9
+    # ball-limited
+    mu, sd, st = HipEngine.idw(x, z, c, k, 2, 1, radius=12.0)
+    rmu, rsd, rst = E.idw(x, z, c, k, 2, 1, radius=12.0)
+    assert np.array_equal(st, rst)
+    ok = st == 0
+    assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-10
