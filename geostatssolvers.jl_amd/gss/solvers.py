@@ -132,16 +132,48 @@ def _distance(p):
     return None if p["neighborhood"] is not None else d
 
 
-def _path_order(path, n):
+def multigrid_order(dims):
+    """Coarse-to-fine visiting order of a Cartesian grid ([DEP] Meshes `MultiGridPath`, test/estimation/krig.jl:87):
+    cells whose indices are all multiples of the largest power-of-two stride first, then stride / 2, ... down to 1,
+    each level in linear (first axis fastest) order.  The package's exact order is not vendored; an estimation
+    solver only permutes its output columns by it (krig.jl:179-183), a simulation solver conditions on it."""
+    dims = tuple(int(d) for d in dims)
+    idx = np.indices(dims[::-1])[::-1]                      # idx[a]: index along axis a, element order (axis 0 fastest)
+    flat = [i.reshape(-1) for i in idx]
+    stride = 1
+    while stride * 2 < max(dims):
+        stride *= 2
+    level = np.zeros(flat[0].shape, dtype=np.int64)
+    s, lv = stride, 0
+    assigned = np.zeros(flat[0].shape, dtype=bool)
+    while s >= 1:
+        on = np.ones_like(assigned)
+        for f in flat:
+            on &= (f % s) == 0
+        new = on & ~assigned
+        level[new] = lv
+        assigned |= new
+        s //= 2
+        lv += 1
+    return np.argsort(level, kind="stable")
+
+
+def _path_order(path, n, domain=None):
     """Traversal order of the estimation loop (krig.jl:179, idw.jl:112, lwr.jl:115): None for LinearPath, else a
-    permutation of 0..n-1 -- ("random", seed) or an explicit visiting order.  The reference stores its results in
-    traversal order (`pred = map(inds) do ind ...`, krig.jl:180-183), so the columns are permuted accordingly."""
+    permutation of 0..n-1 -- ("random", seed), "multigrid" (Cartesian grids) or an explicit visiting order.  The
+    reference stores its results in traversal order (`pred = map(inds) do ind ...`, krig.jl:180-183), so the columns
+    are permuted accordingly."""
     if path is None or (isinstance(path, str) and path == "linear"):
         return None
     if isinstance(path, tuple) and len(path) == 2 and path[0] == "random":
         return np.random.default_rng(path[1]).permutation(n)
+    if isinstance(path, str) and path == "multigrid":
+        g = parent(domain) if domain is not None else None
+        if g is None or not hasattr(g, "dims") or parentindices(domain) is not None:
+            raise ValueError("path='multigrid' needs a CartesianGrid domain")
+        return multigrid_order(g.dims)
     if isinstance(path, str):
-        raise NotImplementedError(f"path {path!r}: give 'linear', ('random', seed) or a visiting order")
+        raise NotImplementedError(f"path {path!r}: give 'linear', 'multigrid', ('random', seed) or a visiting order")
     order = np.asarray(path, dtype=np.int64)
     if order.shape != (n,) or not np.array_equal(np.sort(order), np.arange(n)):
         raise ValueError("path must be a permutation of the domain elements")
@@ -204,7 +236,7 @@ class KrigingSolver(_Solver):
             if inds.size == 0:
                 raise AssertionError(f"all samples of {var} are missing, aborting...")   # krig.jl:100-102
             _distance(p)
-            _path_order(p["path"], problem.domain.nelements())
+            _path_order(p["path"], problem.domain.nelements(), problem.domain)
             vdom = PointSet(coords[inds])
             variant = kriging_ui(problem.domain, p["variogram"], p["mean"], p["degree"], p["drifts"])
             kind, nmax = searcher_ui(vdom, p["maxneighbors"], p["distance"], p["neighborhood"])
@@ -254,7 +286,7 @@ class KrigingSolver(_Solver):
             if gather and ws > 1:
                 mu = parallel.all_gather_concat(mu, m)
                 var_ = parallel.all_gather_concat(var_, m)
-            order = _path_order(p["path"], m)
+            order = _path_order(p["path"], m, pdom)
             if order is not None and (gather or ws == 1):              # results in traversal order, krig.jl:179-183
                 mu, var_ = mu[order], var_[order]
             cols[var] = mu
@@ -313,7 +345,7 @@ class _NeighborEstimator(_Solver):
             n = inds.size
             assert n > 0, "estimation requires data"                      # idw.jl:95
             _distance(p)
-            order = _path_order(p["path"], m)
+            order = _path_order(p["path"], m, pdom)
             nmin = p["minneighbors"]
             nmax = n if p["maxneighbors"] is None else min(p["maxneighbors"], n)      # idw.jl:93
             self._check(p)

@@ -215,6 +215,12 @@ def test_reference_nearest_and_local_cases_through_solve():
         sol = gss.solve(gss.EstimationProblem(data, grid, "z"),
                         gss.KrigingSolver(("z", dict(variogram=vg, maxneighbors=7))))
     assert np.all(np.isfinite(sol["z"]))
+    # custom path (test/estimation/krig.jl:78-90): the results come back in traversal order (krig.jl:179-183)
+    kw = dict(variogram=vg, maxneighbors=3, neighborhood=gss.MetricBall(100.0))
+    lin = gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", kw)))
+    mg = gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", dict(kw, path="multigrid"))))
+    order = gss.solvers.multigrid_order((100, 100))
+    assert np.array_equal(mg["z"], lin["z"][order]) and np.array_equal(mg["z_variance"], lin["z_variance"][order])
 
 
 def test_config5_shape_small():
