@@ -99,7 +99,7 @@ def test_kriging_variants_through_solve_match_direct_oracle():
 def test_unsupported_options_fail_loudly():
     data = gss.georef({"z": [1.0, 0.0]}, [(0.0, 0.0), (1.0, 1.0)])
     grid = gss.CartesianGrid(4, 4)
-    for bad in (dict(distance="minkowski"), dict(path="multigrid")):   # named paths other than "linear" need an order
+    for bad in (dict(distance="minkowski"), dict(path="source")):     # unknown named paths need an explicit order
         with pytest.raises(NotImplementedError):
             gss.solve(gss.EstimationProblem(data, grid, "z"), gss.KrigingSolver(("z", bad), engine=OracleEngine))
     with pytest.raises(ValueError, match="Cartesian grids"):                                    # fft.jl:40-42
