@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void drift_rows_kernel(DriftSpec ds, const dou
   }
 }
 
+// C(d2) for a single-structure model fixed at compile time, without control flow: the shape is evaluated on
+// max(d2, 1e-300) for every lane and the zero-lag value (the sill, nugget included) is selected afterwards.  For
+// d2 > 0 the operations are those of cov_pair, so values agree with the fit's data-data matrix bit for bit.
+template <int KIND>
+__device__ __forceinline__ double cov_d2_select(const VgDev& vg, double d2) {
+  const double val = vg.cs * vg_shape(KIND, fmax(d2, 1e-300), vg.inv_range, vg.mscale, vg.pw);
+  return d2 <= 0.0 ? vg.sill : val;
+}
+
 // R[j * ldr + p] = C(x_j, x0_p) for the j rows of segment blockIdx.y
 // KIND >= 0: single-structure model fixed at compile time -- the same arithmetic as cov_pair (which the fit uses, so
 // a domain point on a datum reproduces that datum's column of C bit for bit) with the model switch folded away; the
@@ -105,9 +114,78 @@ __global__ __launch_bounds__(256) void krig_rhs_kernel(VgDev vg, const double* _
   }
 }
 
+// The same assembly with two adjacent points per thread: every store instruction writes 16 B per lane (1 KiB per
+// wave and row) instead of 8 -- the store path of this device takes 16-B-per-lane streams at 6.0-6.2 TB/s
+// (tools/probe_hbm.hip) against 4.8 TB/s for the 8-B form of this kernel.  ncols = padded point count (even).
+template <int DIM, int KIND>
+__global__ __launch_bounds__(256) void krig_rhs2_kernel(VgDev vg, const double* __restrict__ xd, int n,
+                                                        const double* __restrict__ x0, int64_t m_valid,
+                                                        double* __restrict__ R, int64_t ldr, int seg_len, int nblk,
+                                                        int64_t ncols) {
+  for (int unit = blockIdx.x; unit < nblk * NSEG; unit += gridDim.x) {
+    const int seg = unit % NSEG;
+    const int64_t p = (int64_t)(unit / NSEG) * 512 + 2 * threadIdx.x;
+    if (p >= ncols) continue;
+    const int64_t pa = p < m_valid ? p : m_valid - 1, pb = p + 1 < m_valid ? p + 1 : m_valid - 1;
+    double ca[DIM], cb[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      ca[k] = x0[pa * DIM + k];
+      cb[k] = x0[pb * DIM + k];
+    }
+    const int j0 = seg * seg_len;
+    const int j1 = j0 + seg_len < n ? j0 + seg_len : n;
+    double2* rp = reinterpret_cast<double2*>(R + (int64_t)j0 * ldr + p);
+    const int64_t ld2 = ldr >> 1;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+      double x[DIM];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) x[k] = xd[j * DIM + k];
+      double2 v;
+      if (KIND < 0) {
+        v.x = cov_pair<DIM>(vg, x, ca);
+        v.y = cov_pair<DIM>(vg, x, cb);
+      } else {
+        // isotropic models carry ir = 1 (make_vgdev): multiplying by it is exact, and cheaper than selecting per
+        // component on the run-time flag
+        const double da = sqdist_nofma<DIM>(x, ca, vg.ir, true);
+        const double db = sqdist_nofma<DIM>(x, cb, vg.ir, true);
+        v.x = cov_d2_select < KIND < 0 ? 0 : KIND > (vg, da);
+        v.y = cov_d2_select < KIND < 0 ? 0 : KIND > (vg, db);
+      }
+      *rp = v;
+      rp += ld2;
+    }
+  }
+}
+
 template <int DIM>
 static void launch_krig_rhs(dim3 grid, hipStream_t s, const VgDev& vg, const double* xd, int n, const double* x0,
                             int64_t m_valid, double* R, int64_t ldr, int seg_len, int nblk) {
+  static const bool wide = [] {
+    const char* e = std::getenv("GSS_K1_WIDE");
+    return !(e && e[0] == '0');
+  }();
+  if (wide && (ldr & 1) == 0) {
+    const int64_t ncols = (int64_t)nblk * 256;
+    const int nblk2 = (int)((ncols + 511) / 512);
+    const dim3 g2((unsigned)(nblk2 * NSEG));
+#define GSS_K1W_LAUNCH(KIND)                                                                                         \
+  hipLaunchKernelGGL((krig_rhs2_kernel<DIM, KIND>), g2, dim3(256), 0, s, vg, xd, n, x0, m_valid, R, ldr, seg_len,    \
+                     nblk2, ncols)
+    switch (vg.nextra == 0 ? vg.kind : -1) {
+      case GSS_VG_GAUSSIAN: GSS_K1W_LAUNCH(GSS_VG_GAUSSIAN); break;
+      case GSS_VG_EXPONENTIAL: GSS_K1W_LAUNCH(GSS_VG_EXPONENTIAL); break;
+      case GSS_VG_SPHERICAL: GSS_K1W_LAUNCH(GSS_VG_SPHERICAL); break;
+      case VG_MATERN12: GSS_K1W_LAUNCH(VG_MATERN12); break;
+      case VG_MATERN32: GSS_K1W_LAUNCH(VG_MATERN32); break;
+      case VG_MATERN52: GSS_K1W_LAUNCH(VG_MATERN52); break;
+      default: GSS_K1W_LAUNCH(-1); break;
+    }
+#undef GSS_K1W_LAUNCH
+    return;
+  }
 #define GSS_K1_LAUNCH(KIND)                                                                                       \
   hipLaunchKernelGGL((krig_rhs_kernel<DIM, KIND>), grid, dim3(256), 0, s, vg, xd, n, x0, m_valid, R, ldr, seg_len, \
                      nblk)
@@ -152,8 +230,8 @@ __global__ __launch_bounds__(256) void krig_batch_mean_kernel(VgDev vg, DriftSpe
     if (KIND < 0) {
       cv = cov_pair<DIM>(vg, x, c);
     } else {
-      const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, vg.aniso != 0);
-      cv = d2 <= 0.0 ? vg.sill : vg.cs * vg_shape(KIND < 0 ? 0 : KIND, d2, vg.inv_range, vg.mscale, vg.pw);
+      const double d2 = sqdist_nofma<DIM>(x, c, vg.ir, true);   // ir = 1 for isotropic models: exact
+      cv = cov_d2_select < KIND < 0 ? 0 : KIND > (vg, d2);
     }
 #pragma unroll
     for (int b = 0; b < BATCH_NB; ++b) acc[b] = fma(cv, WDt[(int64_t)j * BATCH_NB + b], acc[b]);

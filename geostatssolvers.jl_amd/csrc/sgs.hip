@@ -257,6 +257,67 @@ __global__ __launch_bounds__(64) void sgs_sweep_kernel(const int64_t* __restrict
   }
 }
 
+// ---- one visiting order per realisation (seq.jl:99-102 calls traverse inside solvesingle: a RandomPath differs
+//      from realisation to realisation).  Stage A runs once per path; the sweep gives every realisation a lane of its
+//      own: nothing is shared between lanes any more, so the field is realisation-major [R][N] (= the output layout)
+//      and every access is a per-lane gather.
+__global__ __launch_bounds__(256) void sgs_noise_rows_kernel(uint64_t seed, int64_t first_real, int64_t N, int R,
+                                                             const double* __restrict__ noise,
+                                                             double* __restrict__ zr) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * R) return;
+  const int64_t r = e / N, cell = e - r * N;
+  zr[e] = noise ? noise[e] : philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)cell);
+}
+
+__global__ __launch_bounds__(256) void sgs_seed_data_rows_kernel(const int64_t* __restrict__ dlocs,
+                                                                 const double* __restrict__ zd, int64_t nd, int64_t N,
+                                                                 int R, double* __restrict__ zr) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nd * R) return;
+  const int64_t r = e / nd, j = e - r * nd;
+  zr[r * N + dlocs[j]] = zd[j];
+}
+
+__global__ __launch_bounds__(64) void sgs_sweep_paths_kernel(const int64_t* __restrict__ paths,
+                                                             const int* __restrict__ ranks,
+                                                             const int* __restrict__ idx,
+                                                             const int* __restrict__ ncond,
+                                                             const double* __restrict__ w,
+                                                             const double* __restrict__ sigma, int k, int64_t N, int R,
+                                                             int64_t path0, double mean, double* __restrict__ zr) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= R) return;
+  const int64_t pi = path0 + r;                 // realisation r of this call walks path path0 + r
+  const int64_t* path = paths + pi * N;
+  const int* rank = ranks + pi * N;
+  const int* nbr = idx + pi * N * k;
+  const int* nc = ncond + pi * N;
+  const double* wt = w + pi * N * k;
+  const double* sg = sigma + pi * N;
+  double* z = zr + (int64_t)r * N;
+  int64_t node_n = path[0];
+  for (int64_t t = 0; t < N; ++t) {
+    const int64_t node = node_n;
+    if (t + 1 < N) node_n = path[t + 1];        // next node's address is known a step ahead
+    if (rank[node] < 0) continue;               // conditioning cell
+    const int c = nc[node];
+    const int* nb = nbr + node * k;
+    const double* ww = wt + node * k;
+    double acc = 0.0;
+    int j = 0;
+    for (; j + 4 <= c; j += 4) {                // four gathers in flight
+      const double z0 = z[nb[j]], z1 = z[nb[j + 1]], z2 = z[nb[j + 2]], z3 = z[nb[j + 3]];
+      acc = fma(ww[j], z0 - mean, acc);
+      acc = fma(ww[j + 1], z1 - mean, acc);
+      acc = fma(ww[j + 2], z2 - mean, acc);
+      acc = fma(ww[j + 3], z3 - mean, acc);
+    }
+    for (; j < c; ++j) acc = fma(ww[j], z[nb[j]] - mean, acc);
+    z[node] = mean + acc + sg[node] * z[node];  // the cell's own slot holds its normal until it is simulated
+  }
+}
+
 }  // namespace gss
 
 using namespace gss;
@@ -266,17 +327,20 @@ struct gss_sgs {
   int dim = 0, k = 0;
   int64_t N = 0, nd = 0;
   double mean = 0.0;
-  DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;
+  int64_t npaths = 1, path_base = 0;  // npaths > 1: one visiting order per realisation, path p <-> realisation path_base + p
+  DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;   // per path: N entries (path, rank, ncond, sigma), N k (idx, w)
   DevBuf field;  // node-major [N][R] working field of gss_sgs_realize, kept between calls (grows to the largest R seen)
 };
 
 extern "C" {
 
-int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
-                       int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
-                       int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
-                       int32_t flags, void* stream) {
+int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids,
+                             int64_t N, int32_t dim, const int64_t* path, int64_t npaths, int64_t path_base,
+                             const int64_t* dlocs, const double* zdata, int64_t nd, int32_t maxneighbors,
+                             int32_t minneighbors, double radius, const double* inv_radii, int32_t flags,
+                             void* stream) {
   GSS_REQUIRE(out != nullptr, "gss_sgs_create: out is NULL");
+  GSS_REQUIRE(npaths >= 1 && path_base >= 0 && (npaths == 1 || path != nullptr), "gss_sgs_create_paths: bad path set");
   *out = nullptr;
   GSS_REQUIRE(vg && centroids, "gss_sgs_create: NULL argument");
   GSS_REQUIRE(N >= 1 && N < INT_MAX && dim >= 1 && dim <= 3, "gss_sgs_create: bad sizes");
@@ -300,32 +364,38 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
   h->N = N;
   h->nd = nd;
   h->mean = mean;
+  h->npaths = npaths;
+  h->path_base = path_base;
+  const int64_t P = npaths;
 
-  // visiting rank of every cell (-1 = conditioning cell); path must be a permutation of 0..N-1
-  std::vector<int64_t> hpath((size_t)N);
-  std::vector<int> hrank((size_t)N, INT_MAX);
-  for (int64_t t = 0; t < N; ++t) {
-    const int64_t c = path ? path[t] : t;  // LinearPath (seq.jl:33)
-    GSS_REQUIRE(c >= 0 && c < N && hrank[(size_t)c] == INT_MAX, "path is not a permutation of the domain (step %lld)",
-                (long long)t);
-    hpath[(size_t)t] = c;
-    hrank[(size_t)c] = (int)t;
-  }
-  for (int64_t j = 0; j < nd; ++j) {
-    GSS_REQUIRE(dlocs[j] >= 0 && dlocs[j] < N, "data location %lld outside the domain", (long long)dlocs[j]);
-    GSS_REQUIRE(hrank[(size_t)dlocs[j]] >= 0, "data location %lld given twice", (long long)dlocs[j]);
-    hrank[(size_t)dlocs[j]] = -1;
+  // visiting rank of every cell (-1 = conditioning cell) per path; each path must be a permutation of 0..N-1
+  std::vector<int64_t> hpath((size_t)(N * P));
+  std::vector<int> hrank((size_t)(N * P), INT_MAX);
+  for (int64_t pp = 0; pp < P; ++pp) {
+    int* rk = hrank.data() + pp * N;
+    for (int64_t t = 0; t < N; ++t) {
+      const int64_t c = path ? path[pp * N + t] : t;  // LinearPath (seq.jl:33)
+      GSS_REQUIRE(c >= 0 && c < N && rk[c] == INT_MAX, "path %lld is not a permutation of the domain (step %lld)",
+                  (long long)pp, (long long)t);
+      hpath[(size_t)(pp * N + t)] = c;
+      rk[c] = (int)t;
+    }
+    for (int64_t j = 0; j < nd; ++j) {
+      GSS_REQUIRE(dlocs[j] >= 0 && dlocs[j] < N, "data location %lld outside the domain", (long long)dlocs[j]);
+      GSS_REQUIRE(rk[dlocs[j]] >= 0, "data location %lld given twice", (long long)dlocs[j]);
+      rk[dlocs[j]] = -1;
+    }
   }
 
   DevBuf cent, bmin, cnt;
   GSS_TRY(cent.alloc(sizeof(double) * (size_t)(N * dim)));
-  GSS_TRY(h->path.alloc(sizeof(int64_t) * (size_t)N));
-  GSS_TRY(h->rank.alloc(sizeof(int) * (size_t)N));
-  GSS_TRY(h->idx.alloc(sizeof(int) * (size_t)(N * h->k)));
-  GSS_TRY(h->ncond.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(h->path.alloc(sizeof(int64_t) * (size_t)(N * P)));
+  GSS_TRY(h->rank.alloc(sizeof(int) * (size_t)(N * P)));
+  GSS_TRY(h->idx.alloc(sizeof(int) * (size_t)(N * P * h->k)));
+  GSS_TRY(h->ncond.alloc(sizeof(int) * (size_t)(N * P)));
   GSS_TRY(cnt.alloc(sizeof(int) * (size_t)N));
-  GSS_TRY(h->w.alloc(sizeof(double) * (size_t)(N * h->k)));
-  GSS_TRY(h->sigma.alloc(sizeof(double) * (size_t)N));
+  GSS_TRY(h->w.alloc(sizeof(double) * (size_t)(N * P * h->k)));
+  GSS_TRY(h->sigma.alloc(sizeof(double) * (size_t)(N * P)));
   GSS_HIP(hipMemcpyAsync(cent.p, centroids, cent.bytes, hipMemcpyHostToDevice, s));
   GSS_HIP(hipMemcpyAsync(h->path.p, hpath.data(), h->path.bytes, hipMemcpyHostToDevice, s));
   GSS_HIP(hipMemcpyAsync(h->rank.p, hrank.data(), h->rank.bytes, hipMemcpyHostToDevice, s));
@@ -340,30 +410,42 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
   if (N >= KNN_DEVICE_BUILD_MIN) GSS_TRY(knn_index_build_device(cent.as<double>(), N, dim, &ix, s));  // already in HBM
   else GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
   GSS_TRY(bmin.alloc(sizeof(int) * (size_t)ix.nb));
-  hipLaunchKernelGGL(sgs_batch_minrank_kernel, dim3((unsigned)((ix.nb + 3) / 4)), dim3(256), 0, s, ix.perm.as<int>(),
-                     h->rank.as<int>(), (int)N, ix.nb, bmin.as<int>());
-  GSS_HIP(hipGetLastError());
-  {
-    ProfScope ps("sgs_search", s);
-    GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, h->idx.as<int>(), cnt.as<int>(), s,
-                               h->rank.as<int>(), h->rank.as<int>(), bmin.as<int>()));
-  }
-  {
-    ProfScope ps("sgs_weights", s);
-#define GSS_SGS_ARGS h->vg, cent.as<double>(), h->rank.as<int>(), N, h->k, minneighbors, h->idx.as<int>(), \
-                     cnt.as<int>(), h->ncond.as<int>(), h->w.as<double>(), h->sigma.as<double>()
-    switch (dim) {
-      case 1: hipLaunchKernelGGL((sgs_weights_kernel<1>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
-      case 2: hipLaunchKernelGGL((sgs_weights_kernel<2>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
-      default: hipLaunchKernelGGL((sgs_weights_kernel<3>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
-    }
-#undef GSS_SGS_ARGS
+  for (int64_t pp = 0; pp < P; ++pp) {   // stage A once per visiting order
+    int* rk = h->rank.as<int>() + pp * N;
+    int* idxp = h->idx.as<int>() + pp * N * h->k;
+    hipLaunchKernelGGL(sgs_batch_minrank_kernel, dim3((unsigned)((ix.nb + 3) / 4)), dim3(256), 0, s, ix.perm.as<int>(),
+                       rk, (int)N, ix.nb, bmin.as<int>());
     GSS_HIP(hipGetLastError());
+    {
+      ProfScope ps("sgs_search", s);
+      GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
+                                 bmin.as<int>()));
+    }
+    {
+      ProfScope ps("sgs_weights", s);
+#define GSS_SGS_ARGS h->vg, cent.as<double>(), rk, N, h->k, minneighbors, idxp, cnt.as<int>(), \
+                     h->ncond.as<int>() + pp * N, h->w.as<double>() + pp * N * h->k, h->sigma.as<double>() + pp * N
+      switch (dim) {
+        case 1: hipLaunchKernelGGL((sgs_weights_kernel<1>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+        case 2: hipLaunchKernelGGL((sgs_weights_kernel<2>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+        default: hipLaunchKernelGGL((sgs_weights_kernel<3>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+      }
+#undef GSS_SGS_ARGS
+      GSS_HIP(hipGetLastError());
+    }
   }
   GSS_HIP(hipStreamSynchronize(s));  // host staging vectors and scratch are released on return
   guard.p = nullptr;
   *out = h;
   return GSS_OK;
+}
+
+int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
+                       int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
+                       int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
+                       int32_t flags, void* stream) {
+  return gss_sgs_create_paths(out, vg, mean, centroids, N, dim, path, 1, 0, dlocs, zdata, nd, maxneighbors, minneighbors,
+                              radius, inv_radii, flags, stream);
 }
 
 int32_t gss_sgs_destroy(gss_sgs_t* h) {
@@ -376,10 +458,12 @@ int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, d
   GSS_REQUIRE(h != nullptr, "NULL handle");
   hipStream_t s = to_stream(stream);
   const hipMemcpyKind kind = mem == GSS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (idx) GSS_HIP(hipMemcpyAsync(idx, h->idx.p, h->idx.bytes, kind, s));
-  if (ncond) GSS_HIP(hipMemcpyAsync(ncond, h->ncond.p, h->ncond.bytes, kind, s));
-  if (w) GSS_HIP(hipMemcpyAsync(w, h->w.p, h->w.bytes, kind, s));
-  if (sigma) GSS_HIP(hipMemcpyAsync(sigma, h->sigma.p, h->sigma.bytes, kind, s));
+  // (the first visiting order when the handle holds several)
+  const size_t nk = (size_t)(h->N * h->k), n1 = (size_t)h->N;
+  if (idx) GSS_HIP(hipMemcpyAsync(idx, h->idx.p, sizeof(int) * nk, kind, s));
+  if (ncond) GSS_HIP(hipMemcpyAsync(ncond, h->ncond.p, sizeof(int) * n1, kind, s));
+  if (w) GSS_HIP(hipMemcpyAsync(w, h->w.p, sizeof(double) * nk, kind, s));
+  if (sigma) GSS_HIP(hipMemcpyAsync(sigma, h->sigma.p, sizeof(double) * n1, kind, s));
   if (mem == GSS_MEM_HOST) GSS_HIP(hipStreamSynchronize(s));
   return GSS_OK;
 }
@@ -396,6 +480,35 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
   Staged sn, so;
   if (noise) GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(N * R), mem, s));
   GSS_TRY(so.out(out, sizeof(double) * (size_t)(N * R), mem));
+  if (h->npaths > 1) {
+    // one visiting order per realisation: realisation first_real + i walks path first_real + i - path_base
+    const int64_t p0 = first_real - h->path_base;
+    GSS_REQUIRE(p0 >= 0 && p0 + nreals <= h->npaths, "realisations %lld..%lld have no visiting order in this handle "
+                "(paths cover %lld..%lld)", (long long)first_real, (long long)(first_real + nreals - 1),
+                (long long)h->path_base, (long long)(h->path_base + h->npaths - 1));
+    double* zr = so.as<double>();   // realisation-major working field = the output itself
+    {
+      ProfScope ps("sgs_noise", s);
+      hipLaunchKernelGGL(sgs_noise_rows_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real,
+                         N, R, noise ? sn.as<double>() : nullptr, zr);
+      GSS_HIP(hipGetLastError());
+    }
+    if (h->nd > 0) {
+      hipLaunchKernelGGL(sgs_seed_data_rows_kernel, dim3((unsigned)((h->nd * R + 255) / 256)), dim3(256), 0, s,
+                         h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zr);
+      GSS_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps("sgs_sweep", s);
+      hipLaunchKernelGGL(sgs_sweep_paths_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
+                         h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
+                         h->sigma.as<double>(), h->k, N, R, p0, h->mean, zr);
+      GSS_HIP(hipGetLastError());
+    }
+    GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
+    GSS_HIP(hipStreamSynchronize(s));
+    return GSS_OK;
+  }
   // the working field is GBs (8 N R bytes): allocating and freeing it on every call costs more than a short sweep
   if (h->field.bytes < sizeof(double) * (size_t)(N * R)) {
     h->field.release();

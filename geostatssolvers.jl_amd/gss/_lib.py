@@ -75,6 +75,8 @@ SIGNATURES = {
     "gss_lwr_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _i32, _f64, _f64, _p, _p, _p, _i32,
                         _p],
     "gss_sgs_create": [C.POINTER(_p), _VG, _f64, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _f64, _p, _i32, _p],
+    "gss_sgs_create_paths": [C.POINTER(_p), _VG, _f64, _p, _i64, _i32, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _f64, _p,
+                             _i32, _p],
     "gss_sgs_destroy": [_p],
     "gss_sgs_weights": [_p, _p, _p, _p, _p, _i32, _p],
     "gss_sgs_realize": [_p, _u64, _i64, _i64, _p, _p, _i32, _p],

@@ -294,10 +294,13 @@ class LUGSHandle:
 
 
 class SGSHandle:
-    """gss_sgs_t*: neighbour lists, simple-kriging weights and sigmas of every path node in HBM."""
+    """gss_sgs_t*: neighbour lists, simple-kriging weights and sigmas of every path node in HBM.
+
+    `path`: None (LinearPath), a visiting order of N cells shared by every realisation, or an (npaths, N) array with
+    one visiting order per realisation -- row p belongs to realisation `path_base + p` (seq.jl:99-102)."""
 
     def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
-                 radii=None):
+                 radii=None, path_base=0):
         self._l = _lib.lib()
         c = np.ascontiguousarray(centroids, dtype=np.float64)
         if c.ndim == 1:
@@ -305,14 +308,20 @@ class SGSHandle:
         self.N, dim = c.shape
         self.k = int(maxneighbors)
         pa = None if path is None else np.ascontiguousarray(path, dtype=np.int64)
+        npaths = 1
+        if pa is not None and pa.ndim == 2:
+            npaths = pa.shape[0]
+            if pa.shape[1] != self.N:
+                raise ValueError(f"paths must have {self.N} cells each")
         dl = np.ascontiguousarray(dlocs if dlocs is not None else [], dtype=np.int64)
         zd = np.ascontiguousarray(zdata if zdata is not None else [], dtype=np.float64)
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
         v = _vg_struct(vg, dim)
         h = C.c_void_p()
-        check(self._l.gss_sgs_create(C.byref(h), C.byref(v), float(mean), ptr(c), self.N, dim, ptr(pa), ptr(dl),
-                                     ptr(zd), dl.size, self.k, int(minneighbors), r, ptr(ir), 0, current_stream()))
+        check(self._l.gss_sgs_create_paths(C.byref(h), C.byref(v), float(mean), ptr(c), self.N, dim, ptr(pa), npaths,
+                                           int(path_base), ptr(dl), ptr(zd), dl.size, self.k, int(minneighbors), r,
+                                           ptr(ir), 0, current_stream()))
         self._h = h
 
     def close(self):

@@ -650,10 +650,53 @@ class LUGS(_Solver):
 # ------------------------------------------------------------------------------------------
 # SGS
 # ------------------------------------------------------------------------------------------
+SGS_PATHS_PER_HANDLE = 64      # realisations (= visiting orders) per device handle when every realisation has its own
+
+
+class _SGSPlan:
+    """What SGS.preprocess hands to solvesingle / solve for one variable.  A shared visiting order (LinearPath, an
+    explicit order) is one device handle: stage A once, lanes = realisations.  `path=("random", seed)` is a RandomPath:
+    the reference draws a new permutation in every solvesingle (seq.jl:99-102), so realisation r gets the permutation
+    `default_rng([seed, r])` and the handles are built per block of realisations, on demand."""
+
+    def __init__(self, engine, make_args, N, path_seed=None, order=None):
+        self.engine, self.args, self.N = engine, make_args, N
+        self.path_seed, self.order = path_seed, order
+        self.shared = None
+
+    def path_of(self, r):
+        return np.random.default_rng([int(self.path_seed), int(r)]).permutation(self.N)
+
+    def realize(self, seed, first, count):
+        vg, cent, dlocs, zd, mean, nmax, nmin, radius, radii = self.args
+        if count <= 0:
+            return np.empty((0, self.N))
+        if self.path_seed is None:
+            if self.shared is None:
+                self.shared = self.engine.SGS(vg, cent, self.order, dlocs, zd, mean, nmax, nmin, radius, radii)
+            return self.shared.realize(seed, first, count)
+        out = []
+        for a in range(first, first + count, SGS_PATHS_PER_HANDLE):
+            b = min(a + SGS_PATHS_PER_HANDLE, first + count)
+            paths = np.stack([self.path_of(r) for r in range(a, b)])
+            h = self.engine.SGS(vg, cent, paths, dlocs, zd, mean, nmax, nmin, radius, radii, path_base=a)
+            try:
+                out.append(h.realize(seed, a, b - a))
+            finally:
+                h.close()
+        return np.concatenate(out, axis=0)
+
+    def close(self):
+        if self.shared is not None:
+            self.shared.close()
+            self.shared = None
+
+
 class SGS(_Solver):
-    """sgs.jl:45-89 on top of seq.jl:42-141.  `path` is "linear" (LinearPath), ("random", seed) or an explicit
-    visiting order; every realisation of one solve shares it (the device computes the neighbour lists and
-    simple-kriging weights of the path once and reuses them for all realisations)."""
+    """sgs.jl:45-89 on top of seq.jl:42-141.  `path` is "linear" (LinearPath), an explicit visiting order (shared by
+    every realisation: the device computes the neighbour lists and simple-kriging weights of the path once) or
+    ("random", seed) (RandomPath: a new permutation per realisation, as `traverse` inside the reference's
+    solvesingle gives, seq.jl:99-102)."""
     PARAMS = dict(variogram=GaussianVariogram(), mean=0.0, path="linear", minneighbors=1, maxneighbors=10,
                   neighborhood=None, distance="euclidean")                                     # sgs.jl:45-55
     GLOBALS = dict(init="nearest", rng=None)
@@ -670,12 +713,15 @@ class SGS(_Solver):
             if p["distance"] not in ("euclidean", None):
                 raise NotImplementedError("only the Euclidean search distance is available on the device")
             path = p["path"]
+            order = path_seed = None
             if path is None or (isinstance(path, str) and path == "linear"):
                 order = None
             elif isinstance(path, tuple) and path[0] == "random":
-                order = np.random.default_rng(path[1]).permutation(N)
+                path_seed = int(path[1])
+            elif isinstance(path, str) and path == "multigrid":
+                order = _path_order(path, N, pdom)
             elif isinstance(path, str):
-                raise NotImplementedError(f"path {path!r}: give 'linear', ('random', seed) or a visiting order")
+                raise NotImplementedError(f"path {path!r}: give 'linear', 'multigrid', ('random', seed) or a visiting order")
             else:
                 order = np.asarray(path, dtype=np.int64)
             dlocs, zd = np.empty(0, dtype=np.int64), np.empty(0)
@@ -692,8 +738,8 @@ class SGS(_Solver):
                 zd = np.array([buff[j] for j in dlocs])
             _, nmax = searcher_ui(pdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # seq.jl:65
             radius, radii = _ball(p["neighborhood"])
-            pre[var] = self.engine.SGS(p["variogram"], cent, order, dlocs, zd, float(p["mean"]), nmax,
-                                       p["minneighbors"], radius, radii)
+            pre[var] = _SGSPlan(self.engine, (p["variogram"], cent, dlocs, zd, float(p["mean"]), nmax,
+                                              p["minneighbors"], radius, radii), N, path_seed, order)
         pre["_run"] = _run_state(self, problem)
         return pre
 
@@ -710,10 +756,9 @@ class SGS(_Solver):
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
         reals = {}
         for var in problem.variables:
-            h = pre[var]
-            y = (h.realize(run["seed"] + run["vindex"][var], lo, hi - lo) if hi > lo
-                 else np.empty((0, problem.domain.nelements())))
-            h.close()
+            plan = pre[var]
+            y = plan.realize(run["seed"] + run["vindex"][var], lo, hi - lo)
+            plan.close()
             if gather and ws > 1:
                 y = parallel.all_gather_concat(y, problem.nreals)
             reals[var] = [y[r] for r in range(y.shape[0])]

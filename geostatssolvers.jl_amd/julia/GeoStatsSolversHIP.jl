@@ -588,6 +588,8 @@ end
   @global rng = Random.GLOBAL_RNG      # sgs.jl:54
 end
 
+const SGS_PATHS_PER_HANDLE = 64   # visiting orders per device handle when every realisation has its own
+
 function preprocess(problem::SimulationProblem, solver::SGSHIP)
   pdomain = domain(problem)
   buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # seq.jl:85
@@ -597,7 +599,6 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
   for covars in covariables(problem, solver), var in covars.names
     p = covars.params[Set([var])]
     p.distance isa Euclidean || throw(ArgumentError("SGSHIP: only the Euclidean search distance is available"))
-    path = Int64.(collect(traverse(pdomain, p.path)) .- 1)               # one visiting order per preprocess
     dlocs = Int64.(findall(mask[var]) .- 1)
     zdata = Float64.(buff[var][mask[var]])
     k = p.maxneighbors
@@ -606,26 +607,54 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
       k = N
     end
     radius, ir = ballspec(p.neighborhood)
-    vg = Ref(cvariogram(p.variogram, d))
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve C path dlocs zdata ir check(ccall((:gss_sgs_create, libgss), Int32,
-      (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Float64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
-       Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
-      h, vg, Float64(p.mean), C, N, Int32(d), path, dlocs, zdata, length(dlocs), Int32(k), Int32(p.minneighbors),
-      radius, ir, Int32(0), C_NULL))
-    preproc[var] = (handle=Handle(h[], :sgs), N=N)
+    # the device state is built per block of realisations in sgs_block: `traverse` is called once per realisation,
+    # as the reference does inside solvesingle (seq.jl:99-102), so a RandomPath gives every realisation its own order
+    preproc[var] = (pdomain=pdomain, path=p.path, C=C, N=N, d=d, dlocs=dlocs, zdata=zdata, k=Int32(k),
+                    minneighbors=Int32(p.minneighbors), radius=radius, ir=ir, vg=cvariogram(p.variogram, d),
+                    mean=Float64(p.mean), shared=Ref{Union{Nothing,Handle}}(nothing))
   end
   preproc[:_run] = RunState(problem, solver)
   preproc
 end
 
-function sgs_block(preproc, var, first::Int, count::Int)
-  par = preproc[var]
-  out = Matrix{Float64}(undef, par.N, count)
-  count == 0 && return out
+function sgs_handle(par, paths::Matrix{Int64}, base::Int)
+  vg = Ref(par.vg)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  C, dlocs, zdata, ir = par.C, par.dlocs, par.zdata, par.ir
+  GC.@preserve C paths dlocs zdata ir check(ccall((:gss_sgs_create_paths, libgss), Int32,
+    (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Float64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Int64, Int64, Ptr{Int64},
+     Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
+    h, vg, par.mean, C, par.N, Int32(par.d), paths, size(paths, 2), Int64(base), dlocs, zdata, length(dlocs), par.k,
+    par.minneighbors, par.radius, ir, Int32(0), C_NULL))
+  Handle(h[], :sgs)
+end
+
+function sgs_realize!(out, handle, seed, first::Int, count::Int)
   GC.@preserve out check(ccall((:gss_sgs_realize, libgss), Int32,
     (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Cvoid}),
-    par.handle, varseed(preproc[:_run], var), Int64(first), Int64(count), C_NULL, out, GSS_MEM_HOST, C_NULL))
+    handle, seed, Int64(first), Int64(count), C_NULL, out, GSS_MEM_HOST, C_NULL))
+  out
+end
+
+# realisations first .. first+count-1 (N x count)
+function sgs_block(preproc, var, first::Int, count::Int)
+  par = preproc[var]
+  seed = varseed(preproc[:_run], var)
+  out = Matrix{Float64}(undef, par.N, count)
+  count == 0 && return out
+  if par.path isa LinearPath                      # the same order for every realisation: one handle, lanes = realisations
+    if isnothing(par.shared[])
+      par.shared[] = sgs_handle(par, reshape(Int64.(collect(traverse(par.pdomain, par.path)) .- 1), par.N, 1), 0)
+    end
+    return sgs_realize!(out, par.shared[], seed, first, count)
+  end
+  for a in first:SGS_PATHS_PER_HANDLE:(first + count - 1)
+    b = min(a + SGS_PATHS_PER_HANDLE, first + count)
+    paths = reduce(hcat, [Int64.(collect(traverse(par.pdomain, par.path)) .- 1) for _ in a:(b - 1)])   # seq.jl:102
+    h = sgs_handle(par, paths, a)
+    sgs_realize!(view(out, :, (a - first + 1):(b - first)), h, seed, a, b - a)
+    destroy!(h)
+  end
   out
 end
 
@@ -639,9 +668,9 @@ function solve(problem::SimulationProblem, solver::SGSHIP; procs=[myid()])
   preproc = preprocess(problem, solver)
   reals = Dict{Symbol,Vector{Vector{Float64}}}()
   for covars in covariables(problem, solver), var in covars.names
-    Z = sgs_block(preproc, var, 0, nreals(problem))                      # lanes = realisations: one sweep for all
+    Z = sgs_block(preproc, var, 0, nreals(problem))
     reals[var] = [Z[:, r] for r in 1:nreals(problem)]
-    destroy!(preproc[var].handle)
+    isnothing(preproc[var].shared[]) || destroy!(preproc[var].shared[])
   end
   ensemble(problem, reals)
 end

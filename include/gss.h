@@ -283,6 +283,16 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
                        int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
                        int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
                        int32_t flags, void* stream);
+/* One visiting order per realisation -- what the reference does for a RandomPath, whose `traverse` is called inside
+ * solvesingle (seq.jl:99-102): paths = npaths x N cell indices, path p belongs to realisation path_base + p; stage A
+ * (search, fit, weights) runs once per path and gss_sgs_realize(first_real, nreals) needs
+ * path_base <= first_real and first_real + nreals <= path_base + npaths.  npaths == 1 is gss_sgs_create (every
+ * realisation shares the order, lanes = realisations, about R times faster per realisation). */
+int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids,
+                             int64_t N, int32_t dim, const int64_t* paths, int64_t npaths, int64_t path_base,
+                             const int64_t* dlocs, const double* zdata, int64_t nd, int32_t maxneighbors,
+                             int32_t minneighbors, double radius, const double* inv_radii, int32_t flags,
+                             void* stream);
 int32_t gss_sgs_destroy(gss_sgs_t* h);
 int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, double* sigma, int32_t mem,
                         void* stream);

@@ -102,9 +102,11 @@ class _LUGS:
 
 class _SGS:
     def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
-                 radii=None):
-        self.a = (_ovg(vg), mean, np.asarray(centroids, dtype=np.float64), path, np.asarray(dlocs, dtype=np.int64),
-                  np.asarray(zdata, dtype=np.float64))
+                 radii=None, path_base=0):
+        self.a = (_ovg(vg), mean, np.asarray(centroids, dtype=np.float64))
+        self.path = None if path is None else np.asarray(path, dtype=np.int64)
+        self.path_base = path_base
+        self.d = (np.asarray(dlocs, dtype=np.int64), np.asarray(zdata, dtype=np.float64))
         self.kw = dict(maxneighbors=maxneighbors, minneighbors=minneighbors, radius=radius, radii=radii)
 
     def close(self):
@@ -112,7 +114,10 @@ class _SGS:
 
     def realize(self, seed, first_real, nreals, noise=None):
         from oracle import sgs
-        return sgs.realize(*self.a, seed, first_real, nreals, **self.kw)
+        if self.path is not None and self.path.ndim == 2:      # one visiting order per realisation
+            return np.stack([sgs.realize(*self.a, self.path[first_real + r - self.path_base], *self.d, seed,
+                                         first_real + r, 1, **self.kw)[0] for r in range(nreals)])
+        return sgs.realize(*self.a, self.path, *self.d, seed, first_real, nreals, **self.kw)
 
 
 class OracleEngine:

@@ -125,3 +125,42 @@ def test_solver_through_solve_and_errors():
         SGSHandle(gss.SphericalVariogram(range=35.0), cent, None, None, None, 0.0, 65)
     with pytest.raises(_lib.GSSError, match="not a permutation"):
         SGSHandle(gss.SphericalVariogram(range=35.0), cent[:10], np.zeros(10, dtype=np.int64), None, None, 0.0, 3)
+
+
+def test_one_visiting_order_per_realisation_matches_oracle(monkeypatch):
+    """RandomPath semantics (seq.jl:99-102: `traverse` runs inside solvesingle, so every realisation walks its own
+    permutation): gss_sgs_create_paths runs stage A once per path and the sweep gives each realisation a lane of its
+    own.  Oracle = the reference's loop with that realisation's path.  Through the handle, through `solve` with
+    path=("random", seed) and across handle boundaries (blocks of realisations)."""
+    import gss
+    from gss.engine import SGSHandle
+    from gss import solvers
+    gvg, ovg = _vg("spherical", range=7.0, sill=1.3, nugget=0.05)
+    cent = offt.grid_centroids((18, 13))
+    N = cent.shape[0]
+    rng = np.random.default_rng(3)
+    dl = np.sort(rng.choice(N, 9, replace=False))
+    zd = rng.normal(size=9)
+    paths = np.stack([np.random.default_rng([5, r]).permutation(N) for r in range(4, 9)])
+    h = SGSHandle(gvg, cent, paths, dl, zd, 0.4, 7, 1, path_base=4)
+    z = h.realize(21, 5, 3)                                   # realisations 5, 6, 7 <-> rows 1, 2, 3
+    with pytest.raises(Exception, match="no visiting order"):
+        h.realize(21, 8, 2)
+    h.close()
+    for i, r in enumerate((5, 6, 7)):
+        ref = S.realize(ovg, 0.4, cent, paths[r - 4], dl, zd, 21, r, 1, maxneighbors=7)[0]
+        assert np.max(np.abs(z[i] - ref)) < 1e-9 and np.array_equal(z[i][dl], zd)
+    # solver front-end, blocks of two realisations per handle
+    monkeypatch.setattr(solvers, "SGS_PATHS_PER_HANDLE", 2)
+    grid = gss.CartesianGrid(18, 13)
+    data = gss.georef({"z": zd[:3]}, cent[dl[:3]])
+    sol = gss.solve(gss.SimulationProblem(data, grid, "z", 5),
+                    gss.SGS(("z", dict(variogram=gvg, mean=0.4, path=("random", 5), maxneighbors=7)), rng=21))
+    loop = gss.simulate_with_generic_loop(gss.SimulationProblem(data, grid, "z", 5),
+                                          gss.SGS(("z", dict(variogram=gvg, mean=0.4, path=("random", 5), maxneighbors=7)),
+                                                  rng=21))
+    for r in range(5):
+        ref = S.realize(ovg, 0.4, cent, np.random.default_rng([5, r]).permutation(N), dl[:3], zd[:3], 21, r, 1,
+                        maxneighbors=7)[0]
+        assert np.max(np.abs(sol["z"][r] - ref)) < 1e-9 and np.array_equal(sol["z"][r], loop["z"][r])
+    assert np.max(np.abs(sol["z"][0] - sol["z"][1])) > 1e-3

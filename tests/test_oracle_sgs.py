@@ -71,5 +71,19 @@ def test_sgs_solver_through_solve_with_stand_in():
     with pytest.raises(ValueError):
         gss.SGS(("z", dict(nope=1)))
     with pytest.raises(NotImplementedError):
-        gss.solve(gss.SimulationProblem(grid, {"z": float}, 1), gss.SGS(("z", dict(path="multigrid")),
+        gss.solve(gss.SimulationProblem(grid, {"z": float}, 1), gss.SGS(("z", dict(path="source")),
                                                                         engine=OracleEngine))
+    # RandomPath: every realisation walks its own permutation (seq.jl:99-102 calls traverse inside solvesingle)
+    sol_r = gss.solve(gss.SimulationProblem(data, grid, "z", 3),
+                      gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=8.0), path=("random", 3), maxneighbors=5)),
+                              rng=11, engine=OracleEngine))
+    from oracle import sgs as osgs
+    from oracle.variogram import Variogram
+    N = cent.shape[0]
+    dl = np.array(sorted(int(np.argmin(((cent - np.array(p)) ** 2).sum(1))) for p in [(5.2, 4.9), (10.0, 12.0), (15.7, 7.5)]))
+    zd = np.array([{int(np.argmin(((cent - np.array(p)) ** 2).sum(1))): v
+                    for p, v in zip([(5.2, 4.9), (10.0, 12.0), (15.7, 7.5)], [1.0, 0.0, 1.0])}[j] for j in dl])
+    for r in range(3):
+        path = np.random.default_rng([3, r]).permutation(N)
+        ref = osgs.realize(Variogram("spherical", range=8.0), 0.0, cent, path, dl, zd, 11, r, 1, maxneighbors=5)[0]
+        assert np.array_equal(sol_r["z"][r], ref)

@@ -94,8 +94,11 @@ def test_product_library_host_side_under_asan_ubsan():
         lib.gss_profile_reset(); lib.gss_shutdown()
         print("asan-ok")
     """
-    r = _run(code, CLANG_RT, {"LD_LIBRARY_PATH": os.path.dirname(CLANG_RT) + os.pathsep + "/opt/rocm/lib" + os.pathsep +
-                              os.environ.get("LD_LIBRARY_PATH", "")})
+    try:
+        r = _run(code, CLANG_RT, {"LD_LIBRARY_PATH": os.path.dirname(CLANG_RT) + os.pathsep + "/opt/rocm/lib" + os.pathsep +
+                                  os.environ.get("LD_LIBRARY_PATH", "")})
+    finally:   # 23 MB of instrumented objects: not worth shipping to the GPU box with every gpurun snapshot
+        subprocess.call(["make", "-s", "-C", CSRC, "clean-asan"])
     _clean(r)
     assert "asan-ok" in r.stdout
 
@@ -130,6 +133,12 @@ def test_oracle_c_restatement_under_asan_ubsan():
                         assert np.max(np.abs(mu - rmu)) < 1e-6 and np.max(np.abs(var - rvar)) < 1e-6, (kind, dim, variant)
         print("asan-ok")
     """
-    r = _run(code, gcc_asan)
+    try:
+        r = _run(code, gcc_asan)
+    finally:
+        try:
+            os.remove(os.path.join(ROOT, "oracle", "libkrig_oracle_asan.so"))
+        except OSError:
+            pass
     _clean(r)
     assert "asan-ok" in r.stdout
