@@ -144,6 +144,9 @@ int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double
  * (krig.jl:176): it uploads the non-missing samples and, unless GSS_KRIG_NO_FACTOR is set,
  * factorises the (n+nc)^2 kriging system on the device.
  *   xdata n x d point-major, z n values, drift_data n x ndrift (EXTDRIFT only, row per point).
+ *   xdata, z and drift_data are HOST arrays (the preprocess of krig.jl:76-128 is host logic: the library reads the
+ *   coordinates for the drift centring / scaling and the search index, then uploads them); only the predict calls
+ *   take `mem`.
  */
 enum { GSS_KRIG_NO_FACTOR = 1 /* moving-neighbourhood use only, or factor arrives by broadcast */ };
 
