@@ -59,9 +59,11 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double*
                                                          const int* __restrict__ rank, int64_t N, int k,
                                                          int minneighbors, const int* __restrict__ idx,
                                                          const int* __restrict__ count, int* __restrict__ ncond,
-                                                         double* __restrict__ w_out, double* __restrict__ sigma_out) {
+                                                         double* __restrict__ w_out, double* __restrict__ sigma_out,
+                                                         int* __restrict__ idx_rw, int filter_after) {
   __shared__ double Lp[SGS_MAX_K * (SGS_MAX_K + 1) / 2];
   __shared__ double nx[SGS_MAX_K][3];
+  __shared__ int cidx[SGS_MAX_K];
   const int64_t p = blockIdx.x;
   const int lane = threadIdx.x;
   if (rank[p] < 0) {  // data cell: never simulated (seq.jl:103)
@@ -71,7 +73,20 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double*
     }
     return;
   }
-  const int cnt = count[p];
+  int cnt = count[p];
+  if (filter_after) {
+    // the search was NOT masked: of the k nearest cells (the node itself included) keep, in order, those already
+    // simulated when the node is visited (data cells have rank -1) -- `mask=simulated` applied after the search
+    const bool in = lane < cnt;
+    const int nb = in ? idx[p * k + lane] : 0;
+    const bool keep = in && rank[nb] < rank[p];
+    const unsigned long long bm = __ballot(keep);
+    if (keep) cidx[__popcll(bm & ((1ull << lane) - 1ull))] = nb;
+    __syncthreads();
+    cnt = __popcll(bm);
+    if (lane < k) idx_rw[p * k + lane] = lane < cnt ? cidx[lane] : -1;
+    __syncthreads();
+  }
   const double smarg = sqrt(vg.sill);  // sgs.jl:66
   if (cnt < minneighbors || cnt <= 0) {  // seq.jl:107-109
     if (lane == 0) {
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double*
 #pragma unroll
   for (int a = 0; a < DIM; ++a) c0[a] = cent[p * DIM + a];
   const bool act = lane < cnt;
-  const int nj = act ? idx[p * k + lane] : 0;
+  const int nj = act ? (filter_after ? cidx[lane] : idx[p * k + lane]) : 0;
 #pragma unroll
   for (int a = 0; a < DIM; ++a) {
     xj[a] = act ? cent[(int64_t)nj * DIM + a] : 0.0;
@@ -327,6 +342,7 @@ struct gss_sgs {
   int dim = 0, k = 0;
   int64_t N = 0, nd = 0;
   double mean = 0.0;
+  int filter_after = 0;   // GSS_SGS_MASK_AFTER_SEARCH
   int64_t npaths = 1, path_base = 0;  // npaths > 1: one visiting order per realisation, path p <-> realisation path_base + p
   DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;   // per path: N entries (path, rank, ncond, sigma), N k (idx, w)
   DevBuf field;  // node-major [N][R] working field of gss_sgs_realize, kept between calls (grows to the largest R seen)
@@ -349,7 +365,6 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
               "ui.jl:18-20)", maxneighbors, (long long)N);
   GSS_REQUIRE(maxneighbors <= SGS_MAX_K, "maxneighbors = %d: the neighbour kernels hold at most %d neighbours",
               maxneighbors, SGS_MAX_K);
-  (void)flags;
   hipStream_t s = to_stream(stream);
   auto* h = new gss_sgs();
   struct Guard {
@@ -366,6 +381,7 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   h->mean = mean;
   h->npaths = npaths;
   h->path_base = path_base;
+  h->filter_after = (flags & GSS_SGS_MASK_AFTER_SEARCH) ? 1 : 0;
   const int64_t P = npaths;
 
   // visiting rank of every cell (-1 = conditioning cell) per path; each path must be a permutation of 0..N-1
@@ -410,6 +426,7 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   if (N >= KNN_DEVICE_BUILD_MIN) GSS_TRY(knn_index_build_device(cent.as<double>(), N, dim, &ix, s));  // already in HBM
   else GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
   GSS_TRY(bmin.alloc(sizeof(int) * (size_t)ix.nb));
+  DevBuf rawidx;   // GSS_SGS_MASK_AFTER_SEARCH: the unmasked neighbour lists, shared by every path
   for (int64_t pp = 0; pp < P; ++pp) {   // stage A once per visiting order
     int* rk = h->rank.as<int>() + pp * N;
     int* idxp = h->idx.as<int>() + pp * N * h->k;
@@ -418,13 +435,22 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
     GSS_HIP(hipGetLastError());
     {
       ProfScope ps("sgs_search", s);
-      GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
-                                 bmin.as<int>()));
+      if (h->filter_after) {   // one unmasked search serves every path: k nearest cells of the whole domain
+        if (pp == 0) {
+          GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
+          GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s));
+        }
+      } else {
+        GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
+                                   bmin.as<int>()));
+      }
     }
     {
       ProfScope ps("sgs_weights", s);
-#define GSS_SGS_ARGS h->vg, cent.as<double>(), rk, N, h->k, minneighbors, idxp, cnt.as<int>(), \
-                     h->ncond.as<int>() + pp * N, h->w.as<double>() + pp * N * h->k, h->sigma.as<double>() + pp * N
+#define GSS_SGS_ARGS h->vg, cent.as<double>(), rk, N, h->k, minneighbors, \
+                     (h->filter_after ? rawidx.as<int>() : idxp), cnt.as<int>(), \
+                     h->ncond.as<int>() + pp * N, h->w.as<double>() + pp * N * h->k, h->sigma.as<double>() + pp * N, \
+                     idxp, h->filter_after
       switch (dim) {
         case 1: hipLaunchKernelGGL((sgs_weights_kernel<1>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
         case 2: hipLaunchKernelGGL((sgs_weights_kernel<2>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;

@@ -26,6 +26,7 @@ KRIG_NO_FACTOR = 1
 FFTGS_NO_SPECTRUM = 1
 LUGS_NO_FACTOR = 1
 LUGS_FACT_LU = 2
+SGS_MASK_AFTER_SEARCH = 1
 
 
 class GSSError(RuntimeError):

@@ -26,7 +26,7 @@ from .geo import Ensemble, GeoTable, PointSet, georef, parent, parentindices
 from .problems import EstimationProblem, SimulationProblem
 from .variograms import GaussianVariogram, MetricBall
 
-_GLOBAL_KEYS = {"rng", "threads", "init", "engine", "share"}
+_GLOBAL_KEYS = {"rng", "threads", "init", "engine", "share", "mask"}
 
 
 class _Solver:
@@ -659,9 +659,10 @@ class _SGSPlan:
     the reference draws a new permutation in every solvesingle (seq.jl:99-102), so realisation r gets the permutation
     `default_rng([seed, r])` and the handles are built per block of realisations, on demand."""
 
-    def __init__(self, engine, make_args, N, path_seed=None, order=None):
+    def __init__(self, engine, make_args, N, path_seed=None, order=None, mask_after=True):
         self.engine, self.args, self.N = engine, make_args, N
         self.path_seed, self.order = path_seed, order
+        self.kw = dict(mask_after_search=True) if mask_after else {}
         self.shared = None
 
     def path_of(self, r):
@@ -673,13 +674,13 @@ class _SGSPlan:
             return np.empty((0, self.N))
         if self.path_seed is None:
             if self.shared is None:
-                self.shared = self.engine.SGS(vg, cent, self.order, dlocs, zd, mean, nmax, nmin, radius, radii)
+                self.shared = self.engine.SGS(vg, cent, self.order, dlocs, zd, mean, nmax, nmin, radius, radii, **self.kw)
             return self.shared.realize(seed, first, count)
         out = []
         for a in range(first, first + count, SGS_PATHS_PER_HANDLE):
             b = min(a + SGS_PATHS_PER_HANDLE, first + count)
             paths = np.stack([self.path_of(r) for r in range(a, b)])
-            h = self.engine.SGS(vg, cent, paths, dlocs, zd, mean, nmax, nmin, radius, radii, path_base=a)
+            h = self.engine.SGS(vg, cent, paths, dlocs, zd, mean, nmax, nmin, radius, radii, path_base=a, **self.kw)
             try:
                 out.append(h.realize(seed, a, b - a))
             finally:
@@ -696,10 +697,13 @@ class SGS(_Solver):
     """sgs.jl:45-89 on top of seq.jl:42-141.  `path` is "linear" (LinearPath), an explicit visiting order (shared by
     every realisation: the device computes the neighbour lists and simple-kriging weights of the path once) or
     ("random", seed) (RandomPath: a new permutation per realisation, as `traverse` inside the reference's
-    solvesingle gives, seq.jl:99-102)."""
+    solvesingle gives, seq.jl:99-102).
+    Global `mask`: how `search!(..., mask=simulated)` (seq.jl:105) is read -- "after" (default): the searcher returns its
+    k nearest cells of the whole domain and the mask keeps the simulated ones ([DEP] Meshes' KNearestSearch / KBallSearch
+    as recalled; unverifiable here); "during": the k nearest among the simulated cells."""
     PARAMS = dict(variogram=GaussianVariogram(), mean=0.0, path="linear", minneighbors=1, maxneighbors=10,
                   neighborhood=None, distance="euclidean")                                     # sgs.jl:45-55
-    GLOBALS = dict(init="nearest", rng=None)
+    GLOBALS = dict(init="nearest", rng=None, mask="after")
 
     def preprocess(self, problem: SimulationProblem):
         pdom = problem.domain
@@ -738,8 +742,11 @@ class SGS(_Solver):
                 zd = np.array([buff[j] for j in dlocs])
             _, nmax = searcher_ui(pdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # seq.jl:65
             radius, radii = _ball(p["neighborhood"])
+            mask = self.globals.get("mask", "after")
+            if mask not in ("after", "during"):
+                raise ValueError(f"mask={mask!r}: 'after' or 'during'")
             pre[var] = _SGSPlan(self.engine, (p["variogram"], cent, dlocs, zd, float(p["mean"]), nmax,
-                                              p["minneighbors"], radius, radii), N, path_seed, order)
+                                              p["minneighbors"], radius, radii), N, path_seed, order, mask == "after")
         pre["_run"] = _run_state(self, problem)
         return pre
 

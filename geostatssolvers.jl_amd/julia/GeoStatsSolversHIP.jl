@@ -40,6 +40,7 @@ const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 const GSS_MEM_HOST = Int32(0)
 const GSS_KRIG_NO_FACTOR = Int32(1)
 const GSS_LUGS_FACT_LU = Int32(2)
+const GSS_SGS_MASK_AFTER_SEARCH = Int32(1)
 
 # ---- units (src/utils.jl:5-15): affine units are made absolute before the values are stripped for the device;
 #      estimates get the unit back, variances its square (krig.jl:94,160; idw.jl:109; lwr.jl:112,153) --------------
@@ -625,7 +626,7 @@ function sgs_handle(par, paths::Matrix{Int64}, base::Int)
     (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Float64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Int64, Int64, Ptr{Int64},
      Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
     h, vg, par.mean, C, par.N, Int32(par.d), paths, size(paths, 2), Int64(base), dlocs, zdata, length(dlocs), par.k,
-    par.minneighbors, par.radius, ir, Int32(0), C_NULL))
+    par.minneighbors, par.radius, ir, GSS_SGS_MASK_AFTER_SEARCH, C_NULL))   # search!(...; mask=simulated): mask after the query
   Handle(h[], :sgs)
 end
 

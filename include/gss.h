@@ -282,6 +282,11 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
  *   (8 N nreals bytes for the largest nreals seen) until gss_sgs_destroy.
  * gss_sgs_weights (test support): per node the neighbour list (N x k), the number of conditioning
  *   neighbours actually used (0 = marginal or data cell), the weights (N x k) and sigma (N). */
+/* flags: how `search!(neighbors, p, searcher, mask=simulated)` (seq.jl:105) treats the mask.  0: the k nearest AMONG the
+ * already simulated cells.  GSS_SGS_MASK_AFTER_SEARCH: the k nearest cells of the whole domain (the node itself
+ * included), of which the already simulated ones are kept -- what [DEP] Meshes' KNearestSearch / KBallSearch are recalled
+ * to do (the mask is applied to the result of the tree query); the front-ends pass it by default. */
+enum { GSS_SGS_MASK_AFTER_SEARCH = 1 };
 int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
                        int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
                        int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,

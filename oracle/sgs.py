@@ -23,8 +23,11 @@ from .variogram import cov_pairwise
 
 def solvesingle(vg, mean: float, cent: np.ndarray, path: np.ndarray, dlocs: np.ndarray, zdata: np.ndarray,
                 eps: np.ndarray, maxneighbors: int = 10, minneighbors: int = 1, radius: Optional[float] = None,
-                radii: Optional[Sequence[float]] = None) -> np.ndarray:
-    """seq.jl:76-141 for one realisation; `eps[cell]` is the standard normal consumed at that cell."""
+                radii: Optional[Sequence[float]] = None, mask_after_search: bool = False) -> np.ndarray:
+    """seq.jl:76-141 for one realisation; `eps[cell]` is the standard normal consumed at that cell.
+    `mask_after_search`: how `search!(neighbors, p, searcher, mask=simulated)` (seq.jl:105) treats the mask -- False: the k
+    nearest among the simulated cells; True: the k nearest cells of the whole domain (p itself included), of which the
+    simulated ones are kept ([DEP] Meshes KNearestSearch / KBallSearch as recalled: the mask filters the tree query)."""
     cent = np.atleast_2d(np.asarray(cent, dtype=np.float64))
     N = cent.shape[0]
     real = np.zeros(N)
@@ -45,12 +48,19 @@ def solvesingle(vg, mean: float, cent: np.ndarray, path: np.ndarray, dlocs: np.n
     for ind in path:                                                        # seq.jl:102
         if simulated[ind]:
             continue
-        cand = np.flatnonzero(simulated)                                    # search!(..., mask=simulated) seq.jl:105
-        d2 = sqdist(cent[cand], cent[ind], inv)
-        order = np.argsort(d2, kind="stable")[:k]                           # (d2, index) ascending
-        if r2 is not None:
-            order = order[d2[order] <= r2]
-        nb = cand[order]
+        if mask_after_search:
+            d2 = sqdist(cent, cent[ind], inv)
+            order = np.argsort(d2, kind="stable")[:k]
+            if r2 is not None:
+                order = order[d2[order] <= r2]
+            nb = order[simulated[order]]
+        else:
+            cand = np.flatnonzero(simulated)                                # search!(..., mask=simulated) seq.jl:105
+            d2 = sqdist(cent[cand], cent[ind], inv)
+            order = np.argsort(d2, kind="stable")[:k]                       # (d2, index) ascending
+            if r2 is not None:
+                order = order[d2[order] <= r2]
+            nb = cand[order]
         if nb.size < minneighbors or nb.size == 0:                          # seq.jl:107-109
             real[ind] = mean + smarg * eps[ind]
         else:

@@ -31,8 +31,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mask_after", [False, True])
 @pytest.mark.parametrize("dims,vgspec,mean,k,nmin,ball,nd,rpath", CASES)
-def test_realisations_match_oracle(dims, vgspec, mean, k, nmin, ball, nd, rpath):
+def test_realisations_match_oracle(dims, vgspec, mean, k, nmin, ball, nd, rpath, mask_after):
+    """Both readings of `search!(..., mask=simulated)` (seq.jl:105): the k nearest among the simulated cells, and the
+    k nearest cells of the whole domain filtered by the mask (GSS_SGS_MASK_AFTER_SEARCH, the front-ends' default)."""
     from gss.engine import SGSHandle
     gvg, ovg = _vg(vgspec[0], **vgspec[1])
     cent = offt.grid_centroids(dims)
@@ -41,9 +44,11 @@ def test_realisations_match_oracle(dims, vgspec, mean, k, nmin, ball, nd, rpath)
     dl = np.sort(rng.choice(N, nd, replace=False)) if nd else np.empty(0, dtype=np.int64)
     zd = rng.normal(size=nd)
     path = rng.permutation(N) if rpath else None
-    h = SGSHandle(gvg, cent, path, dl, zd, mean, k, nmin, ball.get("radius"), ball.get("radii"))
+    h = SGSHandle(gvg, cent, path, dl, zd, mean, k, nmin, ball.get("radius"), ball.get("radii"),
+                  mask_after_search=mask_after)
     z = h.realize(42, 3, 3)
-    ref = S.realize(ovg, mean, cent, path, dl, zd, 42, 3, 3, maxneighbors=k, minneighbors=nmin, **ball)
+    ref = S.realize(ovg, mean, cent, path, dl, zd, 42, 3, 3, maxneighbors=k, minneighbors=nmin,
+                    mask_after_search=mask_after, **ball)
     assert np.max(np.abs(z - ref)) < 1e-9
     if nd:
         assert np.array_equal(z[:, dl], np.tile(zd, (3, 1)))                  # test/simulation/sgs.jl:18-20
@@ -161,6 +166,6 @@ def test_one_visiting_order_per_realisation_matches_oracle(monkeypatch):
                                                   rng=21))
     for r in range(5):
         ref = S.realize(ovg, 0.4, cent, np.random.default_rng([5, r]).permutation(N), dl[:3], zd[:3], 21, r, 1,
-                        maxneighbors=7)[0]
+                        maxneighbors=7, mask_after_search=True)[0]     # front-end default: mask = "after"
         assert np.max(np.abs(sol["z"][r] - ref)) < 1e-9 and np.array_equal(sol["z"][r], loop["z"][r])
     assert np.max(np.abs(sol["z"][0] - sol["z"][1])) > 1e-3

@@ -85,5 +85,12 @@ def test_sgs_solver_through_solve_with_stand_in():
                     for p, v in zip([(5.2, 4.9), (10.0, 12.0), (15.7, 7.5)], [1.0, 0.0, 1.0])}[j] for j in dl])
     for r in range(3):
         path = np.random.default_rng([3, r]).permutation(N)
-        ref = osgs.realize(Variogram("spherical", range=8.0), 0.0, cent, path, dl, zd, 11, r, 1, maxneighbors=5)[0]
+        ref = osgs.realize(Variogram("spherical", range=8.0), 0.0, cent, path, dl, zd, 11, r, 1, maxneighbors=5,
+                           mask_after_search=True)[0]          # the front-end default: mask = "after"
         assert np.array_equal(sol_r["z"][r], ref)
+    sol_d = gss.solve(gss.SimulationProblem(data, grid, "z", 1),
+                      gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=8.0), path=("random", 3), maxneighbors=5)),
+                              rng=11, engine=OracleEngine, mask="during"))
+    ref_d = osgs.realize(Variogram("spherical", range=8.0), 0.0, cent, np.random.default_rng([3, 0]).permutation(N), dl, zd,
+                         11, 0, 1, maxneighbors=5)[0]
+    assert np.array_equal(sol_d["z"][0], ref_d) and not np.array_equal(sol_d["z"][0], sol_r["z"][0])
