@@ -7,6 +7,9 @@
 // factorisations into large-K GEMMs, which is where the MFMA tile kernel is efficient; the leaves
 // (<= 64 x 64) run in one workgroup out of LDS.
 #include "gss_internal.h"
+
+#include <mutex>
+#include <unordered_map>
 #include "mfma_f64.h"
 #include "tile16.h"
 
@@ -531,10 +534,11 @@ constexpr int L128_TILES = 36;  // upper block triangle of 8 x 8
 constexpr size_t L128_LDS_BYTES = sizeof(double) * ((L128_TILES + 16) * 256 + 2 * 16 * 17);
 __host__ __device__ constexpr int tile_id8(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }
 
-__global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restrict__ A, int n, int64_t lda, int row_offset,
-                                                                int* __restrict__ info, double* __restrict__ dinv,
-                                                                int64_t ldd) {
-  extern __shared__ __attribute__((aligned(16))) double sm128[];
+// NW waves share the tile products (8 = two per SIMD: the LDS round trips of one wave hide behind the MFMAs of the other)
+template <int NW>
+__device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int64_t lda, int row_offset,
+                                             int* __restrict__ info, double* __restrict__ dinv, int64_t ldd,
+                                             double* __restrict__ sm128) {
   double* Tl = sm128;                  // 36 tiles: U (upper block triangle), later W below the diagonal
   double* Vl = Tl + L128_TILES * 256;  // V_k = U_kk^-1
   double* VTl = Vl + 8 * 256;          // V_k'
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
     int q = 0;
     for (int I = 0; I < nt; ++I)
       for (int J = I; J < nt; ++J) {
-        if ((q++ & 3) != wave) continue;
+        if ((q++ % NW) != wave) continue;
         d4_t t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
     __syncthreads();
     {
       const d4_t V = ld(Vl, kk);
-      for (int j = kk + 1 + wave; j < nt; j += 4) st(Tl, tile_id8(kk, j), xty(V, ld(Tl, tile_id8(kk, j)), zero4));
+      for (int j = kk + 1 + wave; j < nt; j += NW) st(Tl, tile_id8(kk, j), xty(V, ld(Tl, tile_id8(kk, j)), zero4));
     }
     __syncthreads();
     {
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
         const bool mine_any = true;
         (void)mine_any;
         for (int j = i; j < nt; ++j) {
-          if ((q++ & 3) != wave) continue;
+          if ((q++ % NW) != wave) continue;
           const d4_t N = -ld(Tl, tile_id8(kk, i));
           st(Tl, tile_id8(i, j), xty(N, ld(Tl, tile_id8(kk, j)), ld(Tl, tile_id8(i, j))));
         }
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
     int q = 0;
     for (int I = 0; I < nt; ++I)
       for (int J = I; J < nt; ++J) {
-        if ((q++ & 3) != wave) continue;
+        if ((q++ % NW) != wave) continue;
         const d4_t t = ld(Tl, tile_id8(I, J));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -624,9 +628,9 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
   if (!dinv) return;
   // W = inv(L): W_II = V_I', W_JI = -V_J' sum_{K = I .. J-1} U_KJ' W_KI (J > I); W_KI sits in slot (I, K) once row K is done
   for (int J = 1; J < nt; ++J) {
-    d4_t wreg[2] = {zero4, zero4};
+    d4_t wreg[(7 + NW - 1) / NW];
     int cnt = 0;
-    for (int I = wave; I < J; I += 4) {
+    for (int I = wave; I < J; I += NW) {
       d4_t acc = zero4;
       for (int K = I; K < J; ++K) {
         const d4_t Wki = (K == I) ? ld(VTl, I) : ld(Tl, tile_id8(I, K));
@@ -636,26 +640,290 @@ __global__ __launch_bounds__(256) void potrf_inv_leaf128_kernel(double* __restri
     }
     __syncthreads();  // every wave has read what it needs of column J of U
     cnt = 0;
-    for (int I = wave; I < J; I += 4) st(Tl, tile_id8(I, J), wreg[cnt++]);
+    for (int I = wave; I < J; I += NW) st(Tl, tile_id8(I, J), wreg[cnt++]);
     __syncthreads();
   }
-  // dinv (column-major, leading dimension ldd): the n x n block, zero above the diagonal
+  // dinv (column-major, leading dimension ldd): the n x n block, zero above the diagonal.  The tile element of
+  // (lane = 16 g + c, register r) is (row g + 4 r, column c); read back transposed -- lane (g', c'), register r'
+  // takes (row c', column g' + 4 r') from slot [(c' >> 2) * 64 + (c' & 3) * 16 + g' + 4 r'] -- the lanes run along
+  // the rows of W, so every store instruction writes 128-B column pieces instead of 64 scattered doubles.
   {
     int q = 0;
     for (int I = 0; I < nt; ++I)
       for (int J = 0; J < nt; ++J) {
-        if ((q++ & 3) != wave) continue;
-        d4_t t = zero4;
-        if (J == I) t = ld(VTl, I);
-        else if (J > I) t = ld(Tl, tile_id8(I, J));
+        if ((q++ % NW) != wave) continue;
+        const double* src = (J == I) ? VTl + I * 256 : (J > I ? Tl + tile_id8(I, J) * 256 : nullptr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int wrow = 16 * J + g + 4 * r, wcol = 16 * I + c;
-          if (wrow < n && wcol < n) dinv[wrow + (int64_t)wcol * ldd] = t[r];
+          const int wrow = 16 * J + c, wcol = 16 * I + g + 4 * r;
+          const double v = src ? src[(c >> 2) * 64 + (c & 3) * 16 + g + 4 * r] : 0.0;
+          if (wrow < n && wcol < n) dinv[wrow + (int64_t)wcol * ldd] = v;
         }
       }
   }
 }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void potrf_inv_leaf128_kernel(double* __restrict__ A, int n, int64_t lda, int row_offset,
+                                                                int* __restrict__ info, double* __restrict__ dinv,
+                                                                int64_t ldd) {
+  extern __shared__ __attribute__((aligned(16))) double sm128[];
+  leaf128_body<NW>(A, n, lda, row_offset, info, dinv, ldd, sm128);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Factor and inverse of a block of up to PANEL_MAX rows in ONE launch (the fit at n = 1 000 and every 1 024-column
+// panel of the LUGS factorisations used to be a chain of ~95 dependent launches: 8 leaves of 58 us and ~30 GEMMs of
+// 10-30 us on a few of the 256 CUs each).  A cooperative grid of a few dozen workgroups walks the 128 x 128 block
+// columns; phases are separated by a grid barrier (one agent-scope atomic per workgroup, tools/probe_gridsync.hip):
+//   phase 1   workgroup 0: leaf k (L_kk and W_kk = inv(L_kk), the kernel above as a device function).
+//             every other workgroup meanwhile: the trailing updates of step k-1 that nobody waits for yet
+//             (A_ij -= L_i,k-1 L_j,k-1' for j > k) and T_kj = sum_m L_km W_mj (row k of the inverse before its scaling);
+//   phase 2   L_ik = A_ik W_kk' (i > k) into the scratch P, and W_kj = -W_kk T_kj (j < k);
+//   phase 3   look-ahead: column k+1 alone receives the update of step k (A_i,k+1 -= L_ik L_k+1,k'), P -> A_ik.
+// So the chain between two leaves is two GEMM rounds of one 16 x 16 tile per wave and three barriers; everything
+// else hides behind the leaf.  Work items are single MFMA tiles read straight from global memory (L2): the kernel is
+// latency-bound, its 0.7 GFLOP would take 9 us at the rate of K3.  Tiles are loaded "transposed" (lane c runs along a
+// column: 128-byte pieces), which is the orientation acc + X'Y wants for D = A B' with all three operands coalesced;
+// the one product that is not of that shape (T = L W) reads W tiles with 32-byte pieces.
+constexpr int PANEL_NB = 128;
+constexpr int PANEL_WAVES = 8;
+
+// Tile loads.  Transposed: element (rho, gamma) of the tile <- M(r0 + gamma, c0 + rho) (lane c runs along a column
+// of M); NATURAL: element (rho, gamma) <- M(r0 + rho, c0 + gamma).  r0, c0 and ld are wave-uniform (the wave index
+// goes through readfirstlane), so a tile is four loads from scalar bases with one lane offset per leading dimension,
+// and the sixteen tiles of a product are all in flight before its first MFMA.  No guards: the kernel works on whole
+// tiles (n a multiple of 16, or rows and columns up to the next multiple present in memory and zero).
+template <bool NATURAL>
+__device__ __forceinline__ d4_t tile_ld(const double* __restrict__ M, int ld, int r0, int c0, int g, int c) {
+  d4_t t;
+  const double* __restrict__ Mu = M + (unsigned)(r0 + c0 * ld);
+  const unsigned lo = NATURAL ? (unsigned)(g + c * ld) : (unsigned)(c + g * ld);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = (Mu + (unsigned)(NATURAL ? 4 * r : 4 * r * ld))[lo];
+  return t;
+}
+__device__ __forceinline__ void tile_st(double* __restrict__ M, int ld, int r0, int c0, int g, int c, const d4_t& t) {
+  double* __restrict__ Mu = M + (unsigned)(r0 + c0 * ld);
+  const unsigned lo = (unsigned)(c + g * ld);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) (Mu + (unsigned)(4 * r * ld))[lo] = t[r];
+}
+
+// acc (+/-)= sum over the k-tiles tp_lo .. tp_hi of  X_tp' Y_tp  with X = tile (xr0, xc0 + 16 tp) of MX and Y = tile
+// (yr0, yc0 + 16 tp) of MY (k runs along the columns of both: D = A B' in the transposed tile orientation);
+// YNAT: Y = natural tile (yr0 + 16 tp, yc0) of MY instead (k along its rows: the product T = L W).  All eight
+// k-tiles are loaded (the skipped ones below tp_lo are structural zeros in memory, those above tp_hi repeat tile tp_hi).
+template <bool NEG, bool YNAT>
+__device__ __forceinline__ d4_t tile_dot(d4_t acc, const double* __restrict__ MX, int ldx, int xr0, int xc0,
+                                         const double* __restrict__ MY, int ldy, int yr0, int yc0, int tp_lo, int tp_hi,
+                                         int g, int c) {
+  d4_t X[8], Y[8];
+#pragma unroll
+  for (int tp = 0; tp < 8; ++tp) {
+    const int tq = tp < tp_hi ? tp : tp_hi;  // never beyond the last k-tile that is used (the block may end there)
+    X[tp] = tile_ld<false>(MX, ldx, xr0, xc0 + 16 * tq, g, c);
+    Y[tp] = YNAT ? tile_ld<true>(MY, ldy, yr0 + 16 * tq, yc0, g, c) : tile_ld<false>(MY, ldy, yr0, yc0 + 16 * tq, g, c);
+  }
+#pragma unroll
+  for (int tp = 0; tp < 8; ++tp)
+    if (tp >= tp_lo && tp <= tp_hi) acc = xty(NEG ? -X[tp] : X[tp], Y[tp], acc);
+  return acc;
+}
+
+// bar[0]: arrivals (monotone), bar[1]: set when a wait gave up (every later barrier falls through, the grid drains)
+__device__ __forceinline__ void panel_grid_sync(unsigned* bar, unsigned& epoch, int* info) {
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(&bar[0], 1u);
+    const unsigned target = epoch * gridDim.x;
+    unsigned spins = 0;
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      if (++spins > 4000000u) {
+        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicCAS(info, 0, -1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// lower tiles of a diagonal block, 36 of them: idx -> (ta >= tb)
+__device__ __forceinline__ void lower_tile(int idx, int& ta, int& tb) {
+  tb = 0;
+  int cnt = 8;
+  while (idx >= cnt) {
+    idx -= cnt;
+    ++tb;
+    --cnt;
+  }
+  ta = tb + idx;
+}
+
+// The leading dimensions are re-read through an opaque copy at the top of every phase: otherwise the address
+// arithmetic of all phases is hoisted out of the step loop and stays live across the leaf.
+#define PANEL_OPAQUE_LDS()                                   \
+  int lda = (int)lda_, ldw = (int)ldw_, ldp = ldp_;          \
+  asm volatile("" : "+s"(lda), "+s"(ldw), "+s"(ldp))
+
+// n: rows of the block as the tiles see it (a multiple of 16); nreal <= n: rows of the matrix (the leaf treats the
+// rest of its block as the identity; in memory rows and columns nreal .. n-1 are zeros and stay zeros).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __restrict__ A, int n, int nreal, int64_t lda_,
+                                                                  double* __restrict__ W, int64_t ldw_,
+                                                                  double* __restrict__ scr, int row_offset,
+                                                                  int* __restrict__ info, unsigned* __restrict__ bar) {
+  extern __shared__ __attribute__((aligned(16))) double sm128[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int G = gridDim.x;
+  const int nbk = (n + PANEL_NB - 1) / PANEL_NB;
+  const int ldp_ = nbk * PANEL_NB;
+  double* P = scr;                               // ldp x 128: L_ik of the current step (rows as in the block)
+  double* TT = scr + (int64_t)ldp_ * PANEL_NB;   // ldp x 128: TT(b, a) = T_kj(a, b), b = column in the block
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  unsigned epoch = 0;
+  // GSS_PANEL_TIMES: workgroup 0 stamps every phase boundary (100 MHz counter) behind the barrier words
+  long long* stamps = (bar[2] != 0u && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long long*>(bar + 16) : nullptr;
+  int nstamp = 0;
+  auto stamp = [&] {
+    if (stamps) stamps[nstamp++] = (long long)wall_clock64();
+  };
+  stamp();
+
+  for (int k = 0; k < nbk; ++k) {
+    const int k0 = k * PANEL_NB;
+    // ---------------- phase 1
+    if (blockIdx.x == 0) {
+      const int nk = nreal - k0 < PANEL_NB ? nreal - k0 : PANEL_NB;
+      leaf128_body<NW>(A + k0 + (int64_t)k0 * lda_, nk, lda_, row_offset + k0, info, W + k0 + (int64_t)k0 * ldw_, ldw_,
+                       sm128);
+    } else if (k >= 1) {
+      PANEL_OPAQUE_LDS();
+      const int nw = (G - 1) * NW;
+      int t = (blockIdx.x - 1) * NW + wave, base = 0;
+      const int kc0 = k0 - PANEL_NB;  // column block of step k-1
+      // trailing updates of step k-1 on the columns behind the look-ahead column
+      for (int j = k + 1; j < nbk; ++j)
+        for (int i = j; i < nbk; ++i) {
+          const int ntile = (i == j) ? 36 : 64;
+          for (; t < base + ntile; t += nw) {
+            int ta, tb;
+            if (i == j) lower_tile(t - base, ta, tb);
+            else {
+              ta = (t - base) & 7;
+              tb = (t - base) >> 3;
+            }
+            const int ar = i * PANEL_NB + 16 * ta, br = j * PANEL_NB + 16 * tb;
+            if (ar < n && br < n) {
+              d4_t acc = tile_ld<false>(A, lda, ar, br, g, c);
+              acc = tile_dot<true, false>(acc, A, lda, br, kc0, A, lda, ar, kc0, 0, 7, g, c);
+              tile_st(A, lda, ar, br, g, c, acc);
+            }
+          }
+          base += ntile;
+        }
+      // T_kj (natural orientation: element (a, b)) -> TT(j0 + b, a)
+      for (int j = 0; j < k; ++j) {
+        for (; t < base + 64; t += nw) {
+          const int ta = (t - base) & 7, tb = (t - base) >> 3;
+          const int ar = k0 + 16 * ta, bc = j * PANEL_NB + 16 * tb;
+          if (ar < n) {
+            d4_t acc = zero4;
+            for (int m = j; m < k; ++m)  // W_jj is lower triangular: k-tiles from tb on
+              acc = tile_dot<false, true>(acc, A, lda, ar, m * PANEL_NB, W, ldw, m * PANEL_NB, bc, m == j ? tb : 0, 7, g, c);
+            tile_st(TT, ldp, bc, 16 * ta, g, c, acc);
+          }
+        }
+        base += 64;
+      }
+    }
+    stamp();
+    panel_grid_sync(bar, epoch, info);
+    stamp();
+    // ---------------- phase 2
+    {
+      PANEL_OPAQUE_LDS();
+      const int nw = G * NW;
+      int t = blockIdx.x * NW + wave, base = 0;
+      // L_ik = A_ik W_kk' -> P (block k is a full block here: k < nbk - 1)
+      for (int i = k + 1; i < nbk; ++i) {
+        for (; t < base + 64; t += nw) {
+          const int ta = (t - base) & 7, tb = (t - base) >> 3;
+          const int ar = i * PANEL_NB + 16 * ta;
+          if (ar < n) {
+            const d4_t acc = tile_dot<false, false>(zero4, W, ldw, k0 + 16 * tb, k0, A, lda, ar, k0, 0, tb, g, c);
+            tile_st(P, ldp, ar, 16 * tb, g, c, acc);
+          }
+        }
+        base += 64;
+      }
+      // W_kj = -W_kk T_kj (the k-tiles stop at the row tile: W_kk is lower triangular, so they never leave the block)
+      for (int j = 0; j < k; ++j) {
+        for (; t < base + 64; t += nw) {
+          const int ta = (t - base) & 7, tb = (t - base) >> 3;
+          const int ar = k0 + 16 * ta, bc = j * PANEL_NB + 16 * tb;
+          if (ar < n) {
+            const d4_t acc = tile_dot<true, false>(zero4, TT, ldp, bc, 0, W, ldw, ar, k0, 0, ta, g, c);
+            tile_st(W, ldw, ar, bc, g, c, acc);
+          }
+        }
+        base += 64;
+      }
+    }
+    stamp();
+    if (k == nbk - 1) break;
+    panel_grid_sync(bar, epoch, info);
+    stamp();
+    // ---------------- phase 3
+    {
+      PANEL_OPAQUE_LDS();
+      (void)ldw;
+      const int nw = G * NW;
+      int t = blockIdx.x * NW + wave, base = 0;
+      const int j0 = k0 + PANEL_NB;
+      // look-ahead: column k+1 receives the update of step k (L_.k read from P)
+      for (int i = k + 1; i < nbk; ++i) {
+        const int ntile = (i == k + 1) ? 36 : 64;
+        for (; t < base + ntile; t += nw) {
+          int ta, tb;
+          if (i == k + 1) lower_tile(t - base, ta, tb);
+          else {
+            ta = (t - base) & 7;
+            tb = (t - base) >> 3;
+          }
+          const int ar = i * PANEL_NB + 16 * ta, br = j0 + 16 * tb;
+          if (ar < n && br < n) {
+            d4_t acc = tile_ld<false>(A, lda, ar, br, g, c);
+            acc = tile_dot<true, false>(acc, P, ldp, br, 0, P, ldp, ar, 0, 0, 7, g, c);
+            tile_st(A, lda, ar, br, g, c, acc);
+          }
+        }
+        base += ntile;
+      }
+      // P -> A_ik
+      for (int i = k + 1; i < nbk; ++i) {
+        for (; t < base + 64; t += nw) {
+          const int ta = (t - base) & 7, tb = (t - base) >> 3;
+          const int ar = i * PANEL_NB + 16 * ta;
+          if (ar < n) tile_st(A, lda, ar, k0 + 16 * tb, g, c, tile_ld<false>(P, ldp, ar, 16 * tb, g, c));
+        }
+        base += 64;
+      }
+    }
+    stamp();
+    panel_grid_sync(bar, epoch, info);
+    stamp();
+  }
+}
+#undef PANEL_OPAQUE_LDS
 
 // W = inv(L) for one lower-triangular block (used when no cached inverse exists)
 __global__ __launch_bounds__(64) void trtri_leaf_kernel(const double* __restrict__ L, int n, int64_t ldl,
@@ -802,9 +1070,82 @@ static int32_t copy_block(const double* src, int64_t lds, int64_t m, int64_t n, 
   return GSS_OK;
 }
 
+// barrier words of the panel kernel, one pair per stream (launches on one stream are ordered)
+static unsigned* panel_barrier_words(hipStream_t s) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, unsigned*> words;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = words.find(s);
+  if (it != words.end()) return it->second;
+  unsigned* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+  words.emplace(s, p);
+  return p;
+}
+
+constexpr int64_t PANEL_MIN = 257;
+static int64_t panel_max_rows() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("GSS_PANEL_MAX");  // 0 switches the single-launch panel off
+    return e ? (int64_t)std::atoll(e) : (int64_t)1024;
+  }();
+  return v;
+}
+static int panel_workgroups() {
+  static const int v = [] {
+    const char* e = std::getenv("GSS_PANEL_WGS");
+    int w = e ? std::atoi(e) : 64;
+    return w < 2 ? 2 : (w > 256 ? 256 : w);
+  }();
+  return v;
+}
+static bool use_panel(int64_t n) { return n >= PANEL_MIN && n <= panel_max_rows(); }
+constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets inside the kernel
+
+// scratch of potrf_inverse_f64 (doubles)
+int64_t potrf_inverse_work_doubles(int64_t n) {
+  if (n <= 2 * LEAF) return 0;
+  if (use_panel(n)) return 2 * PANEL_NB * (((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB);
+  const int64_t n1 = split_point(n), n2 = n - n1;
+  const int64_t a = potrf_inverse_work_doubles(n1), b = 2 * n1 * n2 + potrf_inverse_work_doubles(n2);
+  return a > b ? a : b;
+}
+
+// padded16: rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are zero (they stay zero)
 static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw, int64_t n, int64_t row_offset,
-                                 int* d_info, double* scr, bool keep_L, hipStream_t s) {
+                                 int* d_info, double* scr, bool keep_L, hipStream_t s, bool padded16) {
   if (n <= 0) return GSS_OK;
+  if (use_panel(n) && lda < PANEL_MAX_LD && ldw < PANEL_MAX_LD && (n % 16 == 0 || padded16)) {
+    static bool attr = false;
+    if (!attr) {
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_panel_kernel<PANEL_WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
+      attr = true;
+    }
+    unsigned* bar = panel_barrier_words(s);
+    GSS_REQUIRE(bar != nullptr, "potrf_inverse: no memory for the barrier words");
+    static const bool times = std::getenv("GSS_PANEL_TIMES") != nullptr;
+    GSS_HIP(hipMemsetAsync(bar, 0, 16, s));
+    if (times) GSS_HIP(hipMemsetAsync(bar + 2, 1, 1, s));
+    int n16 = (int)((n + 15) / 16 * 16), n32 = (int)n, ro = (int)row_offset;
+    // An ordinary launch: 64 workgroups of a 256-CU device are resident together whenever fewer than four such
+    // kernels run at once (one workgroup per CU: 110 KB of LDS); a cooperative launch would guarantee it but goes
+    // through a queue of its own (12 us of cross-queue hand-over on either side of every launch).  Should the
+    // workgroups ever not all arrive, the barrier gives up after a bounded spin and *d_info becomes -1.
+    hipLaunchKernelGGL(potrf_inv_panel_kernel<PANEL_WAVES>, dim3((unsigned)panel_workgroups()), dim3(64 * PANEL_WAVES),
+                       L128_LDS_BYTES, s, A, n16, n32, lda, W, ldw, scr, ro, d_info, bar);
+    GSS_HIP(hipGetLastError());
+    if (times) {  // debugging aid: phase boundaries as seen by workgroup 0, in microseconds from the start
+      long long st[64] = {0};
+      GSS_HIP(hipStreamSynchronize(s));
+      GSS_HIP(hipMemcpy(st, bar + 16, sizeof(st), hipMemcpyDeviceToHost));
+      const int nb = (int)((n + PANEL_NB - 1) / PANEL_NB), ns = 1 + 6 * nb - 3;
+      fprintf(stderr, "panel n=%d:", n32);
+      for (int i = 1; i < ns && i < 64; ++i) fprintf(stderr, " %.1f", (double)(st[i] - st[0]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+    return GSS_OK;
+  }
   if (n <= LEAF) {
     hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, W,
                        ldw, 0);
@@ -818,11 +1159,11 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
   if (n <= 2 * LEAF && leaf128) {
     static bool attr = false;
     if (!attr) {
-      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_leaf128_kernel),
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_leaf128_kernel<8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
       attr = true;
     }
-    hipLaunchKernelGGL(potrf_inv_leaf128_kernel, dim3(1), dim3(256), L128_LDS_BYTES, s, A, (int)n, lda, (int)row_offset,
+    hipLaunchKernelGGL(potrf_inv_leaf128_kernel<8>, dim3(1), dim3(512), L128_LDS_BYTES, s, A, (int)n, lda, (int)row_offset,
                        d_info, W, ldw);
     GSS_HIP(hipGetLastError());
     return GSS_OK;
@@ -832,23 +1173,24 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
   double* A22 = A + n1 + n1 * lda;
   double* W21 = W + n1;
   double* W22 = W + n1 + n1 * ldw;
-  GSS_TRY(potrf_inverse_rec(A, lda, W, ldw, n1, row_offset, d_info, scr, keep_L, s));
+  GSS_TRY(potrf_inverse_rec(A, lda, W, ldw, n1, row_offset, d_info, scr, keep_L, s, false));
   double* L21 = scr;            // n2 x n1, column-major, ld n2
   double* T2 = scr + n1 * n2;   // n2 x n1
   double* rest = T2 + n1 * n2;
   GSS_TRY(gemm_f64(n2, n1, n1, 1.0, A21, 1, lda, W, ldw, 1, 0.0, L21, 1, n2, false, s, GEMM_TRI_B_UPPER));
   if (keep_L) GSS_TRY(copy_block(L21, n2, n2, n1, A21, lda, s));
   GSS_TRY(gemm_f64(n2, n2, n1, -1.0, L21, 1, n2, L21, n2, 1, 1.0, A22, 1, lda, true, s));
-  GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, keep_L, s));
+  GSS_TRY(potrf_inverse_rec(A22, lda, W22, ldw, n2, row_offset + n1, d_info, rest, keep_L, s, padded16));
   GSS_TRY(gemm_f64(n2, n1, n1, 1.0, L21, 1, n2, W, 1, ldw, 0.0, T2, 1, n2, false, s, GEMM_TRI_B_LOWER));
   GSS_TRY(gemm_f64(n2, n1, n2, -1.0, W22, 1, ldw, T2, 1, n2, 0.0, W21, 1, ldw, false, s, GEMM_TRI_A_LOWER));
   return GSS_OK;
 }
 
 int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,
-                          bool keep_L, hipStream_t s) {
+                          bool keep_L, hipStream_t s, bool padded16) {
   GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
-  return potrf_inverse_rec(A, lda, W, ldw, n, 0, d_info, scr, keep_L, s);
+  const int64_t n16 = (n + 15) / 16 * 16;
+  return potrf_inverse_rec(A, lda, W, ldw, n, 0, d_info, scr, keep_L, s, padded16 && lda >= n16 && ldw >= n16);
 }
 
 // Right-looking Cholesky by panels of POTRF_PANEL columns for large blocks whose inverse is not wanted (LUGS): the
@@ -859,21 +1201,23 @@ constexpr int64_t POTRF_PANEL = 1024;
 
 int64_t potrf_blocked_work_doubles(int64_t n) {
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
-  return 2 * B * B + n * B;
+  const int64_t w = potrf_inverse_work_doubles(B);
+  return B * B + (w > B * B ? w : B * B) + n * B;
 }
 
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
   double* Wk = work;           // B x B inverse of the diagonal block
-  double* scr = Wk + B * B;    // B x B scratch of the recursion
-  double* P = scr + B * B;     // (n - k0 - nb) x nb panel
+  double* scr = Wk + B * B;    // scratch of the factor-and-inverse step (at least B x B)
+  const int64_t wscr = potrf_inverse_work_doubles(B);
+  double* P = scr + (wscr > B * B ? wscr : B * B);     // (n - k0 - nb) x nb panel
   for (int64_t k0 = 0; k0 < n; k0 += B) {
     const int64_t nb = (n - k0) < B ? (n - k0) : B;
     const int64_t m2 = n - k0 - nb;
     double* Akk = A + k0 + k0 * lda;
     GSS_TRY(dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s));
-    GSS_TRY(potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s));
+    GSS_TRY(potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s, false));
     if (m2 > 0) {
       double* Ap = Akk + nb;                 // rows below the diagonal block
       double* A22 = Akk + nb + nb * lda;
@@ -901,6 +1245,50 @@ int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream) {
   int h = 0;
   GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
+  if (h != 0) {
+    set_error("Cholesky failed: non-positive pivot at row %d", h - 1);
+    return GSS_ERR_NOT_POSDEF;
+  }
+  return GSS_OK;
+}
+
+int32_t gss_dev_potrf_inverse(double* a, int64_t n, int64_t lda, double* w, int64_t ldw, void* stream) {
+  GSS_REQUIRE(a != nullptr && w != nullptr && n >= 0 && lda >= n && ldw >= n, "gss_dev_potrf_inverse: bad arguments");
+  if (n == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  DevBuf info, scr, pad;
+  GSS_TRY(info.alloc(sizeof(int)));
+  const int64_t ws = potrf_inverse_work_doubles(n) > n * n ? potrf_inverse_work_doubles(n) : n * n;
+  GSS_TRY(scr.alloc(sizeof(double) * (size_t)ws));
+  // a size that is not a multiple of 16 goes through zero-padded copies (what gss_krig_fit's own buffers are)
+  const int64_t n16 = (n + 15) / 16 * 16;
+  double *A = a, *W = w;
+  int64_t la = lda, lw = ldw;
+  if (n16 != n) {
+    GSS_TRY(pad.alloc(sizeof(double) * (size_t)(2 * n16 * n16)));
+    GSS_TRY(dev_zero_bytes(pad.p, pad.bytes, s));
+    A = pad.as<double>();
+    W = A + n16 * n16;
+    la = lw = n16;
+    GSS_HIP(hipMemcpy2DAsync(A, sizeof(double) * la, a, sizeof(double) * lda, sizeof(double) * n, n,
+                             hipMemcpyDeviceToDevice, s));
+  } else {
+    GSS_HIP(hipMemset2DAsync(w, sizeof(double) * ldw, 0, sizeof(double) * n, n, s));
+  }
+  GSS_TRY(potrf_inverse_f64(A, n, la, W, lw, scr.as<double>(), info.as<int>(), true, s, n16 != n));
+  if (n16 != n) {
+    GSS_HIP(hipMemcpy2DAsync(a, sizeof(double) * lda, A, sizeof(double) * la, sizeof(double) * n, n,
+                             hipMemcpyDeviceToDevice, s));
+    GSS_HIP(hipMemcpy2DAsync(w, sizeof(double) * ldw, W, sizeof(double) * lw, sizeof(double) * n, n,
+                             hipMemcpyDeviceToDevice, s));
+  }
+  int h = 0;
+  GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  if (h < 0) {
+    set_error("factor and inverse: the kernel gave up waiting at a grid barrier");
+    return GSS_ERR_HIP;
+  }
   if (h != 0) {
     set_error("Cholesky failed: non-positive pivot at row %d", h - 1);
     return GSS_ERR_NOT_POSDEF;

@@ -660,10 +660,13 @@ int32_t gemv_f64(bool trans, int64_t m, int64_t n, const double* A, int64_t lda,
 int64_t potrf_dinv_doubles(int64_t n);
 int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, hipStream_t s);
 // Factor and inverse together (A = L L', W = inv(L)); W's strict upper triangle must be zero on entry, scr holds
-// n * n doubles.  *d_info as potrf_f64.  Asynchronous on s.
+// max(n * n, potrf_inverse_work_doubles(n)) doubles.  *d_info = -1: the single-launch panel gave up at a grid barrier.  *d_info as potrf_f64.  Asynchronous on s.
 // keep_L: also leave the complete factor L in the lower triangle of A (otherwise only its diagonal leaf blocks).
+int64_t potrf_inverse_work_doubles(int64_t n);
+// padded16: the caller guarantees that rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are
+// zero (they stay zero): a size that is not a multiple of 16 then still runs on the single-launch panel kernel.
 int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,
-                          bool keep_L, hipStream_t s);
+                          bool keep_L, hipStream_t s, bool padded16 = false);
 // Cholesky of a large block without its inverse, by panels (work: potrf_blocked_work_doubles(n) doubles).
 int64_t potrf_blocked_work_doubles(int64_t n);
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s);

@@ -706,7 +706,8 @@ struct FitPlan {
 static int32_t krig_fit_plan(gss_krig* h, FitPlan* fp) {
   const int64_t n = h->n, N1pad = h->N1pad, ldw = h->ldw;
   const int64_t szM = ldw * N1pad;
-  const int64_t szT = n * n > (int64_t)MAX_NC * n ? n * n : (int64_t)MAX_NC * n;  // potrf_inverse_f64 scratch
+  int64_t szT = n * n > (int64_t)MAX_NC * n ? n * n : (int64_t)MAX_NC * n;  // potrf_inverse_f64 scratch
+  if (potrf_inverse_work_doubles(n) > szT) szT = potrf_inverse_work_doubles(n);
   const int64_t szDinv = 64 * 64;  // scratch of the constraint-block leaf
   const int64_t szFd = (int64_t)MAX_NC * n, szBm = (int64_t)MAX_NC * n;
   const int64_t szS = 2 * MAX_NC * MAX_NC + 64 * 64;
@@ -745,7 +746,8 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(info2, sizeof(int), s));
   GSS_TRY(cov_pairwise_dev(h->vg, h->xdata.as<double>(), n, h->xdata.as<double>(), n, M, ldw, s));
   double* Wp = h->Wp();
-  GSS_TRY(potrf_inverse_f64(M, n, ldw, Wp, ldw, T, info, false, s));
+  // M and W' are zero outside the n x n blocks and reach past the next multiple of 16 (N1pad, ldw): the padded contract
+  GSS_TRY(potrf_inverse_f64(M, n, ldw, Wp, ldw, T, info, false, s, true));
 
   if (nc > 0) {
     GSS_TRY(dev_zero_bytes(S, sizeof(double) * (size_t)szS, s));
@@ -801,6 +803,11 @@ static int32_t krig_fit_wait(gss_krig* h) {
   GSS_HIP(hipMemcpy(hinfo, h->fit_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
   h->fit_ws.release();
   h->fit_info = nullptr;
+  if (hinfo[0] < 0) {
+    h->factored = false;
+    set_error("kriging fit: the factorisation kernel gave up waiting at a grid barrier (device shared with other work?)");
+    return GSS_ERR_HIP;
+  }
   if (hinfo[0] != 0) {
     h->factored = false;
     set_error("kriging covariance matrix is not positive definite (pivot %d of %lld); add a nugget or remove "

@@ -74,6 +74,10 @@ static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   int h = 0;
   GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
+  if (h < 0) {
+    set_error("%s: the factorisation kernel gave up waiting at a grid barrier (device shared with other work?)", what);
+    return GSS_ERR_HIP;
+  }
   if (h != 0) {
     set_error("%s is not positive definite (pivot %d); add a nugget or remove duplicate locations", what, h - 1);
     return GSS_ERR_NOT_POSDEF;
@@ -157,7 +161,9 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
       GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
       GSS_TRY(W11.alloc(sizeof(double) * (size_t)(nd * nd)));
       const int64_t tq = nd / 2 + 64;   // trtri_f64's scratch requirement
-      GSS_TRY(scr.alloc(sizeof(double) * (size_t)(nd * nd > tq * tq ? nd * nd : tq * tq)));
+      int64_t wscr = nd * nd > tq * tq ? nd * nd : tq * tq;
+      if (potrf_inverse_work_doubles(nd) > wscr) wscr = potrf_inverse_work_doubles(nd);
+      GSS_TRY(scr.alloc(sizeof(double) * (size_t)wscr));
       GSS_TRY(C21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(A21.alloc(sizeof(double) * (size_t)(ns * nd)));
       GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gss_dev_potrf": [_p, _i64, _i64, _p],
     "gss_dev_getrf_l": [_p, _i64, _i64, _p],
     "gss_dev_trtri": [_p, _i64, _i64, _p, _i64, _p],
+    "gss_dev_potrf_inverse": [_p, _i64, _i64, _p, _i64, _p],
     "gss_dev_gemm": [_i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _f64, _p, _i64, _i64, _i32, _p],
 }
 

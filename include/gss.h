@@ -318,6 +318,9 @@ int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream);
 /* a (n x n, full) <- unit lower-triangular L of the partial-pivot LU P a = L U (LAPACK getrf pivoting rule) */
 int32_t gss_dev_getrf_l(double* a, int64_t n, int64_t lda, void* stream);
 int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_t ldw, void* stream);
+/* factor and inverse in one go (the fit of gss_krig_fit and of gss_lugs_create): lower triangle of a <- L,
+ * w <- inv(L) with zeros above the diagonal */
+int32_t gss_dev_potrf_inverse(double* a, int64_t n, int64_t lda, double* w, int64_t ldw, void* stream);
 /* D = alpha * A * B + beta * D with arbitrary element strides (A is M x K, B is K x N) */
 int32_t gss_dev_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i,
                      int64_t sa_k, const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D,

@@ -92,6 +92,46 @@ def test_potrf_and_trtri(n):
     assert np.max(np.abs(W @ Lref - np.eye(n))) < 1e-9
 
 
+@pytest.mark.parametrize("n", [5, 128, 129, 256, 257, 300, 384, 385, 1000, 1024, 1025, 1600, 2048])
+def test_potrf_inverse_single_launch_panel(n):
+    """Factor and inverse together (the kriging fit, the LUGS blocks): blocks of 257 ... 1 024 rows run as one
+    cooperative launch (potrf_inv_panel_kernel, grid barriers between its phases), larger ones split down to it,
+    smaller ones are the 64 / 128 leaves.  Partial last blocks, leading dimensions that are not multiples of
+    anything, and what lies outside the n x n blocks is left alone."""
+    import torch
+    from gss import _lib
+    l = _lib.lib()
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n + 8))
+    A = G @ G.T / n + np.eye(n)
+    lda, ldw = n + 3, n + 5
+    buf = np.full((n + 2, lda), 9.0)
+    buf[:n, :n] = A
+    dA = _t(buf)
+    dW = torch.full((n + 2, ldw), 7.0, dtype=torch.float64, device="cuda")
+    _lib.check(l.gss_dev_potrf_inverse(_lib.ptr(dA), n, lda, _lib.ptr(dW), ldw, _lib.current_stream()))
+    gotA, gotW = dA.cpu().numpy(), dW.cpu().numpy()
+    L = np.tril(gotA[:n, :n].T)
+    Lref = np.linalg.cholesky(A)
+    assert np.max(np.abs(L - Lref)) < 1e-10 * np.max(np.abs(Lref))
+    W = gotW[:n, :n].T
+    assert np.array_equal(np.triu(W, 1), np.zeros((n, n)))
+    assert np.max(np.abs(W @ Lref - np.eye(n))) < 1e-9
+    assert np.all(gotA[n:, :] == 9.0) and np.all(gotA[:, n:] == 9.0)
+    assert np.all(gotW[n:, :] == 7.0) and np.all(gotW[:, n:] == 7.0)
+
+
+def test_potrf_inverse_panel_reports_the_pivot():
+    from gss import _lib
+    l = _lib.lib()
+    n = 700
+    A = np.eye(n)
+    A[533, 533] = -2.0
+    dA, dW = _t(A), _t(np.zeros((n, n)))
+    code = l.gss_dev_potrf_inverse(_lib.ptr(dA), n, n, _lib.ptr(dW), n, _lib.current_stream())
+    assert code == _lib.ERR_NOT_POSDEF and "pivot at row 533" in _lib.last_error()
+
+
 def test_potrf_reports_indefinite():
     from gss import _lib
     l = _lib.lib()

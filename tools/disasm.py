@@ -13,6 +13,7 @@ from check_dpp_hazards import OBJDUMP, code_objects
 
 path, sub = sys.argv[1], sys.argv[2]
 dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
+dumped = []
 for co in code_objects(path):
     with tempfile.NamedTemporaryFile(suffix=".co") as f:
         f.write(co)
@@ -56,5 +57,6 @@ for co in code_objects(path):
                 cls["other"] += v
         print("  ", dict(cls))
         print("  ", c.most_common(28))
-    if dump:
-        open(dump, "w").write("\n".join(out))
+    dumped += out
+if dump:
+    open(dump, "w").write("\n".join(dumped))
