@@ -524,27 +524,50 @@ __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restr
       }
 }
 
-// The same leaf for blocks of up to 128 x 128, one workgroup of four waves: the 8 x 8 grid of 16 x 16 tiles lives in
-// LDS in tile layout (element of lane l, register r at [r * 64 + l]: conflict-free), wave 0 factors the diagonal tile
-// of a step (potrf16_full, wave-local synchronisation) and all four waves share the X'Y products of the row solve, the
-// trailing update and the block forward substitution for W = inv(L).  Row J of W overwrites column J of U, which is
-// dead once that row is known (held in registers across the barrier).  One such launch replaces two 64 x 64 leaves,
-// four 64^3 GEMM launches and a copy of the recursion.
+// The same leaf for blocks of up to 128 x 128, one workgroup of NW waves: the 8 x 8 grid of 16 x 16 tiles lives in
+// LDS in tile layout (element of lane l, register r at [r * 64 + l]: conflict-free).  The leaf is the latency chain of
+// every fit (eight of them per 1 024 rows), so it is arranged around its one sequential part, the sixteen-column
+// factorisation of the diagonal tiles (potrf16_full, 2.5 us each, wave 0):
+//   R(k)  all waves: row solve U_kj = V_k' A_kj (j > k); each solved tile goes to global memory at once;
+//   T(k)  wave 0: A_k+1,k+1 -= U_k,k+1' U_k,k+1, then its factorisation (U, V = U^-1, V');
+//         the other waves meanwhile: the rest of the trailing update of step k, and row k of W = inv(L):
+//         W_kI = -V_k' sum_{K = I .. k-1} U_Kk' W_KI, kept in registers until everybody has read column k of U,
+//         whose slots it then takes (W_KI sits in slot (I, K)).
+// Two LDS-only barriers per step (fence on the local address space: the global stores issued along the way keep
+// draining behind them); the loads of the block are all in flight before the first tile is stored.
 constexpr int L128_TILES = 36;  // upper block triangle of 8 x 8
 constexpr size_t L128_LDS_BYTES = sizeof(double) * ((L128_TILES + 16) * 256 + 2 * 16 * 17);
 __host__ __device__ constexpr int tile_id8(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }
 
-// NW waves share the tile products (8 = two per SIMD: the LDS round trips of one wave hide behind the MFMAs of the other)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// NW waves (8 = two per SIMD); dbg: time stamps of wave 0 (GSS_PANEL_TIMES)
 template <int NW>
 __device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int64_t lda, int row_offset,
                                              int* __restrict__ info, double* __restrict__ dinv, int64_t ldd,
-                                             double* __restrict__ sm128) {
+                                             double* __restrict__ sm128, long long* dbg = nullptr) {
+  static_assert(NW >= 2, "one wave factors, the others update");
+  // waves that share the trailing update and the rows of W: not wave 0, and not wave 4 either, which sits on wave 0's
+  // SIMD -- FP64 MFMAs and FP64 vector instructions use the same pipe, its MFMAs would stretch the factorisation chain
+  constexpr int NWK = NW > 4 ? NW - 2 : NW - 1;
+  constexpr int LMAX = (L128_TILES + NW - 1) / NW;  // tiles per wave when the block is loaded
+  constexpr int WMAX = (7 + NWK - 1) / NWK;        // tiles of a row of W per wave
+  int ndbg = 0;
+  auto stamp = [&] {
+    if (dbg && threadIdx.x == 0) dbg[ndbg++] = (long long)wall_clock64();
+  };
+  stamp();
   double* Tl = sm128;                  // 36 tiles: U (upper block triangle), later W below the diagonal
   double* Vl = Tl + L128_TILES * 256;  // V_k = U_kk^-1
   double* VTl = Vl + 8 * 256;          // V_k'
   double* S = VTl + 8 * 256;
   double* S2 = S + 16 * 17;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int nt = (n + 15) >> 4;
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -558,109 +581,136 @@ __device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int6
 #pragma unroll
     for (int r = 0; r < 4; ++r) base[id * 256 + r * 64 + lane] = t[r];
   };
-  // block -> tiles (lower triangle of A is the storage; rows / columns beyond n are the identity)
-  {
-    int q = 0;
-    for (int I = 0; I < nt; ++I)
-      for (int J = I; J < nt; ++J) {
-        if ((q++ % NW) != wave) continue;
-        d4_t t;
+  // L = U': element (rho, gamma) of U_IJ is L[16 J + gamma][16 I + rho]
+  auto store_L = [&](int I, int J, const d4_t& u) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + g + 4 * r, col = 16 * J + c;
-          double v = (row == col) ? 1.0 : 0.0;
-          if (row < n && col < n) {
-            const int hi = row > col ? row : col, lo = row > col ? col : row;
-            v = A[hi + (int64_t)lo * lda];
-          }
-          t[r] = v;
-        }
-        st(Tl, tile_id8(I, J), t);
-      }
-  }
-  __syncthreads();
-  int bad = 0;
-  for (int kk = 0; kk < nt; ++kk) {
-    if (wave == 0) {
-      d4_t U, V, VT;
-      int bc;
-      potrf16_full<true>(ld(Tl, tile_id8(kk, kk)), S, S2, lane, &U, &V, &VT, &bc);
-      if (bc >= 0 && bad == 0) bad = row_offset + 16 * kk + bc + 1;
-      st(Tl, tile_id8(kk, kk), U);
-      st(Vl, kk, V);
-      st(VTl, kk, VT);
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = 16 * J + c, lcol = 16 * I + g + 4 * r;
+      if (lrow < n && lcol < n && lrow >= lcol) A[lrow + (int64_t)lcol * lda] = u[r];
     }
-    __syncthreads();
+  };
+  // W_JI from its LDS tile (element (rho, gamma) at [(rho & 3) * 16 + gamma + (rho >> 2) * 64]), read transposed so
+  // that the lanes run along the rows of W: 128-byte column pieces.  The caller has just written the tile itself.
+  auto store_W = [&](int J, int I, const double* src) {
+    tile_sync<true>();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int wrow = 16 * J + c, wcol = 16 * I + g + 4 * r;
+      const double v = src[(c >> 2) * 64 + (c & 3) * 16 + g + 4 * r];
+      if (wrow < n && wcol < n) dinv[wrow + (int64_t)wcol * ldd] = v;
+    }
+  };
+  // ---- block -> tiles (lower triangle of A is the storage; rows / columns beyond n are the identity)
+  {
+    d4_t t[LMAX];
+    int tid[LMAX];
+#pragma unroll
+    for (int u = 0; u < LMAX; ++u) {
+      int idx = wave + u * NW, I = 0, cnt = nt;
+      const bool have = idx < nt * (nt + 1) / 2;
+      if (!have) idx = 0;
+      while (idx >= cnt) {
+        idx -= cnt;
+        ++I;
+        --cnt;
+      }
+      const int J = I + idx;
+      tid[u] = have ? tile_id8(I, J) : -1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * J + c;
+        const bool ok = row < n && col < n;
+        const int hi = row > col ? row : col, lo = row > col ? col : row;
+        const double v = A[ok ? hi + (int64_t)lo * lda : (int64_t)0];
+        t[u][r] = ok ? v : (row == col ? 1.0 : 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LMAX; ++u)
+      if (tid[u] >= 0) st(Tl, tid[u], t[u]);
+  }
+  lds_barrier();
+  stamp();
+  int bad = 0;
+  auto factor_tile = [&](int kk, const d4_t& t) {  // wave 0
+    d4_t U, V, VT;
+    int bc;
+    potrf16_full<true>(t, S, S2, lane, &U, &V, &VT, &bc);
+    if (bc >= 0 && bad == 0) bad = row_offset + 16 * kk + bc + 1;
+    st(Tl, tile_id8(kk, kk), U);
+    st(Vl, kk, V);
+    st(VTl, kk, VT);
+    store_L(kk, kk, U);
+    if (dinv) store_W(kk, kk, VTl + kk * 256);
+  };
+  if (wave == 0) factor_tile(0, ld(Tl, tile_id8(0, 0)));
+  lds_barrier();
+  stamp();
+  d4_t wreg[WMAX];
+  for (int kk = 0; kk < nt; ++kk) {
+    // ---- R(kk): row kk of W (computed in T(kk-1)... no: in T(kk) below; stored here one step later), row solve
     {
       const d4_t V = ld(Vl, kk);
-      for (int j = kk + 1 + wave; j < nt; j += NW) st(Tl, tile_id8(kk, j), xty(V, ld(Tl, tile_id8(kk, j)), zero4));
+      for (int j = kk + 1 + wave; j < nt; j += NW) {
+        const d4_t u = xty(V, ld(Tl, tile_id8(kk, j)), zero4);
+        st(Tl, tile_id8(kk, j), u);
+        store_L(kk, j, u);
+      }
     }
-    __syncthreads();
-    {
+    lds_barrier();
+    // ---- T(kk)
+    const int m = nt - 1 - kk;                                  // rows below
+    const int ntr = m > 0 ? m * (m + 1) / 2 - 1 : 0;            // trailing tiles without (kk+1, kk+1)
+    if (wave == 0) {
+      if (m > 0) {
+        const d4_t x = ld(Tl, tile_id8(kk, kk + 1));
+        factor_tile(kk + 1, xty(-x, x, ld(Tl, tile_id8(kk + 1, kk + 1))));
+      }
+      stamp();
+    } else if (wave != 4) {
+      const int w = wave < 4 ? wave - 1 : wave - 2;
       int q = 0;
-      for (int i = kk + 1; i < nt; ++i) {
-        const bool mine_any = true;
-        (void)mine_any;
+      for (int i = kk + 1; i < nt; ++i)
         for (int j = i; j < nt; ++j) {
-          if ((q++ % NW) != wave) continue;
+          if (i == kk + 1 && j == kk + 1) continue;
+          if ((q++ % NWK) != w) continue;
           const d4_t N = -ld(Tl, tile_id8(kk, i));
           st(Tl, tile_id8(i, j), xty(N, ld(Tl, tile_id8(kk, j)), ld(Tl, tile_id8(i, j))));
         }
+      if (dinv && kk >= 1) {
+        const d4_t NV = -ld(Vl, kk);
+        const int I0 = ((w - ntr) % NWK + NWK) % NWK;  // chain I belongs to worker (ntr + I) mod NWK
+#pragma unroll
+        for (int u = 0; u < WMAX; ++u) {
+          const int I = I0 + u * NWK;
+          if (I < kk) {
+            d4_t acc = zero4;
+            for (int K = I; K < kk; ++K) {
+              const d4_t Wki = (K == I) ? ld(VTl, I) : ld(Tl, tile_id8(I, K));
+              acc = xty(ld(Tl, tile_id8(K, kk)), Wki, acc);
+            }
+            wreg[u] = xty(NV, acc, zero4);
+          }
+        }
       }
     }
-    __syncthreads();
+    lds_barrier();  // every wave has read what it needs of column kk of U
+    if (wave != 0 && wave != 4 && dinv && kk >= 1) {
+      const int w = wave < 4 ? wave - 1 : wave - 2;
+      const int I0 = ((w - ntr) % NWK + NWK) % NWK;
+#pragma unroll
+      for (int u = 0; u < WMAX; ++u) {
+        const int I = I0 + u * NWK;
+        if (I < kk) {
+          st(Tl, tile_id8(I, kk), wreg[u]);
+          store_W(kk, I, Tl + tile_id8(I, kk) * 256);
+        }
+      }
+    }
+    // (the W tiles written above are first read in T(kk+1), behind the barrier of R(kk+1))
   }
   if (wave == 0 && bad != 0 && lane == 0 && *info == 0) *info = bad;
-  // L = U': element (r, c) of U_IJ is L[16 J + c][16 I + r]
-  {
-    int q = 0;
-    for (int I = 0; I < nt; ++I)
-      for (int J = I; J < nt; ++J) {
-        if ((q++ % NW) != wave) continue;
-        const d4_t t = ld(Tl, tile_id8(I, J));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lrow = 16 * J + c, lcol = 16 * I + g + 4 * r;
-          if (lrow < n && lcol < n && lrow >= lcol) A[lrow + (int64_t)lcol * lda] = t[r];
-        }
-      }
-  }
-  if (!dinv) return;
-  // W = inv(L): W_II = V_I', W_JI = -V_J' sum_{K = I .. J-1} U_KJ' W_KI (J > I); W_KI sits in slot (I, K) once row K is done
-  for (int J = 1; J < nt; ++J) {
-    d4_t wreg[(7 + NW - 1) / NW];
-    int cnt = 0;
-    for (int I = wave; I < J; I += NW) {
-      d4_t acc = zero4;
-      for (int K = I; K < J; ++K) {
-        const d4_t Wki = (K == I) ? ld(VTl, I) : ld(Tl, tile_id8(I, K));
-        acc = xty(ld(Tl, tile_id8(K, J)), Wki, acc);
-      }
-      wreg[cnt++] = xty(-ld(Vl, J), acc, zero4);
-    }
-    __syncthreads();  // every wave has read what it needs of column J of U
-    cnt = 0;
-    for (int I = wave; I < J; I += NW) st(Tl, tile_id8(I, J), wreg[cnt++]);
-    __syncthreads();
-  }
-  // dinv (column-major, leading dimension ldd): the n x n block, zero above the diagonal.  The tile element of
-  // (lane = 16 g + c, register r) is (row g + 4 r, column c); read back transposed -- lane (g', c'), register r'
-  // takes (row c', column g' + 4 r') from slot [(c' >> 2) * 64 + (c' & 3) * 16 + g' + 4 r'] -- the lanes run along
-  // the rows of W, so every store instruction writes 128-B column pieces instead of 64 scattered doubles.
-  {
-    int q = 0;
-    for (int I = 0; I < nt; ++I)
-      for (int J = 0; J < nt; ++J) {
-        if ((q++ % NW) != wave) continue;
-        const double* src = (J == I) ? VTl + I * 256 : (J > I ? Tl + tile_id8(I, J) * 256 : nullptr);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int wrow = 16 * J + c, wcol = 16 * I + g + 4 * r;
-          const double v = src ? src[(c >> 2) * 64 + (c & 3) * 16 + g + 4 * r] : 0.0;
-          if (wrow < n && wcol < n) dinv[wrow + (int64_t)wcol * ldd] = v;
-        }
-      }
-  }
+  stamp();
 }
 
 template <int NW>
@@ -674,18 +724,21 @@ __global__ __launch_bounds__(64 * NW) void potrf_inv_leaf128_kernel(double* __re
 // ---------------------------------------------------------------------------------------------------------------
 // Factor and inverse of a block of up to PANEL_MAX rows in ONE launch (the fit at n = 1 000 and every 1 024-column
 // panel of the LUGS factorisations used to be a chain of ~95 dependent launches: 8 leaves of 58 us and ~30 GEMMs of
-// 10-30 us on a few of the 256 CUs each).  A cooperative grid of a few dozen workgroups walks the 128 x 128 block
-// columns; phases are separated by a grid barrier (one agent-scope atomic per workgroup, tools/probe_gridsync.hip):
-//   phase 1   workgroup 0: leaf k (L_kk and W_kk = inv(L_kk), the kernel above as a device function).
-//             every other workgroup meanwhile: the trailing updates of step k-1 that nobody waits for yet
-//             (A_ij -= L_i,k-1 L_j,k-1' for j > k) and T_kj = sum_m L_km W_mj (row k of the inverse before its scaling);
-//   phase 2   L_ik = A_ik W_kk' (i > k) into the scratch P, and W_kj = -W_kk T_kj (j < k);
-//   phase 3   look-ahead: column k+1 alone receives the update of step k (A_i,k+1 -= L_ik L_k+1,k'), P -> A_ik.
-// So the chain between two leaves is two GEMM rounds of one 16 x 16 tile per wave and three barriers; everything
-// else hides behind the leaf.  Work items are single MFMA tiles read straight from global memory (L2): the kernel is
-// latency-bound, its 0.7 GFLOP would take 9 us at the rate of K3.  Tiles are loaded "transposed" (lane c runs along a
-// column: 128-byte pieces), which is the orientation acc + X'Y wants for D = A B' with all three operands coalesced;
-// the one product that is not of that shape (T = L W) reads W tiles with 32-byte pieces.
+// 10-30 us on a few of the 256 CUs each).  A grid of a few dozen workgroups walks the 128 x 128 block columns; what
+// lies between two leaves is kept as short as the data dependence allows, everything else runs beside the next leaf:
+//   leaf k        workgroup 0: L_kk and W_kk = inv(L_kk) (the leaf above as a device function).
+//                 The other workgroups meanwhile finish step k-1 in two rounds with a barrier of their own between:
+//                   B1  L_i,k-1 = A_i,k-1 W_k-1,k-1' for the rows i > k (into the scratch P) and row k-1 of the
+//                       inverse, W_k-1,j = -W_k-1,k-1 T_k-1,j;
+//                   B2  every trailing update of step k-1 except the diagonal block (k, k), P -> A, and the
+//                       contributions of row k-1 of W to the running sums T_ij += L_i,k-1 W_k-1,j (i >= k, j < k);
+//   grid barrier, L_k+1,k = A_k+1,k W_kk' (64 tiles), grid barrier, A_k+1,k+1 -= L_k+1,k L_k+1,k' (36 tiles),
+//   grid barrier, leaf k+1.
+// Barriers are one agent-scope atomic per workgroup (tools/probe_gridsync.hip).  Work items are single MFMA tiles
+// read straight from global memory (L2): the kernel is latency-bound, its 0.7 GFLOP would take 9 us at the rate of
+// K3.  Tiles are loaded "transposed" (lane c runs along a column: 128-byte pieces), which is the orientation
+// acc + X'Y wants for D = A B' with all three operands coalesced; the one product that is not of that shape
+// (T += L W) reads its W tiles with 32-byte pieces.
 constexpr int PANEL_NB = 128;
 constexpr int PANEL_WAVES = 8;
 
@@ -707,7 +760,8 @@ __device__ __forceinline__ void tile_st(double* __restrict__ M, int ld, int r0, 
   double* __restrict__ Mu = M + (unsigned)(r0 + c0 * ld);
   const unsigned lo = (unsigned)(c + g * ld);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) (Mu + (unsigned)(4 * r * ld))[lo] = t[r];
+  for (int r = 0; r < 4; ++r)  // write-through (sc1): nothing dirty is left in this XCD's L2 for the next barrier to flush
+    __hip_atomic_store(&(Mu + (unsigned)(4 * r * ld))[lo], t[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // acc (+/-)= sum over the k-tiles tp_lo .. tp_hi of  X_tp' Y_tp  with X = tile (xr0, xc0 + 16 tp) of MX and Y = tile
@@ -731,19 +785,20 @@ __device__ __forceinline__ d4_t tile_dot(d4_t acc, const double* __restrict__ MX
   return acc;
 }
 
-// bar[0]: arrivals (monotone), bar[1]: set when a wait gave up (every later barrier falls through, the grid drains)
-__device__ __forceinline__ void panel_grid_sync(unsigned* bar, unsigned& epoch, int* info) {
+// cnt: arrivals (monotone) of the `members` workgroups taking part; dead: set when a wait gave up (every later
+// barrier falls through and the grid drains)
+__device__ __forceinline__ void panel_sync(unsigned* cnt, unsigned* dead, unsigned& epoch, unsigned members, int* info) {
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
     __threadfence();
-    atomicAdd(&bar[0], 1u);
-    const unsigned target = epoch * gridDim.x;
+    atomicAdd(cnt, 1u);
+    const unsigned target = epoch * members;
     unsigned spins = 0;
-    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
       if (++spins > 4000000u) {
-        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicCAS(info, 0, -1);
         break;
       }
@@ -774,6 +829,9 @@ __device__ __forceinline__ void lower_tile(int idx, int& ta, int& tb) {
 
 // n: rows of the block as the tiles see it (a multiple of 16); nreal <= n: rows of the matrix (the leaf treats the
 // rest of its block as the identity; in memory rows and columns nreal .. n-1 are zeros and stay zeros).
+// scr: P (ldp x 128: column k of L while step k is being finished) and T (ldp x ldp: slab i holds T_i.' as
+// TT_i(b, a) = T_ib-block(a, b)), ldp = 128 ceil(n / 128).  bar: [0] grid arrivals, [1] gave-up flag, [2] time stamps
+// wanted, [4] arrivals of the barrier among the workgroups 1 .. G-1, [8] arrivals of the team's barrier, [16 ...] stamps.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __restrict__ A, int n, int nreal, int64_t lda_,
                                                                   double* __restrict__ W, int64_t ldw_,
@@ -786,11 +844,11 @@ __global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __rest
   const int G = gridDim.x;
   const int nbk = (n + PANEL_NB - 1) / PANEL_NB;
   const int ldp_ = nbk * PANEL_NB;
-  double* P = scr;                               // ldp x 128: L_ik of the current step (rows as in the block)
-  double* TT = scr + (int64_t)ldp_ * PANEL_NB;   // ldp x 128: TT(b, a) = T_kj(a, b), b = column in the block
+  double* P = scr;
+  double* TT = scr + (int64_t)ldp_ * PANEL_NB;
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-  unsigned epoch = 0;
-  // GSS_PANEL_TIMES: workgroup 0 stamps every phase boundary (100 MHz counter) behind the barrier words
+  unsigned epoch = 0, epoch_bg = 0, epoch_team = 0;
+  const int team = G < 16 ? G : 16;
   long long* stamps = (bar[2] != 0u && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long long*>(bar + 16) : nullptr;
   int nstamp = 0;
   auto stamp = [&] {
@@ -800,127 +858,153 @@ __global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __rest
 
   for (int k = 0; k < nbk; ++k) {
     const int k0 = k * PANEL_NB;
-    // ---------------- phase 1
+    // ---------------- leaf k, and the rest of step k-1 beside it
     if (blockIdx.x == 0) {
       const int nk = nreal - k0 < PANEL_NB ? nreal - k0 : PANEL_NB;
       leaf128_body<NW>(A + k0 + (int64_t)k0 * lda_, nk, lda_, row_offset + k0, info, W + k0 + (int64_t)k0 * ldw_, ldw_,
-                       sm128);
+                       sm128, (stamps && k == 1) ? stamps + 128 : nullptr);
     } else if (k >= 1) {
-      PANEL_OPAQUE_LDS();
-      const int nw = (G - 1) * NW;
-      int t = (blockIdx.x - 1) * NW + wave, base = 0;
-      const int kc0 = k0 - PANEL_NB;  // column block of step k-1
-      // trailing updates of step k-1 on the columns behind the look-ahead column
-      for (int j = k + 1; j < nbk; ++j)
-        for (int i = j; i < nbk; ++i) {
-          const int ntile = (i == j) ? 36 : 64;
-          for (; t < base + ntile; t += nw) {
-            int ta, tb;
-            if (i == j) lower_tile(t - base, ta, tb);
-            else {
-              ta = (t - base) & 7;
-              tb = (t - base) >> 3;
-            }
-            const int ar = i * PANEL_NB + 16 * ta, br = j * PANEL_NB + 16 * tb;
-            if (ar < n && br < n) {
-              d4_t acc = tile_ld<false>(A, lda, ar, br, g, c);
-              acc = tile_dot<true, false>(acc, A, lda, br, kc0, A, lda, ar, kc0, 0, 7, g, c);
-              tile_st(A, lda, ar, br, g, c, acc);
+      const int nw = (G - 1) * NW, wid = (blockIdx.x - 1) + (G - 1) * wave;  // consecutive tasks on different CUs
+      const int kp = k - 1, kp0 = k0 - PANEL_NB;
+      {  // B1
+        PANEL_OPAQUE_LDS();
+        int t = wid, base = 0;
+        for (int i = k + 1; i < nbk; ++i) {   // L_i,kp = A_i,kp W_kp,kp' -> P
+          for (; t < base + 64; t += nw) {
+            const int ta = (t - base) & 7, tb = (t - base) >> 3;
+            const int ar = i * PANEL_NB + 16 * ta;
+            if (ar < n) {
+              const d4_t acc = tile_dot<false, false>(zero4, W, ldw, kp0 + 16 * tb, kp0, A, lda, ar, kp0, 0, tb, g, c);
+              tile_st(P, ldp, ar, 16 * tb, g, c, acc);
             }
           }
-          base += ntile;
+          base += 64;
         }
-      // T_kj (natural orientation: element (a, b)) -> TT(j0 + b, a)
-      for (int j = 0; j < k; ++j) {
-        for (; t < base + 64; t += nw) {
-          const int ta = (t - base) & 7, tb = (t - base) >> 3;
-          const int ar = k0 + 16 * ta, bc = j * PANEL_NB + 16 * tb;
-          if (ar < n) {
-            d4_t acc = zero4;
-            for (int m = j; m < k; ++m)  // W_jj is lower triangular: k-tiles from tb on
-              acc = tile_dot<false, true>(acc, A, lda, ar, m * PANEL_NB, W, ldw, m * PANEL_NB, bc, m == j ? tb : 0, 7, g, c);
-            tile_st(TT, ldp, bc, 16 * ta, g, c, acc);
+        const double* TTk = TT + (int64_t)kp * ldp * PANEL_NB;
+        for (int j = 0; j < kp; ++j) {        // W_kp,j = -W_kp,kp T_kp,j (block kp is a full block: kp < nbk - 1)
+          for (; t < base + 64; t += nw) {
+            const int ta = (t - base) & 7, tb = (t - base) >> 3;
+            const int ar = kp0 + 16 * ta, bc = j * PANEL_NB + 16 * tb;
+            const d4_t acc = tile_dot<true, false>(zero4, TTk, ldp, bc, 0, W, ldw, ar, kp0, 0, ta, g, c);
+            tile_st(W, ldw, ar, bc, g, c, acc);
+          }
+          base += 64;
+        }
+      }
+      panel_sync(bar + 4, bar + 1, epoch_bg, G - 1, info);
+      {  // B2
+        PANEL_OPAQUE_LDS();
+        int t = wid, base = 0;
+        // trailing updates of step kp, all but the diagonal block (k, k): A_ij -= L_i,kp L_j,kp' from P
+        for (int j = k; j < nbk; ++j)
+          for (int i = (j == k ? k + 1 : j); i < nbk; ++i) {
+            const int ntile = (i == j) ? 36 : 64;
+            for (; t < base + ntile; t += nw) {
+              int ta, tb;
+              if (i == j) lower_tile(t - base, ta, tb);
+              else {
+                ta = (t - base) & 7;
+                tb = (t - base) >> 3;
+              }
+              const int ar = i * PANEL_NB + 16 * ta, br = j * PANEL_NB + 16 * tb;
+              if (ar < n && br < n) {
+                d4_t acc = tile_ld<false>(A, lda, ar, br, g, c);
+                acc = tile_dot<true, false>(acc, P, ldp, br, 0, P, ldp, ar, 0, 0, 7, g, c);
+                tile_st(A, lda, ar, br, g, c, acc);
+              }
+            }
+            base += ntile;
+          }
+        // T_ij (+)= L_i,kp W_kp,j for the rows i >= k and j <= kp (natural orientation (a, b) -> TT_i(j0 + b, a));
+        // j == kp starts the sum with the lower-triangular W_kp,kp (k-tiles from tb on)
+        for (int i = k; i < nbk; ++i) {
+          double* TTi = TT + (int64_t)i * ldp * PANEL_NB;
+          for (int j = 0; j <= kp; ++j) {
+            for (; t < base + 64; t += nw) {
+              const int ta = (t - base) & 7, tb = (t - base) >> 3;
+              const int ar = i * PANEL_NB + 16 * ta, bc = j * PANEL_NB + 16 * tb;
+              if (ar < n) {
+                d4_t acc = (j == kp) ? zero4 : tile_ld<false>(TTi, ldp, bc, 16 * ta, g, c);
+                acc = tile_dot<false, true>(acc, P, ldp, ar, 0, W, ldw, kp0, bc, j == kp ? tb : 0, 7, g, c);
+                tile_st(TTi, ldp, bc, 16 * ta, g, c, acc);
+              }
+            }
+            base += 64;
           }
         }
-        base += 64;
+        // P -> A_i,kp (nobody reads column kp of A in this round)
+        for (int i = k; i < nbk; ++i) {
+          for (; t < base + 64; t += nw) {
+            const int ta = (t - base) & 7, tb = (t - base) >> 3;
+            const int ar = i * PANEL_NB + 16 * ta;
+            if (ar < n) tile_st(A, lda, ar, kp0 + 16 * tb, g, c, tile_ld<false>(P, ldp, ar, 16 * tb, g, c));
+          }
+          base += 64;
+        }
       }
     }
     stamp();
-    panel_grid_sync(bar, epoch, info);
+    panel_sync(bar, bar + 1, epoch, G, info);
     stamp();
-    // ---------------- phase 2
-    {
+    if (k == nbk - 1) {
+      // ---------------- the last row of the inverse: W_kj = -W_kk T_kj (the k-tiles stop at the row tile, inside n)
       PANEL_OPAQUE_LDS();
+      (void)lda;
       const int nw = G * NW;
-      int t = blockIdx.x * NW + wave, base = 0;
-      // L_ik = A_ik W_kk' -> P (block k is a full block here: k < nbk - 1)
-      for (int i = k + 1; i < nbk; ++i) {
-        for (; t < base + 64; t += nw) {
-          const int ta = (t - base) & 7, tb = (t - base) >> 3;
-          const int ar = i * PANEL_NB + 16 * ta;
-          if (ar < n) {
-            const d4_t acc = tile_dot<false, false>(zero4, W, ldw, k0 + 16 * tb, k0, A, lda, ar, k0, 0, tb, g, c);
-            tile_st(P, ldp, ar, 16 * tb, g, c, acc);
-          }
-        }
-        base += 64;
-      }
-      // W_kj = -W_kk T_kj (the k-tiles stop at the row tile: W_kk is lower triangular, so they never leave the block)
+      int t = blockIdx.x + G * wave, base = 0;
+      const double* TTk = TT + (int64_t)k * ldp * PANEL_NB;
       for (int j = 0; j < k; ++j) {
         for (; t < base + 64; t += nw) {
           const int ta = (t - base) & 7, tb = (t - base) >> 3;
           const int ar = k0 + 16 * ta, bc = j * PANEL_NB + 16 * tb;
           if (ar < n) {
-            const d4_t acc = tile_dot<true, false>(zero4, TT, ldp, bc, 0, W, ldw, ar, k0, 0, ta, g, c);
+            const d4_t acc = tile_dot<true, false>(zero4, TTk, ldp, bc, 0, W, ldw, ar, k0, 0, ta, g, c);
             tile_st(W, ldw, ar, bc, g, c, acc);
           }
         }
         base += 64;
       }
+      stamp();
+      break;
     }
-    stamp();
-    if (k == nbk - 1) break;
-    panel_grid_sync(bar, epoch, info);
-    stamp();
-    // ---------------- phase 3
-    {
-      PANEL_OPAQUE_LDS();
-      (void)ldw;
-      const int nw = G * NW;
-      int t = blockIdx.x * NW + wave, base = 0;
-      const int j0 = k0 + PANEL_NB;
-      // look-ahead: column k+1 receives the update of step k (L_.k read from P)
-      for (int i = k + 1; i < nbk; ++i) {
-        const int ntile = (i == k + 1) ? 36 : 64;
-        for (; t < base + ntile; t += nw) {
-          int ta, tb;
-          if (i == k + 1) lower_tile(t - base, ta, tb);
-          else {
-            ta = (t - base) & 7;
-            tb = (t - base) >> 3;
+    // ---------------- the chain to the next leaf, on a team of a few workgroups (sixteen arrivals at a barrier cost
+    // 1.5 us, sixty-four 5 us: the atomics on one word serialise); the rest go straight on to B1, which touches
+    // nothing these two steps touch, and meet the team again at the barrier between B1 and B2
+    if ((int)blockIdx.x < team) {
+      {  // L_k+1,k = A_k+1,k W_kk' -> P
+        PANEL_OPAQUE_LDS();
+        const int nw = team * NW;
+        for (int t = blockIdx.x + team * wave; t < 64; t += nw) {
+          const int ta = t & 7, tb = t >> 3;
+          const int ar = k0 + PANEL_NB + 16 * ta;
+          if (ar < n) {
+            const d4_t acc = tile_dot<false, false>(zero4, W, ldw, k0 + 16 * tb, k0, A, lda, ar, k0, 0, tb, g, c);
+            tile_st(P, ldp, ar, 16 * tb, g, c, acc);
           }
-          const int ar = i * PANEL_NB + 16 * ta, br = j0 + 16 * tb;
+        }
+      }
+      stamp();
+      panel_sync(bar + 8, bar + 1, epoch_team, team, info);
+      stamp();
+      {  // A_k+1,k+1 -= L_k+1,k L_k+1,k'
+        PANEL_OPAQUE_LDS();
+        (void)ldw;
+        const int nw = team * NW;
+        for (int t = blockIdx.x + team * wave; t < 36; t += nw) {
+          int ta, tb;
+          lower_tile(t, ta, tb);
+          const int ar = k0 + PANEL_NB + 16 * ta, br = k0 + PANEL_NB + 16 * tb;
           if (ar < n && br < n) {
             d4_t acc = tile_ld<false>(A, lda, ar, br, g, c);
             acc = tile_dot<true, false>(acc, P, ldp, br, 0, P, ldp, ar, 0, 0, 7, g, c);
             tile_st(A, lda, ar, br, g, c, acc);
           }
         }
-        base += ntile;
       }
-      // P -> A_ik
-      for (int i = k + 1; i < nbk; ++i) {
-        for (; t < base + 64; t += nw) {
-          const int ta = (t - base) & 7, tb = (t - base) >> 3;
-          const int ar = i * PANEL_NB + 16 * ta;
-          if (ar < n) tile_st(A, lda, ar, k0 + 16 * tb, g, c, tile_ld<false>(P, ldp, ar, 16 * tb, g, c));
-        }
-        base += 64;
-      }
+      stamp();
+      panel_sync(bar + 8, bar + 1, epoch_team, team, info);
+      stamp();
     }
-    stamp();
-    panel_grid_sync(bar, epoch, info);
-    stamp();
   }
 }
 #undef PANEL_OPAQUE_LDS
@@ -1105,7 +1189,10 @@ constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets in
 // scratch of potrf_inverse_f64 (doubles)
 int64_t potrf_inverse_work_doubles(int64_t n) {
   if (n <= 2 * LEAF) return 0;
-  if (use_panel(n)) return 2 * PANEL_NB * (((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB);
+  if (use_panel(n)) {
+    const int64_t ldp = ((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB;
+    return ldp * (ldp + PANEL_NB);
+  }
   const int64_t n1 = split_point(n), n2 = n - n1;
   const int64_t a = potrf_inverse_work_doubles(n1), b = 2 * n1 * n2 + potrf_inverse_work_doubles(n2);
   return a > b ? a : b;
@@ -1125,7 +1212,7 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
     unsigned* bar = panel_barrier_words(s);
     GSS_REQUIRE(bar != nullptr, "potrf_inverse: no memory for the barrier words");
     static const bool times = std::getenv("GSS_PANEL_TIMES") != nullptr;
-    GSS_HIP(hipMemsetAsync(bar, 0, 16, s));
+    GSS_HIP(hipMemsetAsync(bar, 0, 64, s));
     if (times) GSS_HIP(hipMemsetAsync(bar + 2, 1, 1, s));
     int n16 = (int)((n + 15) / 16 * 16), n32 = (int)n, ro = (int)row_offset;
     // An ordinary launch: 64 workgroups of a 256-CU device are resident together whenever fewer than four such
@@ -1139,9 +1226,14 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
       long long st[64] = {0};
       GSS_HIP(hipStreamSynchronize(s));
       GSS_HIP(hipMemcpy(st, bar + 16, sizeof(st), hipMemcpyDeviceToHost));
-      const int nb = (int)((n + PANEL_NB - 1) / PANEL_NB), ns = 1 + 6 * nb - 3;
+      const int nb = (int)((n + PANEL_NB - 1) / PANEL_NB), ns = 6 * nb - 2;
       fprintf(stderr, "panel n=%d:", n32);
       for (int i = 1; i < ns && i < 64; ++i) fprintf(stderr, " %.1f", (double)(st[i] - st[0]) * 0.01);
+      fprintf(stderr, "\n");
+      long long lf[24] = {0};
+      GSS_HIP(hipMemcpy(lf, reinterpret_cast<long long*>(bar + 16) + 128, sizeof(lf), hipMemcpyDeviceToHost));
+      fprintf(stderr, "leaf of step 1 (loaded | per step: tile factor, step done | L written | W done | end):");
+      for (int i = 1; i < 22; ++i) fprintf(stderr, " %.1f", (double)(lf[i] - lf[0]) * 0.01);
       fprintf(stderr, "\n");
     }
     return GSS_OK;
