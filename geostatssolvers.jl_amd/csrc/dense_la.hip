@@ -831,7 +831,8 @@ __device__ __forceinline__ void lower_tile(int idx, int& ta, int& tb) {
 // rest of its block as the identity; in memory rows and columns nreal .. n-1 are zeros and stay zeros).
 // scr: P (ldp x 128: column k of L while step k is being finished) and T (ldp x ldp: slab i holds T_i.' as
 // TT_i(b, a) = T_ib-block(a, b)), ldp = 128 ceil(n / 128).  bar: [0] grid arrivals, [1] gave-up flag, [2] time stamps
-// wanted, [4] arrivals of the barrier among the workgroups 1 .. G-1, [8] arrivals of the team's barrier, [16 ...] stamps.
+// wanted, [4] arrivals of the barrier among the workgroups 1 .. G-1, [8] arrivals of the team's barrier, [12] workgroups
+// that have left, [16 ...] stamps.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __restrict__ A, int n, int nreal, int64_t lda_,
                                                                   double* __restrict__ W, int64_t ldw_,
@@ -1006,6 +1007,18 @@ __global__ __launch_bounds__(64 * NW) void potrf_inv_panel_kernel(double* __rest
       stamp();
     }
   }
+  // the last workgroup to leave puts the barrier words back to zero for the next launch on this stream (everybody
+  // is out of every barrier by then): no memset in front of each launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&bar[12], 1u) == (unsigned)G - 1u) {
+      __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bar[4], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bar[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&bar[12], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 #undef PANEL_OPAQUE_LDS
 
@@ -1163,6 +1176,10 @@ static unsigned* panel_barrier_words(hipStream_t s) {
   if (it != words.end()) return it->second;
   unsigned* p = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, 4096) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
   words.emplace(s, p);
   return p;
 }
@@ -1212,8 +1229,7 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
     unsigned* bar = panel_barrier_words(s);
     GSS_REQUIRE(bar != nullptr, "potrf_inverse: no memory for the barrier words");
     static const bool times = std::getenv("GSS_PANEL_TIMES") != nullptr;
-    GSS_HIP(hipMemsetAsync(bar, 0, 64, s));
-    if (times) GSS_HIP(hipMemsetAsync(bar + 2, 1, 1, s));
+    if (times) GSS_HIP(hipMemsetAsync(bar + 2, 1, 1, s));  // (the kernel leaves the barrier words at zero)
     int n16 = (int)((n + 15) / 16 * 16), n32 = (int)n, ro = (int)row_offset;
     // An ordinary launch: 64 workgroups of a 256-CU device are resident together whenever fewer than four such
     // kernels run at once (one workgroup per CU: 110 KB of LDS); a cooperative launch would guarantee it but goes
@@ -1308,7 +1324,9 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     const int64_t nb = (n - k0) < B ? (n - k0) : B;
     const int64_t m2 = n - k0 - nb;
     double* Akk = A + k0 + k0 * lda;
-    GSS_TRY(dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s));
+    // (Wk's strict upper triangle is zero on entry and nothing ever writes there: zeroed once, and again only for
+    // the last panel, whose leading dimension differs)
+    if (k0 == 0 || nb != B) GSS_TRY(dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s));
     GSS_TRY(potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s, false));
     if (m2 > 0) {
       double* Ap = Akk + nb;                 // rows below the diagonal block
