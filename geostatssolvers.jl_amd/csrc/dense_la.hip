@@ -8,6 +8,7 @@
 // (<= 64 x 64) run in one workgroup out of LDS.
 #include "gss_internal.h"
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include "mfma_f64.h"
@@ -1200,7 +1201,11 @@ static int panel_workgroups() {
   }();
   return v;
 }
-static bool use_panel(int64_t n) { return n >= PANEL_MIN && n <= panel_max_rows(); }
+// set when a launch reported -1 (its workgroups were not all resident within the bounded spin, e.g. many such
+// kernels at once): the process goes back to the launch-per-block recursion from then on
+static std::atomic<bool> g_panel_off{false};
+void potrf_panel_disable() { g_panel_off.store(true); }
+static bool use_panel(int64_t n) { return !g_panel_off.load() && n >= PANEL_MIN && n <= panel_max_rows(); }
 constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets inside the kernel
 
 // scratch of potrf_inverse_f64 (doubles)

@@ -556,6 +556,7 @@ struct gss_krig {
   hipEvent_t fit_done = nullptr;
   bool fit_pending = false;
   int* fit_info = nullptr;
+  hipStream_t fit_stream = nullptr;  // stream of the fit in flight (a retry goes back on it)
   ~gss_krig() {
     if (fit_pending && fit_done) (void)hipEventSynchronize(fit_done);
     if (fit_done) (void)hipEventDestroy(fit_done);
@@ -787,6 +788,7 @@ static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
   GSS_TRY(krig_fit_plan(h, &fp));
   GSS_TRY(krig_fit_enqueue(h, fp, s));
   h->fit_info = fp.info;
+  h->fit_stream = s;
   if (!h->fit_done) GSS_HIP(hipEventCreateWithFlags(&h->fit_done, hipEventDisableTiming));
   GSS_HIP(hipEventRecord(h->fit_done, s));
   h->fit_pending = true;
@@ -804,8 +806,19 @@ static int32_t krig_fit_wait(gss_krig* h) {
   h->fit_ws.release();
   h->fit_info = nullptr;
   if (hinfo[0] < 0) {
+    // the single-launch factorisation gave up at a grid barrier (its workgroups were not resident together):
+    // once, on the launch-per-block path, which has no such requirement
     h->factored = false;
-    set_error("kriging fit: the factorisation kernel gave up waiting at a grid barrier (device shared with other work?)");
+    static thread_local bool retrying = false;
+    if (!retrying) {
+      potrf_panel_disable();
+      retrying = true;
+      int32_t rc = krig_factorize(h, h->fit_stream);
+      if (rc == GSS_OK) rc = krig_fit_wait(h);
+      retrying = false;
+      return rc;
+    }
+    set_error("kriging fit: the factorisation kernel gave up waiting at a grid barrier");
     return GSS_ERR_HIP;
   }
   if (hinfo[0] != 0) {

@@ -75,7 +75,9 @@ static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
   if (h < 0) {
-    set_error("%s: the factorisation kernel gave up waiting at a grid barrier (device shared with other work?)", what);
+    potrf_panel_disable();  // the next create runs on the launch-per-block path, which has no residency requirement
+    set_error("%s: the single-launch factorisation gave up waiting at a grid barrier (its workgroups were not resident "
+              "together); it is switched off for this process now -- call again", what);
     return GSS_ERR_HIP;
   }
   if (h != 0) {
