@@ -1212,8 +1212,8 @@ constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets in
 int64_t potrf_inverse_work_doubles(int64_t n) {
   if (n <= 2 * LEAF) return 0;
   if (use_panel(n)) {
-    const int64_t ldp = ((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB;
-    return ldp * (ldp + PANEL_NB);
+    const int64_t ldp = ((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB, n16 = (n + 15) / 16 * 16;
+    return ldp * (ldp + PANEL_NB) + (n16 != n ? 2 * n16 * n16 : 0);  // + the zero-padded copies of a ragged size
   }
   const int64_t n1 = split_point(n), n2 = n - n1;
   const int64_t a = potrf_inverse_work_doubles(n1), b = 2 * n1 * n2 + potrf_inverse_work_doubles(n2);
@@ -1224,6 +1224,19 @@ int64_t potrf_inverse_work_doubles(int64_t n) {
 static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw, int64_t n, int64_t row_offset,
                                  int* d_info, double* scr, bool keep_L, hipStream_t s, bool padded16) {
   if (n <= 0) return GSS_OK;
+  if (use_panel(n) && n % 16 != 0 && !padded16) {
+    // whole tiles through zero-padded copies at the head of the scratch (three copies and a fill: ~25 us against the
+    // 0.6 ms the launch chain would add)
+    const int64_t n16 = (n + 15) / 16 * 16;
+    double* Ap = scr;
+    double* Wp = scr + n16 * n16;
+    GSS_TRY(dev_zero_bytes(Ap, sizeof(double) * (size_t)(2 * n16 * n16), s));
+    GSS_TRY(copy_block(A, lda, n, n, Ap, n16, s));
+    GSS_TRY(potrf_inverse_rec(Ap, n16, Wp, n16, n, row_offset, d_info, scr + 2 * n16 * n16, keep_L, s, true));
+    GSS_TRY(copy_block(Ap, n16, n, n, A, lda, s));
+    GSS_TRY(copy_block(Wp, n16, n, n, W, ldw, s));
+    return GSS_OK;
+  }
   if (use_panel(n) && lda < PANEL_MAX_LD && ldw < PANEL_MAX_LD && (n % 16 == 0 || padded16)) {
     static bool attr = false;
     if (!attr) {
@@ -1253,8 +1266,8 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
       fprintf(stderr, "\n");
       long long lf[24] = {0};
       GSS_HIP(hipMemcpy(lf, reinterpret_cast<long long*>(bar + 16) + 128, sizeof(lf), hipMemcpyDeviceToHost));
-      fprintf(stderr, "leaf of step 1 (loaded | per step: tile factor, step done | L written | W done | end):");
-      for (int i = 1; i < 22; ++i) fprintf(stderr, " %.1f", (double)(lf[i] - lf[0]) * 0.01);
+      fprintf(stderr, "leaf of step 1 (block loaded | first tile factored | next tile factored, per step ... | end):");
+      for (int i = 1; i < 12; ++i) fprintf(stderr, " %.1f", (double)(lf[i] - lf[0]) * 0.01);
       fprintf(stderr, "\n");
     }
     return GSS_OK;
@@ -1371,32 +1384,12 @@ int32_t gss_dev_potrf_inverse(double* a, int64_t n, int64_t lda, double* w, int6
   GSS_REQUIRE(a != nullptr && w != nullptr && n >= 0 && lda >= n && ldw >= n, "gss_dev_potrf_inverse: bad arguments");
   if (n == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
-  DevBuf info, scr, pad;
+  DevBuf info, scr;
   GSS_TRY(info.alloc(sizeof(int)));
   const int64_t ws = potrf_inverse_work_doubles(n) > n * n ? potrf_inverse_work_doubles(n) : n * n;
   GSS_TRY(scr.alloc(sizeof(double) * (size_t)ws));
-  // a size that is not a multiple of 16 goes through zero-padded copies (what gss_krig_fit's own buffers are)
-  const int64_t n16 = (n + 15) / 16 * 16;
-  double *A = a, *W = w;
-  int64_t la = lda, lw = ldw;
-  if (n16 != n) {
-    GSS_TRY(pad.alloc(sizeof(double) * (size_t)(2 * n16 * n16)));
-    GSS_TRY(dev_zero_bytes(pad.p, pad.bytes, s));
-    A = pad.as<double>();
-    W = A + n16 * n16;
-    la = lw = n16;
-    GSS_HIP(hipMemcpy2DAsync(A, sizeof(double) * la, a, sizeof(double) * lda, sizeof(double) * n, n,
-                             hipMemcpyDeviceToDevice, s));
-  } else {
-    GSS_HIP(hipMemset2DAsync(w, sizeof(double) * ldw, 0, sizeof(double) * n, n, s));
-  }
-  GSS_TRY(potrf_inverse_f64(A, n, la, W, lw, scr.as<double>(), info.as<int>(), true, s, n16 != n));
-  if (n16 != n) {
-    GSS_HIP(hipMemcpy2DAsync(a, sizeof(double) * lda, A, sizeof(double) * la, sizeof(double) * n, n,
-                             hipMemcpyDeviceToDevice, s));
-    GSS_HIP(hipMemcpy2DAsync(w, sizeof(double) * ldw, W, sizeof(double) * lw, sizeof(double) * n, n,
-                             hipMemcpyDeviceToDevice, s));
-  }
+  GSS_HIP(hipMemset2DAsync(w, sizeof(double) * ldw, 0, sizeof(double) * n, n, s));
+  GSS_TRY(potrf_inverse_f64(a, n, lda, w, ldw, scr.as<double>(), info.as<int>(), true, s));
   int h = 0;
   GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
