@@ -301,7 +301,7 @@ def fftgs_leg(c):
     torch.cuda.synchronize()
     _lib.profile_enable(False)
     names = ("fftgs_noise", "fftgs_fwd", "fftgs_phase", "fftgs_inv", "fftgs_p1", "fftgs_p2", "fftgs_p3", "fftgs_p4",
-             "fftgs_p5")
+             "fftgs_p234", "fftgs_p5")   # p234: the three strided passes run slab by slab (GSS_FFTGS_SLAB)
     parts = {k: _lib.profile_read(k) for k in names}
     seq_ms = sum(v[0] / max(v[1], 1) for v in parts.values())
     # (b) the timed region: B realisations per call, HIP events on the launch stream around the whole region

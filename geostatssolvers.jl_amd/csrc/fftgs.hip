@@ -302,8 +302,10 @@ static int env_int(const char* name, int dflt) {
 
 // strided pass `mode` (0 forward, 1 inverse, 2 forward-phase-inverse) along y (axis 1) or z (axis 2)
 template <int MODE>
-static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s) {
-  const FusedGrid& f = h->fg;
+static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 = 0, int slab_nt = 0) {
+  FusedGrid f = h->fg;
+  f.slab_t0 = slab_t0;
+  f.slab_nt = slab_nt;
   const int L = axis == 1 ? f.n2 : f.n3, logL = axis == 1 ? f.l2 : f.l3, nouter = axis == 1 ? f.n3 : f.n2;
   const double2* tw = axis == 1 ? h->tw2.as<double2>() : h->tw3.as<double2>();
   const int64_t ostride = axis == 1 ? (int64_t)f.n2 * f.nhp : (int64_t)f.nhp;
@@ -316,8 +318,9 @@ static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s) {
                        tw, ostride, lstride, X, fh, mean);
   } else {
     const int txlog = axis == 1 ? h->txy_log : h->txz_log;
-    const unsigned blocks = (unsigned)(nouter * (f.nhp >> txlog));
+    const unsigned blocks = (unsigned)(nouter * (slab_nt > 0 ? slab_nt : (f.nhp >> txlog)));
     const size_t lds = ff_axis2_lds(L, txlog);
+    if (slab_nt > 0 && !(txlog == 3 && logL == 9 && h->axis_fast)) return GSS_ERR_UNSUPPORTED;
     if (txlog == 3 && logL == 9 && h->axis_fast)
       hipLaunchKernelGGL((ff_axis2_fast_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, tw, ostride, lstride,
                          X, fh, mean);
@@ -351,6 +354,7 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   f.nh = (int)g.nh;
   f.nhp = (f.nh + FF_PITCH_ALIGN - 1) / FF_PITCH_ALIGN * FF_PITCH_ALIGN;
   f.ntx = f.nhp / FF_TX;
+  f.slab_t0 = f.slab_nt = 0;
   h->fg = f;
   GSS_TRY(upload_twiddles(h->tw1, f.n1, s));
   GSS_TRY(upload_twiddles(h->tw2, f.n2, s));
@@ -535,6 +539,23 @@ static int32_t fftgs_fused_p1(gss_fftgs* h, uint64_t seed, int64_t real, const d
 }
 
 static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
+  // The three strided passes run slab by slab over the x tiles (GSS_FFTGS_SLAB tiles per slab, 0 = whole buffer per
+  // pass): a slab of 7 tiles (235 MB of the 1.1 GB half spectrum at 512^3) written by one pass is read back by the
+  // next while much of it is still in the 256 MB memory-side cache.  Measured 2.23 -> 2.09 ms per realisation
+  // (slabs of 5 ... 8 tiles within 1 %; 3 tiles 2.15 ms, 1 tile 2.52 ms: launches too small to fill the device).
+  static const int slab = env_int("GSS_FFTGS_SLAB", 7);
+  const FusedGrid& f = h->fg;
+  const bool can_slab = slab > 0 && h->axis_gen != 1 && h->txy_log == 3 && h->txz_log == 3 && f.l2 == 9 && f.l3 == 9 && h->axis_fast;
+  if (can_slab) {
+    ProfScope ps("fftgs_p234", s);
+    const int ntx = f.nhp >> 3;
+    for (int t0 = 0; t0 < ntx; t0 += slab) {
+      const int nt = t0 + slab <= ntx ? slab : ntx - t0;
+      GSS_TRY(launch_axis_mode<0>(h, 1, s, t0, nt));
+      GSS_TRY(launch_axis_mode<2>(h, 2, s, t0, nt));
+      GSS_TRY(launch_axis_mode<1>(h, 1, s, t0, nt));
+    }
+  } else {
   {
     ProfScope ps("fftgs_p2", s);
     launch_p2(h, s);
@@ -546,6 +567,7 @@ static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
   {
     ProfScope ps("fftgs_p4", s);
     GSS_TRY(launch_axis_mode<1>(h, 1, s));
+  }
   }
   {
     ProfScope ps("fftgs_p5", s);

@@ -49,6 +49,7 @@ struct FusedGrid {
   int nh;              // n1 / 2 + 1
   int nhp;             // row pitch of the half-spectrum buffer: nh rounded up to FF_PITCH_ALIGN
   int ntx;             // nhp / FF_TX
+  int slab_t0, slab_nt;  // strided passes restricted to the x tiles slab_t0 .. slab_t0 + slab_nt - 1 (slab_nt = 0: all)
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -925,6 +926,7 @@ __global__ __launch_bounds__(NT) void ff_axis2_fast_kernel(FusedGrid g, const do
   const int tid = threadIdx.x;
   const int ntx = g.nhp >> TXLOG;
   int tile = blockIdx.x;
+  if (g.slab_nt > 0) tile = (int)(blockIdx.x / (unsigned)g.slab_nt) * ntx + g.slab_t0 + (int)(blockIdx.x % (unsigned)g.slab_nt);
   if (TXLOG < 3) {
     constexpr int GL = 3 - (TXLOG < 3 ? TXLOG : 3);
     const int bb = blockIdx.x;
