@@ -557,6 +557,9 @@ __device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int6
   constexpr int NWK = NW > 4 ? NW - 2 : NW - 1;
   constexpr int LMAX = (L128_TILES + NW - 1) / NW;  // tiles per wave when the block is loaded
   constexpr int WMAX = (7 + NWK - 1) / NWK;        // tiles of a row of W per wave
+  // wave 0's chain carries no global stores when there is an idle wave: wave SW writes out the diagonal tiles (from
+  // LDS, one step later) and the one row tile wave 0 solves itself
+  constexpr int SW = NW > 4 ? 4 : 0;
   int ndbg = 0;
   auto stamp = [&] {
     if (dbg && threadIdx.x == 0) dbg[ndbg++] = (long long)wall_clock64();
@@ -633,29 +636,38 @@ __device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int6
   lds_barrier();
   stamp();
   int bad = 0;
+  d4_t Vmine = zero4, umine = zero4;  // wave 0: V of the tile it factored last, the row tile it solved last
   auto factor_tile = [&](int kk, const d4_t& t) {  // wave 0
     d4_t U, V, VT;
     int bc;
     potrf16_full<true>(t, S, S2, lane, &U, &V, &VT, &bc);
+    Vmine = V;
     if (bc >= 0 && bad == 0) bad = row_offset + 16 * kk + bc + 1;
     st(Tl, tile_id8(kk, kk), U);
     st(Vl, kk, V);
     st(VTl, kk, VT);
-    store_L(kk, kk, U);
-    if (dinv) store_W(kk, kk, VTl + kk * 256);
+    if (SW == 0) {  // (with more than four waves the idle wave SW takes the tile to global memory, see R(kk))
+      store_L(kk, kk, U);
+      if (dinv) store_W(kk, kk, VTl + kk * 256);
+    }
   };
   if (wave == 0) factor_tile(0, ld(Tl, tile_id8(0, 0)));
   lds_barrier();
   stamp();
   d4_t wreg[WMAX];
   for (int kk = 0; kk < nt; ++kk) {
-    // ---- R(kk): row kk of W (computed in T(kk-1)... no: in T(kk) below; stored here one step later), row solve
+    // ---- R(kk): row solve (wave 0 keeps V_kk and the tile it solves in registers: no LDS round trips on its chain)
     {
-      const d4_t V = ld(Vl, kk);
+      const d4_t V = wave == 0 ? Vmine : ld(Vl, kk);
       for (int j = kk + 1 + wave; j < nt; j += NW) {
         const d4_t u = xty(V, ld(Tl, tile_id8(kk, j)), zero4);
         st(Tl, tile_id8(kk, j), u);
-        store_L(kk, j, u);
+        if (SW == 0 || wave != 0) store_L(kk, j, u);
+        if (wave == 0) umine = u;  // (kk, kk + 1): wave 0 has one tile per row at most
+      }
+      if (SW != 0 && wave == SW) {  // the diagonal tile factored one phase ago
+        store_L(kk, kk, ld(Tl, tile_id8(kk, kk)));
+        if (dinv) store_W(kk, kk, VTl + kk * 256);
       }
     }
     lds_barrier();
@@ -664,11 +676,12 @@ __device__ __forceinline__ void leaf128_body(double* __restrict__ A, int n, int6
     const int ntr = m > 0 ? m * (m + 1) / 2 - 1 : 0;            // trailing tiles without (kk+1, kk+1)
     if (wave == 0) {
       if (m > 0) {
-        const d4_t x = ld(Tl, tile_id8(kk, kk + 1));
-        factor_tile(kk + 1, xty(-x, x, ld(Tl, tile_id8(kk + 1, kk + 1))));
+        factor_tile(kk + 1, xty(-umine, umine, ld(Tl, tile_id8(kk + 1, kk + 1))));
       }
       stamp();
-    } else if (wave != 4) {
+    } else if (wave == 4) {
+      if (SW != 0 && m > 0) store_L(kk, kk + 1, ld(Tl, tile_id8(kk, kk + 1)));  // the row tile wave 0 solved
+    } else {
       const int w = wave < 4 ? wave - 1 : wave - 2;
       int q = 0;
       for (int i = kk + 1; i < nt; ++i)
