@@ -183,6 +183,10 @@ struct gss_fftgs {
   int axis_fast = 1;            // 512-point lines: the pass-by-pass kernel with all loads issued up front
   int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
+  // slab order of the strided passes: helper streams 1 .. slab_ns-1 (slab i runs on stream i mod slab_ns, 0 = the caller's)
+  static constexpr int SLAB_MAX_STREAMS = 4;
+  hipStream_t slab_s[SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t slab_e0 = nullptr, slab_e[SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
   ~gss_fftgs() {
@@ -195,6 +199,14 @@ struct gss_fftgs {
       if (ev_p5[b]) (void)hipEventDestroy(ev_p5[b]);
     }
     if (ev_in) (void)hipEventDestroy(ev_in);
+    for (int i = 0; i < SLAB_MAX_STREAMS; ++i) {
+      if (slab_s[i]) {
+        (void)hipStreamSynchronize(slab_s[i]);
+        (void)hipStreamDestroy(slab_s[i]);
+      }
+      if (slab_e[i]) (void)hipEventDestroy(slab_e[i]);
+    }
+    if (slab_e0) (void)hipEventDestroy(slab_e0);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
     if (info) rocfft_execution_info_destroy(info);
@@ -539,21 +551,44 @@ static int32_t fftgs_fused_p1(gss_fftgs* h, uint64_t seed, int64_t real, const d
 }
 
 static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
-  // The three strided passes run slab by slab over the x tiles (GSS_FFTGS_SLAB tiles per slab, 0 = whole buffer per
-  // pass): a slab of 7 tiles (235 MB of the 1.1 GB half spectrum at 512^3) written by one pass is read back by the
-  // next while much of it is still in the 256 MB memory-side cache.  Measured 2.23 -> 2.09 ms per realisation
-  // (slabs of 5 ... 8 tiles within 1 %; 3 tiles 2.15 ms, 1 tile 2.52 ms: launches too small to fill the device).
-  static const int slab = env_int("GSS_FFTGS_SLAB", 7);
+  // The three strided passes run slab by slab over the x tiles: P2, P3, P4 on the tiles of slab 0, then slab 1, ...
+  // A slab (GSS_FFTGS_SLAB tiles; 2 tiles = 67 MB of the 1.1 GB half spectrum at 512^3) written by one pass is read
+  // back by the next from the 256 MB memory-side cache; consecutive slabs go to GSS_FFTGS_SLAB_STREAMS streams in
+  // turn (the caller's and helper streams fenced by events), so that the short launches of a slab -- two rounds of
+  // resident workgroups each -- overlap with those of its neighbours instead of draining the device 45 times per
+  // realisation.  Measured per 512^3 realisation: one launch per pass 2.23 ms; slabs of 7 tiles on one stream 2.09
+  // (1 tile: 2.52, the launches are too small); slabs of 2 tiles on 3 streams 1.93 (2 streams 1.93-1.97, 4 streams 1.96;
+  // 1 tile on 4 streams 1.95, 3 tiles on 3 streams 2.02).  GSS_FFTGS_SLAB=0: whole buffer per pass.
+  static const int slab = env_int("GSS_FFTGS_SLAB", 2);
+  static const int slab_streams = env_int("GSS_FFTGS_SLAB_STREAMS", 3);
   const FusedGrid& f = h->fg;
   const bool can_slab = slab > 0 && h->axis_gen != 1 && h->txy_log == 3 && h->txz_log == 3 && f.l2 == 9 && f.l3 == 9 && h->axis_fast;
   if (can_slab) {
     ProfScope ps("fftgs_p234", s);
     const int ntx = f.nhp >> 3;
-    for (int t0 = 0; t0 < ntx; t0 += slab) {
+    const int ns = slab_streams < 1 ? 1 : (slab_streams > gss_fftgs::SLAB_MAX_STREAMS ? gss_fftgs::SLAB_MAX_STREAMS : slab_streams);
+    if (ns > 1 && !h->slab_e0) {
+      GSS_HIP(hipEventCreateWithFlags(&h->slab_e0, hipEventDisableTiming));
+      for (int i = 1; i < ns; ++i) {
+        GSS_HIP(hipStreamCreateWithFlags(&h->slab_s[i], hipStreamNonBlocking));
+        GSS_HIP(hipEventCreateWithFlags(&h->slab_e[i], hipEventDisableTiming));
+      }
+    }
+    if (ns > 1) {
+      GSS_HIP(hipEventRecord(h->slab_e0, s));   // P1 (and whatever else the caller's stream holds) comes first
+      for (int i = 1; i < ns; ++i) GSS_HIP(hipStreamWaitEvent(h->slab_s[i], h->slab_e0, 0));
+    }
+    int islab = 0;
+    for (int t0 = 0; t0 < ntx; t0 += slab, ++islab) {
       const int nt = t0 + slab <= ntx ? slab : ntx - t0;
-      GSS_TRY(launch_axis_mode<0>(h, 1, s, t0, nt));
-      GSS_TRY(launch_axis_mode<2>(h, 2, s, t0, nt));
-      GSS_TRY(launch_axis_mode<1>(h, 1, s, t0, nt));
+      hipStream_t st = (islab % ns) ? h->slab_s[islab % ns] : s;
+      GSS_TRY(launch_axis_mode<0>(h, 1, st, t0, nt));
+      GSS_TRY(launch_axis_mode<2>(h, 2, st, t0, nt));
+      GSS_TRY(launch_axis_mode<1>(h, 1, st, t0, nt));
+    }
+    for (int i = 1; i < ns; ++i) {              // P5 waits for every slab
+      GSS_HIP(hipEventRecord(h->slab_e[i], h->slab_s[i]));
+      GSS_HIP(hipStreamWaitEvent(s, h->slab_e[i], 0));
     }
   } else {
   {
