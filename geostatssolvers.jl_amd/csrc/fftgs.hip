@@ -183,9 +183,9 @@ struct gss_fftgs {
   int axis_fast = 1;            // 512-point lines: the pass-by-pass kernel with all loads issued up front
   int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
-  // slab order of the strided passes: helper streams 1 .. slab_ns-1 (slab i runs on stream i mod slab_ns, 0 = the caller's)
+  // slab order of the strided passes: slab i runs on stream i mod ns (0 = the caller's, the others are helper streams
+  // of the process, slab_stream()); the events that fence them belong to the handle
   static constexpr int SLAB_MAX_STREAMS = 4;
-  hipStream_t slab_s[SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t slab_e0 = nullptr, slab_e[SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   double* Fh() const { return state.as<double>(); }
   double* scal() const { return state.as<double>() + NH; }
@@ -199,13 +199,11 @@ struct gss_fftgs {
       if (ev_p5[b]) (void)hipEventDestroy(ev_p5[b]);
     }
     if (ev_in) (void)hipEventDestroy(ev_in);
-    for (int i = 0; i < SLAB_MAX_STREAMS; ++i) {
-      if (slab_s[i]) {
-        (void)hipStreamSynchronize(slab_s[i]);
-        (void)hipStreamDestroy(slab_s[i]);
+    for (int i = 0; i < SLAB_MAX_STREAMS; ++i)
+      if (slab_e[i]) {
+        (void)hipEventSynchronize(slab_e[i]);   // the helper streams may still be working on this handle's buffers
+        (void)hipEventDestroy(slab_e[i]);
       }
-      if (slab_e[i]) (void)hipEventDestroy(slab_e[i]);
-    }
     if (slab_e0) (void)hipEventDestroy(slab_e0);
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
@@ -550,6 +548,16 @@ static int32_t fftgs_fused_p1(gss_fftgs* h, uint64_t seed, int64_t real, const d
   return GSS_OK;
 }
 
+// helper streams of the slab order, shared by every handle of the process (creating a stream costs milliseconds);
+// what runs on them is fenced by the calling handle's events on both sides
+static hipStream_t slab_stream(int i) {
+  static std::mutex mu;
+  static hipStream_t st[gss_fftgs::SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  std::lock_guard<std::mutex> lock(mu);
+  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
+  return st[i];
+}
+
 static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
   // The three strided passes run slab by slab over the x tiles: P2, P3, P4 on the tiles of slab 0, then slab 1, ...
   // A slab (GSS_FFTGS_SLAB tiles; 2 tiles = 67 MB of the 1.1 GB half spectrum at 512^3) written by one pass is read
@@ -567,27 +575,29 @@ static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
     ProfScope ps("fftgs_p234", s);
     const int ntx = f.nhp >> 3;
     const int ns = slab_streams < 1 ? 1 : (slab_streams > gss_fftgs::SLAB_MAX_STREAMS ? gss_fftgs::SLAB_MAX_STREAMS : slab_streams);
+    hipStream_t side[gss_fftgs::SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 1; i < ns; ++i) {
+      side[i] = slab_stream(i);
+      GSS_REQUIRE(side[i] != nullptr, "FFTGS: cannot create a helper stream");
+    }
     if (ns > 1 && !h->slab_e0) {
       GSS_HIP(hipEventCreateWithFlags(&h->slab_e0, hipEventDisableTiming));
-      for (int i = 1; i < ns; ++i) {
-        GSS_HIP(hipStreamCreateWithFlags(&h->slab_s[i], hipStreamNonBlocking));
-        GSS_HIP(hipEventCreateWithFlags(&h->slab_e[i], hipEventDisableTiming));
-      }
+      for (int i = 1; i < ns; ++i) GSS_HIP(hipEventCreateWithFlags(&h->slab_e[i], hipEventDisableTiming));
     }
     if (ns > 1) {
       GSS_HIP(hipEventRecord(h->slab_e0, s));   // P1 (and whatever else the caller's stream holds) comes first
-      for (int i = 1; i < ns; ++i) GSS_HIP(hipStreamWaitEvent(h->slab_s[i], h->slab_e0, 0));
+      for (int i = 1; i < ns; ++i) GSS_HIP(hipStreamWaitEvent(side[i], h->slab_e0, 0));
     }
     int islab = 0;
     for (int t0 = 0; t0 < ntx; t0 += slab, ++islab) {
       const int nt = t0 + slab <= ntx ? slab : ntx - t0;
-      hipStream_t st = (islab % ns) ? h->slab_s[islab % ns] : s;
+      hipStream_t st = (islab % ns) ? side[islab % ns] : s;
       GSS_TRY(launch_axis_mode<0>(h, 1, st, t0, nt));
       GSS_TRY(launch_axis_mode<2>(h, 2, st, t0, nt));
       GSS_TRY(launch_axis_mode<1>(h, 1, st, t0, nt));
     }
     for (int i = 1; i < ns; ++i) {              // P5 waits for every slab
-      GSS_HIP(hipEventRecord(h->slab_e[i], h->slab_s[i]));
+      GSS_HIP(hipEventRecord(h->slab_e[i], side[i]));
       GSS_HIP(hipStreamWaitEvent(s, h->slab_e[i], 0));
     }
   } else {
