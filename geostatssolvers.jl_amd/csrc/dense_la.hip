@@ -1341,33 +1341,90 @@ constexpr int64_t POTRF_PANEL = 1024;
 int64_t potrf_blocked_work_doubles(int64_t n) {
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
   const int64_t w = potrf_inverse_work_doubles(B);
-  return B * B + (w > B * B ? w : B * B) + n * B;
+  return B * B + (w > B * B ? w : B * B) + 2 * n * B;
 }
 
+// low-priority helper stream of the process for the look-ahead of potrf_blocked_f64 (fenced by events on both sides)
+static hipStream_t lookahead_stream() {
+  static std::mutex mu;
+  static hipStream_t st = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!st) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+  }
+  return st;
+}
+
+// Look-ahead: the trailing update of panel k is split into (a) the next 1 024 columns, which the next panel needs,
+// and (b) everything to the right of them.  (b) runs on a helper stream beside the next panel's single-launch
+// factorisation (64 workgroups: most of the device would idle) and its rows-below product; the panel column P is
+// double buffered for that.  Order of the updates of one column block: (b) of the earlier panels, then (a) of the
+// panel just before it (the caller's stream waits for the helper's event in front of every (a)).
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s) {
   GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
   double* Wk = work;           // B x B inverse of the diagonal block
   double* scr = Wk + B * B;    // scratch of the factor-and-inverse step (at least B x B)
   const int64_t wscr = potrf_inverse_work_doubles(B);
-  double* P = scr + (wscr > B * B ? wscr : B * B);     // (n - k0 - nb) x nb panel
-  for (int64_t k0 = 0; k0 < n; k0 += B) {
+  double* Pbuf[2];
+  Pbuf[0] = scr + (wscr > B * B ? wscr : B * B);   // (n - k0 - nb) x nb panel column, two of them
+  Pbuf[1] = Pbuf[0] + n * B;
+  static const bool la_on = [] {
+    const char* e = std::getenv("GSS_POTRF_LOOKAHEAD");
+    return !(e && e[0] == '0');
+  }();
+  hipStream_t side = (la_on && n > 2 * B) ? lookahead_stream() : nullptr;
+  hipEvent_t ev_p = nullptr, ev_b = nullptr;
+  if (side) {
+    GSS_HIP(hipEventCreateWithFlags(&ev_p, hipEventDisableTiming));
+    GSS_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+  }
+  bool b_pending = false;
+  int32_t rc = GSS_OK;
+  int ip = 0;
+  for (int64_t k0 = 0; k0 < n && rc == GSS_OK; k0 += B, ip ^= 1) {
     const int64_t nb = (n - k0) < B ? (n - k0) : B;
     const int64_t m2 = n - k0 - nb;
     double* Akk = A + k0 + k0 * lda;
+    double* P = Pbuf[ip];
     // (Wk's strict upper triangle is zero on entry and nothing ever writes there: zeroed once, and again only for
     // the last panel, whose leading dimension differs)
-    if (k0 == 0 || nb != B) GSS_TRY(dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s));
-    GSS_TRY(potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s, false));
-    if (m2 > 0) {
-      double* Ap = Akk + nb;                 // rows below the diagonal block
-      double* A22 = Akk + nb + nb * lda;
-      GSS_TRY(gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s, GEMM_TRI_B_UPPER));
-      GSS_TRY(copy_block(P, m2, m2, nb, Ap, lda, s));
-      GSS_TRY(gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s));
+    if (k0 == 0 || nb != B) rc = dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s);
+    if (rc == GSS_OK) rc = potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s, false);
+    if (rc != GSS_OK || m2 <= 0) continue;
+    double* Ap = Akk + nb;                 // rows below the diagonal block
+    double* A22 = Akk + nb + nb * lda;
+    rc = gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s, GEMM_TRI_B_UPPER);
+    if (rc == GSS_OK) rc = copy_block(P, m2, m2, nb, Ap, lda, s);
+    if (rc != GSS_OK) continue;
+    if (!side) {
+      rc = gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s);
+      continue;
+    }
+    const int64_t nbn = m2 < B ? m2 : B, m3 = m2 - nbn;
+    if (b_pending && hipStreamWaitEvent(s, ev_b, 0) != hipSuccess) rc = GSS_ERR_HIP;   // (b) of the panel before
+    b_pending = false;
+    // (a) the next column block, lower tiles; (b) starts behind it, so that (a) -- which the next panel waits for --
+    // has the device to itself
+    if (rc == GSS_OK) rc = gemm_f64(m2, nbn, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s);
+    if (rc == GSS_OK && hipEventRecord(ev_p, s) != hipSuccess) rc = GSS_ERR_HIP;
+    if (rc == GSS_OK && m3 > 0) {
+      if (hipStreamWaitEvent(side, ev_p, 0) != hipSuccess) rc = GSS_ERR_HIP;
+      if (rc == GSS_OK)
+        rc = gemm_f64(m3, m3, nb, -1.0, P + nbn, 1, m2, P + nbn, m2, 1, 1.0, A22 + nbn + nbn * lda, 1, lda, true, side);
+      if (rc == GSS_OK && hipEventRecord(ev_b, side) != hipSuccess) rc = GSS_ERR_HIP;
+      b_pending = rc == GSS_OK;
     }
   }
-  return GSS_OK;
+  if (side) {
+    // whatever happened, the caller's stream comes back behind the helper (the buffers belong to the caller)
+    if (hipEventRecord(ev_b, side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_b, 0);
+    (void)hipEventDestroy(ev_p);
+    (void)hipEventDestroy(ev_b);
+  }
+  return rc;
 }
 
 }  // namespace gss
