@@ -1345,7 +1345,7 @@ int64_t potrf_blocked_work_doubles(int64_t n) {
 }
 
 // low-priority helper stream of the process for the look-ahead of potrf_blocked_f64 (fenced by events on both sides)
-static hipStream_t lookahead_stream() {
+hipStream_t lookahead_stream() {
   static std::mutex mu;
   static hipStream_t st = nullptr;
   std::lock_guard<std::mutex> lock(mu);
@@ -1397,10 +1397,10 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     double* Ap = Akk + nb;                 // rows below the diagonal block
     double* A22 = Akk + nb + nb * lda;
     rc = gemm_f64(m2, nb, nb, 1.0, Ap, 1, lda, Wk, nb, 1, 0.0, P, 1, m2, false, s, GEMM_TRI_B_UPPER);
-    if (rc == GSS_OK) rc = copy_block(P, m2, m2, nb, Ap, lda, s);
     if (rc != GSS_OK) continue;
     if (!side) {
-      rc = gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s);
+      rc = copy_block(P, m2, m2, nb, Ap, lda, s);
+      if (rc == GSS_OK) rc = gemm_f64(m2, m2, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s);
       continue;
     }
     const int64_t nbn = m2 < B ? m2 : B, m3 = m2 - nbn;
@@ -1410,9 +1410,11 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     // has the device to itself
     if (rc == GSS_OK) rc = gemm_f64(m2, nbn, nb, -1.0, P, 1, m2, P, m2, 1, 1.0, A22, 1, lda, true, s);
     if (rc == GSS_OK && hipEventRecord(ev_p, s) != hipSuccess) rc = GSS_ERR_HIP;
-    if (rc == GSS_OK && m3 > 0) {
+    if (rc == GSS_OK) {
+      // the helper: the factor's columns P -> A (nothing on the caller's stream reads them again), then (b)
       if (hipStreamWaitEvent(side, ev_p, 0) != hipSuccess) rc = GSS_ERR_HIP;
-      if (rc == GSS_OK)
+      if (rc == GSS_OK) rc = copy_block(P, m2, m2, nb, Ap, lda, side);
+      if (rc == GSS_OK && m3 > 0)
         rc = gemm_f64(m3, m3, nb, -1.0, P + nbn, 1, m2, P + nbn, m2, 1, 1.0, A22 + nbn + nbn * lda, 1, lda, true, side);
       if (rc == GSS_OK && hipEventRecord(ev_b, side) != hipSuccess) rc = GSS_ERR_HIP;
       b_pending = rc == GSS_OK;
@@ -1424,6 +1426,80 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     (void)hipEventDestroy(ev_p);
     (void)hipEventDestroy(ev_b);
   }
+  return rc;
+}
+
+// LUGS preprocess, data columns (lu.jl:134-139 as one right-looking factorisation of [C11 . ; C21 C22] over the data
+// columns): on return C11 holds L11 (lower triangle), C21 (mb x nd, leading dimension ld21) holds C21 L11^-T -- rows
+// past the ns simulation rows ride along, the caller puts z1' there and reads L11^-1 z1 back --, and the lower tiles
+// of C22 hold C22 - A21 A21'.  Per panel of POTRF_PANEL data columns: single-launch factor and inverse of the diagonal
+// block, the rows below it in C11 and C21, the update of the rest of C11 and of the NEXT column block of C21 on the
+// caller's stream; the update of the remaining columns of C21 and the panel's share of the SYRK on C22 (ns^2 x 1 024:
+// the bulk) go to the helper stream and run beside the next panel.  No inverse of L11 is formed.
+int64_t potrf_joint_work_doubles(int64_t nd, int64_t mb) {
+  const int64_t B = nd < POTRF_PANEL ? nd : POTRF_PANEL;
+  const int64_t w = potrf_inverse_work_doubles(B);
+  return B * B + (w > B * B ? w : B * B) + 2 * (nd + mb) * B;
+}
+
+int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_t ld21, double* C22, int64_t ns,
+                        int* d_info, double* work, hipStream_t s) {
+  GSS_TRY(dev_zero_bytes(d_info, sizeof(int), s));
+  const int64_t B = nd < POTRF_PANEL ? nd : POTRF_PANEL;
+  double* Wk = work;
+  double* scr = Wk + B * B;
+  const int64_t wscr = potrf_inverse_work_doubles(B);
+  double* Pt[2];
+  double* Pb[2];
+  Pt[0] = scr + (wscr > B * B ? wscr : B * B);
+  Pt[1] = Pt[0] + nd * B;
+  Pb[0] = Pt[1] + nd * B;
+  Pb[1] = Pb[0] + mb * B;
+  hipStream_t side = lookahead_stream();
+  GSS_REQUIRE(side != nullptr, "potrf_joint: cannot create the helper stream");
+  hipEvent_t ev_s = nullptr, ev_b = nullptr;
+  GSS_HIP(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
+  GSS_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+  bool b_pending = false;
+  int32_t rc = GSS_OK;
+  int ip = 0;
+  for (int64_t k0 = 0; k0 < nd && rc == GSS_OK; k0 += B, ip ^= 1) {
+    const int64_t nb = (nd - k0) < B ? (nd - k0) : B;
+    const int64_t mt = nd - k0 - nb;              // rows of C11 below the diagonal block
+    double* Akk = C11 + k0 + k0 * nd;
+    double* Atop = Akk + nb;                      // mt x nb
+    double* Abot = C21 + k0 * ld21;               // mb x nb
+    double *Ptop = Pt[ip], *Pbot = Pb[ip];
+    if (k0 == 0 || nb != B) rc = dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s);
+    if (rc == GSS_OK) rc = potrf_inverse_rec(Akk, nd, Wk, nb, nb, k0, d_info, scr, true, s, false);
+    // rows below: [Ptop; Pbot] = [Atop; Abot] Wk'
+    if (rc == GSS_OK && mt > 0) rc = gemm_f64(mt, nb, nb, 1.0, Atop, 1, nd, Wk, nb, 1, 0.0, Ptop, 1, mt, false, s, GEMM_TRI_B_UPPER);
+    if (rc == GSS_OK && mt > 0) rc = copy_block(Ptop, mt, mt, nb, Atop, nd, s);
+    if (rc == GSS_OK) rc = gemm_f64(mb, nb, nb, 1.0, Abot, 1, ld21, Wk, nb, 1, 0.0, Pbot, 1, mb, false, s, GEMM_TRI_B_UPPER);
+    if (rc == GSS_OK) rc = copy_block(Pbot, mb, mb, nb, Abot, ld21, s);
+    if (rc != GSS_OK) break;
+    // the helper's work of the panel before touched the columns of C21 that are updated next
+    if (b_pending && hipStreamWaitEvent(s, ev_b, 0) != hipSuccess) rc = GSS_ERR_HIP;
+    b_pending = false;
+    const int64_t nbn = mt < B ? mt : B;          // the next panel's columns
+    if (rc == GSS_OK && mt > 0) {
+      // rest of C11 (lower tiles) and the next column block of C21: what the next panel reads
+      rc = gemm_f64(mt, mt, nb, -1.0, Ptop, 1, mt, Ptop, mt, 1, 1.0, Akk + nb + nb * nd, 1, nd, true, s);
+      if (rc == GSS_OK)
+        rc = gemm_f64(mb, nbn, nb, -1.0, Pbot, 1, mb, Ptop, mt, 1, 1.0, Abot + nb * ld21, 1, ld21, false, s);
+    }
+    if (rc == GSS_OK && hipEventRecord(ev_s, s) != hipSuccess) rc = GSS_ERR_HIP;
+    if (rc == GSS_OK && hipStreamWaitEvent(side, ev_s, 0) != hipSuccess) rc = GSS_ERR_HIP;
+    if (rc == GSS_OK && mt > nbn)                 // the columns of C21 behind the next block
+      rc = gemm_f64(mb, mt - nbn, nb, -1.0, Pbot, 1, mb, Ptop + nbn, mt, 1, 1.0, Abot + (nb + nbn) * ld21, 1, ld21, false, side);
+    if (rc == GSS_OK && ns > 0)                   // this panel's share of C22 -= A21 A21' (lower tiles)
+      rc = gemm_f64(ns, ns, nb, -1.0, Pbot, 1, mb, Pbot, mb, 1, 1.0, C22, 1, ns, true, side);
+    if (rc == GSS_OK && hipEventRecord(ev_b, side) != hipSuccess) rc = GSS_ERR_HIP;
+    b_pending = rc == GSS_OK;
+  }
+  if (hipEventRecord(ev_b, side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_b, 0);
+  (void)hipEventDestroy(ev_s);
+  (void)hipEventDestroy(ev_b);
   return rc;
 }
 

@@ -672,6 +672,14 @@ int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t 
 // Cholesky of a large block without its inverse, by panels (work: potrf_blocked_work_doubles(n) doubles).
 int64_t potrf_blocked_work_doubles(int64_t n);
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s);
+// Data columns of the LUGS preprocess as one blocked factorisation of [C11 . ; C21 C22] (dense_la.hip): C11 <- L11,
+// C21 (mb >= ns rows, leading dimension ld21) <- C21 L11^-T, lower tiles of C22 <- C22 - A21 A21' (first ns rows of C21).
+// the process's low-priority helper stream of those look-aheads (nullptr if it cannot be created); work put on it
+// must be fenced by events against the caller's stream on both sides
+hipStream_t lookahead_stream();
+int64_t potrf_joint_work_doubles(int64_t nd, int64_t mb);
+int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_t ld21, double* C22, int64_t ns,
+                        int* d_info, double* work, hipStream_t s);
 // lu.hip: A <- unit lower-triangular L of the partial-pivot LU P A = L U (`lu(A).L`, lu.jl:70); ipiv: n device ints,
 // *d_info (zeroed by the caller) = 1 + column of an exactly zero pivot.  mirror_lower: upper triangle <- lower'.
 int32_t getrf_unit_lower_f64(double* A, int64_t n, int64_t lda, int* ipiv, int* d_info, hipStream_t s);

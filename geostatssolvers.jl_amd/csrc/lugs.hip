@@ -156,8 +156,42 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
   GSS_TRY(dev_zero_bytes(info.p, sizeof(int), s));
   if (ns > 0) {
     double* C22 = h->L22();
-    GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, s));   // lu.jl:124
-    if (nd > 0) {
+    // C22 is not needed before the first trailing update: with conditioning data on the Cholesky path it is assembled
+    // on the helper stream, in front of the products potrf_joint_f64 puts there, beside the first data panel
+    hipStream_t side = (nd > 0 && !use_lu) ? lookahead_stream() : nullptr;
+    if (side) {
+      hipEvent_t ev = nullptr;
+      GSS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      GSS_HIP(hipEventRecord(ev, s));              // the coordinates are on the device
+      GSS_HIP(hipStreamWaitEvent(side, ev, 0));
+      GSS_HIP(hipEventDestroy(ev));
+    }
+    GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, side ? side : s));   // lu.jl:124
+    if (nd > 0 && !use_lu) {
+      // Cholesky path: the data columns of [C11 . ; C21 C22] as one blocked factorisation (potrf_joint_f64): L11,
+      // A21 = C21 L11^-T (= B12', lu.jl:135) and C22 - A21 A21' (:139) without forming inv(L11); z1' rides along as
+      // one more row of C21 and comes back as (L11^-1 z1)', so that d2 = A21 (L11 \ z1) (:138) is one GEMV.
+      const int64_t mb = ns + 2;   // row ns: z1', row ns + 1: zero (an even leading dimension keeps the 16-byte loads)
+      DevBuf C11, C21, w, work, gwork;
+      GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
+      GSS_TRY(C21.alloc(sizeof(double) * (size_t)(mb * nd)));
+      GSS_TRY(w.alloc(sizeof(double) * (size_t)nd));
+      GSS_TRY(work.alloc(sizeof(double) * (size_t)potrf_joint_work_doubles(nd, mb)));
+      GSS_TRY(gwork.alloc(sizeof(double) * (size_t)gemv_work_doubles(false, ns, nd)));
+      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxd.as<double>(), nd, C11.as<double>(), nd, s));  // :131
+      GSS_TRY(dev_zero_bytes(C21.p, C21.bytes, s));
+      GSS_TRY(cov_pairwise_dev(h->vg, dxd.as<double>(), nd, dxs.as<double>(), ns, C21.as<double>(), mb, s));  // :132
+      GSS_HIP(hipMemcpy2DAsync(C21.as<double>() + ns, sizeof(double) * mb, h->z1.p, sizeof(double), sizeof(double),
+                               (size_t)nd, hipMemcpyDeviceToDevice, s));
+      GSS_TRY(potrf_joint_f64(C11.as<double>(), nd, C21.as<double>(), mb, mb, C22, ns, info.as<int>(),
+                              work.as<double>(), s));
+      GSS_TRY(check_info(info, "data covariance C11", s));
+      GSS_HIP(hipMemcpy2DAsync(w.p, sizeof(double), C21.as<double>() + ns, sizeof(double) * mb, sizeof(double),
+                               (size_t)nd, hipMemcpyDeviceToDevice, s));
+      GSS_TRY(gemv_f64(false, ns, nd, C21.as<double>(), mb, w.as<double>(), h->d2(), gwork.as<double>(), s));
+      GSS_HIP(hipStreamSynchronize(s));
+    }
+    if (nd > 0 && use_lu) {
       DevBuf C11, W11, C21, A21, w, scr, gwork, ipiv;
       GSS_TRY(ipiv.alloc(sizeof(int) * (size_t)nd));
       GSS_TRY(C11.alloc(sizeof(double) * (size_t)(nd * nd)));
