@@ -19,7 +19,8 @@ def _mk(kind, **kw):
     return ctor(gss.MetricBall(tuple(radii)), **kw) if radii is not None else ctor(**kw)
 
 
-@pytest.mark.parametrize("dims,ndata", [((100,), 5), ((100,), 0), ((30, 20), 40), ((12, 10, 8), 100), ((70, 70), 0)])
+@pytest.mark.parametrize("dims,ndata", [((100,), 5), ((100,), 0), ((30, 20), 40), ((12, 10, 8), 100), ((70, 70), 0),
+                                        ((70, 60), 1500)])   # two ragged data panels, three ragged simulation panels
 def test_factor_and_realisations_match_oracle(dims, ndata):
     from gss.engine import LUGSHandle
     cent = offt.grid_centroids(dims)
