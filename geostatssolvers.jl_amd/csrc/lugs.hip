@@ -14,6 +14,8 @@
 //   lu.jl:217-221  scatter to dlocs / slocs, add the mean when unconditional
 // State kept in HBM: L22 (ns x ns, column-major, strict upper triangle zeroed) followed by d2 (ns).
 #include "gss_internal.h"
+
+#include <mutex>
 #include "philox.h"
 
 #include <cmath>
@@ -69,6 +71,28 @@ struct gss_lugs {
   double* L22() const { return state.as<double>(); }
   double* d2() const { return state.as<double>() + ns * ns; }
 };
+
+constexpr int LUGS_KC = 6;   // column blocks of L22 in gss_lugs_realize
+
+// Y(i, r) = sum over the column blocks c whose first column is <= i of part_c(i, r), in block order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int nchunk, int64_t kc,
+                                                           int64_t ns, int64_t R, double* __restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (i >= ns) return;
+  double acc = 0.0;
+  for (int c = 0; c < nchunk && (int64_t)c * kc <= i; ++c) acc += part[((int64_t)c * R + r) * ns + i];
+  Y[r * ns + i] = acc;
+}
+
+// helper streams of the process for gss_lugs_realize (fenced by events on both sides of every use)
+static hipStream_t realize_stream(int i) {
+  static std::mutex mu;
+  static hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::lock_guard<std::mutex> lock(mu);
+  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
+  return st[i];
+}
 
 static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   int h = 0;
@@ -329,11 +353,54 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
     weff = wmix.as<double>();
   }
   GSS_TRY(Y2.alloc(sizeof(double) * (size_t)(R * ns)));
+  DevBuf Ypart;
   if (ns) {
     ProfScope ps("lugs_gemm", s);
     // Y2 (ns x R, column-major) = L22 * W                                                      // lu.jl:211
-    GSS_TRY(gemm_f64(ns, R, ns, 1.0, h->L22(), 1, ns, weff, 1, ns, 0.0, Y2.as<double>(), 1, ns, false, s,
-                     4 /* L22 is lower triangular: row tile i0 needs k < i0 + T only */));
+    // A tall product with few columns is a handful of workgroups that each walk the whole of K (one memory round
+    // trip per 16-deep stage: 1.2 ms for 12 288 x 100, an order of magnitude above the time to read L22).  It is
+    // therefore cut along K into LUGS_KC column blocks of L22 -- block c only reaches the rows from its first column
+    // down --, the blocks run side by side on the caller's and three helper streams into partial results, and a
+    // kernel adds the partials in fixed order (the result does not depend on timing).
+    static const bool split_on = [] {
+      const char* e = std::getenv("GSS_LUGS_SPLITK");
+      return !(e && e[0] == '0');
+    }();
+    hipStream_t hs[4] = {s, nullptr, nullptr, nullptr};
+    bool split = split_on && ns >= 4096 && R <= 512;
+    for (int i = 1; i < 4 && split; ++i) {
+      hs[i] = realize_stream(i);
+      if (!hs[i]) split = false;
+    }
+    if (!split) {
+      GSS_TRY(gemm_f64(ns, R, ns, 1.0, h->L22(), 1, ns, weff, 1, ns, 0.0, Y2.as<double>(), 1, ns, false, s,
+                       4 /* L22 is lower triangular: row tile i0 needs k < i0 + T only */));
+    } else {
+      const int64_t kc = ((ns + LUGS_KC - 1) / LUGS_KC + 127) / 128 * 128;   // columns per block, multiple of 128
+      const int nchunk = (int)((ns + kc - 1) / kc);
+      GSS_TRY(Ypart.alloc(sizeof(double) * (size_t)(R * ns) * (size_t)nchunk));
+      hipEvent_t e0 = nullptr, e1[4] = {nullptr, nullptr, nullptr, nullptr};
+      GSS_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      GSS_HIP(hipEventRecord(e0, s));
+      for (int i = 1; i < 4; ++i) GSS_HIP(hipStreamWaitEvent(hs[i], e0, 0));
+      int32_t rc = GSS_OK;
+      for (int c = 0; c < nchunk && rc == GSS_OK; ++c) {
+        const int64_t c0 = (int64_t)c * kc, k = (ns - c0) < kc ? (ns - c0) : kc;
+        rc = gemm_f64(ns - c0, R, k, 1.0, h->L22() + c0 + c0 * ns, 1, ns, weff + c0, 1, ns, 0.0,
+                      Ypart.as<double>() + (int64_t)c * R * ns + c0, 1, ns, false, hs[c % 4], 4);
+      }
+      for (int i = 1; i < 4; ++i) {
+        GSS_HIP(hipEventCreateWithFlags(&e1[i], hipEventDisableTiming));
+        GSS_HIP(hipEventRecord(e1[i], hs[i]));
+        GSS_HIP(hipStreamWaitEvent(s, e1[i], 0));
+        GSS_HIP(hipEventDestroy(e1[i]));
+      }
+      GSS_HIP(hipEventDestroy(e0));
+      GSS_TRY(rc);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)R), dim3(256), 0, s,
+                         Ypart.as<double>(), nchunk, kc, ns, R, Y2.as<double>());
+      GSS_HIP(hipGetLastError());
+    }
   }
   const double add = nd == 0 ? h->mean : 0.0;                                                   // lu.jl:221
   hipLaunchKernelGGL(lugs_scatter_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)R), dim3(256), 0, s,
