@@ -1376,10 +1376,10 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     return !(e && e[0] == '0');
   }();
   hipStream_t side = (la_on && n > 2 * B) ? lookahead_stream() : nullptr;
-  hipEvent_t ev_p = nullptr, ev_b = nullptr;
+  ScopedEvent ev_p, ev_b;
   if (side) {
-    GSS_HIP(hipEventCreateWithFlags(&ev_p, hipEventDisableTiming));
-    GSS_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+    GSS_HIP(ev_p.create());
+    GSS_HIP(ev_b.create());
   }
   bool b_pending = false;
   int32_t rc = GSS_OK;
@@ -1423,8 +1423,6 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
   if (side) {
     // whatever happened, the caller's stream comes back behind the helper (the buffers belong to the caller)
     if (hipEventRecord(ev_b, side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_b, 0);
-    (void)hipEventDestroy(ev_p);
-    (void)hipEventDestroy(ev_b);
   }
   return rc;
 }
@@ -1457,9 +1455,9 @@ int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_
   Pb[1] = Pb[0] + mb * B;
   hipStream_t side = lookahead_stream();
   GSS_REQUIRE(side != nullptr, "potrf_joint: cannot create the helper stream");
-  hipEvent_t ev_s = nullptr, ev_b = nullptr;
-  GSS_HIP(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
-  GSS_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+  ScopedEvent ev_s, ev_b;
+  GSS_HIP(ev_s.create());
+  GSS_HIP(ev_b.create());
   bool b_pending = false;
   int32_t rc = GSS_OK;
   int ip = 0;
@@ -1498,8 +1496,6 @@ int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_
     b_pending = rc == GSS_OK;
   }
   if (hipEventRecord(ev_b, side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_b, 0);
-  (void)hipEventDestroy(ev_s);
-  (void)hipEventDestroy(ev_b);
   return rc;
 }
 

@@ -674,6 +674,21 @@ int64_t potrf_blocked_work_doubles(int64_t n);
 int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double* work, hipStream_t s);
 // Data columns of the LUGS preprocess as one blocked factorisation of [C11 . ; C21 C22] (dense_la.hip): C11 <- L11,
 // C21 (mb >= ns rows, leading dimension ld21) <- C21 L11^-T, lower tiles of C22 <- C22 - A21 A21' (first ns rows of C21).
+// An event that lives for one call (timing disabled): created on demand, destroyed when the scope ends -- also on the
+// early returns of GSS_TRY / GSS_HIP.  (Destroying an event that a stream still waits for is allowed: the runtime
+// releases it once the wait has been satisfied.)
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ScopedEvent() = default;
+  ScopedEvent(const ScopedEvent&) = delete;
+  ScopedEvent& operator=(const ScopedEvent&) = delete;
+  ~ScopedEvent() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  hipError_t create() { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+  operator hipEvent_t() const { return e; }
+};
+
 // the process's low-priority helper stream of those look-aheads (nullptr if it cannot be created); work put on it
 // must be fenced by events against the caller's stream on both sides
 hipStream_t lookahead_stream();

@@ -184,11 +184,10 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
     // on the helper stream, in front of the products potrf_joint_f64 puts there, beside the first data panel
     hipStream_t side = (nd > 0 && !use_lu) ? lookahead_stream() : nullptr;
     if (side) {
-      hipEvent_t ev = nullptr;
-      GSS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ScopedEvent ev;
+      GSS_HIP(ev.create());
       GSS_HIP(hipEventRecord(ev, s));              // the coordinates are on the device
       GSS_HIP(hipStreamWaitEvent(side, ev, 0));
-      GSS_HIP(hipEventDestroy(ev));
     }
     GSS_TRY(cov_pairwise_dev(h->vg, dxs.as<double>(), ns, dxs.as<double>(), ns, C22, ns, side ? side : s));   // lu.jl:124
     if (nd > 0 && !use_lu) {
@@ -379,8 +378,8 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
       const int64_t kc = ((ns + LUGS_KC - 1) / LUGS_KC + 127) / 128 * 128;   // columns per block, multiple of 128
       const int nchunk = (int)((ns + kc - 1) / kc);
       GSS_TRY(Ypart.alloc(sizeof(double) * (size_t)(R * ns) * (size_t)nchunk));
-      hipEvent_t e0 = nullptr, e1[4] = {nullptr, nullptr, nullptr, nullptr};
-      GSS_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      ScopedEvent e0, e1[4];
+      GSS_HIP(e0.create());
       GSS_HIP(hipEventRecord(e0, s));
       for (int i = 1; i < 4; ++i) GSS_HIP(hipStreamWaitEvent(hs[i], e0, 0));
       int32_t rc = GSS_OK;
@@ -389,13 +388,11 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
         rc = gemm_f64(ns - c0, R, k, 1.0, h->L22() + c0 + c0 * ns, 1, ns, weff + c0, 1, ns, 0.0,
                       Ypart.as<double>() + (int64_t)c * R * ns + c0, 1, ns, false, hs[c % 4], 4);
       }
-      for (int i = 1; i < 4; ++i) {
-        GSS_HIP(hipEventCreateWithFlags(&e1[i], hipEventDisableTiming));
+      for (int i = 1; i < 4; ++i) {   // the caller's stream comes back behind the helpers whatever happened above
+        GSS_HIP(e1[i].create());
         GSS_HIP(hipEventRecord(e1[i], hs[i]));
         GSS_HIP(hipStreamWaitEvent(s, e1[i], 0));
-        GSS_HIP(hipEventDestroy(e1[i]));
       }
-      GSS_HIP(hipEventDestroy(e0));
       GSS_TRY(rc);
       hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)R), dim3(256), 0, s,
                          Ypart.as<double>(), nchunk, kc, ns, R, Y2.as<double>());
