@@ -218,6 +218,34 @@ def test_fused_pipeline_512_cube_properties():
     h.close()
 
 
+def test_slab_order_of_the_strided_passes_changes_nothing():
+    """512-point y and z lines run their three strided passes slab by slab over the x tiles, slabs alternating over
+    three streams (GSS_FFTGS_SLAB / GSS_FFTGS_SLAB_STREAMS, read once per process): the realisations must be bit for bit
+    those of one launch per pass.  Two subprocesses, a grid with a ragged last slab (5 x tiles, 2 per slab)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import gss\n"
+        "from gss.engine import FFTGSHandle\n"
+        "h = FFTGSHandle(gss.ExponentialVariogram(range=9.0), (64, 512, 512), mean=0.5)\n"
+        "z = h.realize(11, 3, 2, device=True)\n"
+        "torch.cuda.synchronize()\n"
+        "print('DIGEST', hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest(), float(z.std()))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geostatssolvers.jl_amd"))
+    outs = []
+    for env_slab in ("0", "2"):
+        env = dict(os.environ, GSS_FFTGS_SLAB=env_slab)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
+    assert abs(float(outs[0].split()[2]) - 1.0) < 0.05
+
+
 @pytest.mark.parametrize("dims", POW2_GRIDS)
 def test_fused_spectrum_matches_oracle(dims):
     """On power-of-two 3-D grids gss_fftgs_create builds F on the library's own passes (covariance rows generated
