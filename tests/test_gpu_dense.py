@@ -121,6 +121,35 @@ def test_potrf_inverse_single_launch_panel(n):
     assert np.all(gotW[n:, :] == 7.0) and np.all(gotW[:, n:] == 7.0)
 
 
+def test_potrf_inverse_launch_per_block_path_stays_alive():
+    """GSS_PANEL_MAX=0 switches the single-launch kernel off (the path a process falls back to when a launch reports
+    that its workgroups did not all arrive): same answers from the launch-per-block recursion.  The switch is read once
+    per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from gss import _lib\n"
+        "l = _lib.lib()\n"
+        "for n in (700, 1000, 1537):\n"
+        "    rng = np.random.default_rng(n)\n"
+        "    G = rng.normal(size=(n, n + 8)); A = G @ G.T / n + np.eye(n)\n"
+        "    dA = torch.from_numpy(A.copy()).cuda(); dW = torch.zeros((n, n), dtype=torch.float64, device='cuda')\n"
+        "    _lib.check(l.gss_dev_potrf_inverse(_lib.ptr(dA), n, n, _lib.ptr(dW), n, _lib.current_stream()))\n"
+        "    L = np.linalg.cholesky(A); W = dW.cpu().numpy().T\n"
+        "    assert np.max(np.abs(np.tril(dA.cpu().numpy().T) - L)) < 1e-10 * np.max(np.abs(L))\n"
+        "    assert np.max(np.abs(W @ L - np.eye(n))) < 1e-9\n"
+        "print('RECURSION OK')\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSS_PANEL_MAX="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "RECURSION OK" in r.stdout, r.stderr[-2000:]
+
+
 def test_potrf_inverse_panel_reports_the_pivot():
     from gss import _lib
     l = _lib.lib()
