@@ -1257,6 +1257,13 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
       attr = true;
     }
+    // test hook: GSS_PANEL_FAIL=1 makes the first such launch of the process report what a launch whose workgroups did
+    // not all arrive reports (*d_info = -1), so that the callers' recovery (potrf_panel_disable, retry) can be exercised
+    static std::atomic<bool> fail_once{std::getenv("GSS_PANEL_FAIL") != nullptr};
+    if (fail_once.exchange(false)) {
+      GSS_HIP(hipMemsetAsync(d_info, 0xFF, sizeof(int), s));
+      return GSS_OK;
+    }
     unsigned* bar = panel_barrier_words(s);
     GSS_REQUIRE(bar != nullptr, "potrf_inverse: no memory for the barrier words");
     static const bool times = std::getenv("GSS_PANEL_TIMES") != nullptr;

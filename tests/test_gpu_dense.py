@@ -150,6 +150,56 @@ def test_potrf_inverse_launch_per_block_path_stays_alive():
     assert r.returncode == 0 and "RECURSION OK" in r.stdout, r.stderr[-2000:]
 
 
+def test_recovery_when_the_single_launch_kernel_gives_up():
+    """A launch whose workgroups do not all arrive within the bounded spin reports -1 (GSS_PANEL_FAIL=1 fakes exactly
+    that for the first launch of the process): the kriging fit retries on the launch-per-block path by itself and the
+    results are the usual ones; gss_lugs_create reports the condition once and works on the next call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, gss\n"
+        "from gss import _lib\n"
+        "from gss.engine import KrigHandle, LUGSHandle, OK\n"
+        "from oracle import kriging as K\n"
+        "from oracle.variogram import Variogram\n"
+        "rng = np.random.default_rng(0)\n"
+        "x = rng.uniform(0, 100, (600, 3)); z = rng.normal(size=600); x0 = rng.uniform(0, 100, (50, 3))\n"
+        "h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), OK, x, z)\n"
+        "mu, var, st = h.predict_global(x0)\n"
+        "ref = K.predict(K.fit(K.OK, Variogram('matern', range=30.0, nu=1.5), x, z), x0)\n"
+        "assert np.max(np.abs(mu - ref[0])) < 1e-9 and np.max(np.abs(var - ref[1])) < 1e-9\n"
+        "print('KRIG RECOVERED')\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSS_PANEL_FAIL="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "KRIG RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    code2 = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, gss\n"
+        "from gss import _lib\n"
+        "from gss.engine import LUGSHandle\n"
+        "cent = gss.CartesianGrid(40, 30).centroids()\n"
+        "dl = np.arange(0, 1200, 3)[:300]; z1 = np.random.default_rng(1).normal(size=300)\n"
+        "try:\n"
+        "    LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, dl, z1)\n"
+        "    print('NO ERROR')\n"
+        "except _lib.GSSError as e:\n"
+        "    assert 'switched off' in str(e), str(e)\n"
+        "    h = LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, dl, z1)\n"
+        "    r = h.realize(1, 0, 2)\n"
+        "    assert np.array_equal(r[0][:, dl] if isinstance(r, tuple) else r[:, dl], np.tile(z1, (2, 1)))\n"
+        "    print('LUGS RECOVERED')\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, GSS_PANEL_FAIL="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "LUGS RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_potrf_inverse_panel_reports_the_pivot():
     from gss import _lib
     l = _lib.lib()
