@@ -73,6 +73,7 @@ struct gss_lugs {
 };
 
 constexpr int LUGS_KC = 6;   // column blocks of L22 in gss_lugs_realize
+constexpr int32_t LUGS_RETRY = 1000;   // internal: the single-launch factorisation gave up, run the preprocess again
 
 // Y(i, r) = sum over the column blocks c whose first column is <= i of part_c(i, r), in block order
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int nchunk, int64_t kc,
@@ -99,10 +100,10 @@ static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   GSS_HIP(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   GSS_HIP(hipStreamSynchronize(s));
   if (h < 0) {
-    potrf_panel_disable();  // the next create runs on the launch-per-block path, which has no residency requirement
+    potrf_panel_disable();  // from now on the launch-per-block path, which has no residency requirement
     set_error("%s: the single-launch factorisation gave up waiting at a grid barrier (its workgroups were not resident "
-              "together); it is switched off for this process now -- call again", what);
-    return GSS_ERR_HIP;
+              "together); switched off for this process", what);
+    return LUGS_RETRY;
   }
   if (h != 0) {
     set_error("%s is not positive definite (pivot %d); add a nugget or remove duplicate locations", what, h - 1);
@@ -111,11 +112,9 @@ static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   return GSS_OK;
 }
 
-extern "C" {
-
-int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
-                        const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
-                        void* stream) {
+static int32_t lugs_create_impl(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
+                                const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
+                                void* stream) {
   GSS_REQUIRE(out != nullptr, "gss_lugs_create: out is NULL");
   *out = nullptr;
   GSS_REQUIRE(centroids != nullptr && N >= 1 && nd >= 0 && nd <= N, "gss_lugs_create: bad sizes");
@@ -276,6 +275,21 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
   guard.h = nullptr;
   *out = h;
   return GSS_OK;
+}
+
+extern "C" {
+
+int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
+                        const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
+                        void* stream) {
+  int32_t rc = lugs_create_impl(out, vg, centroids, N, dlocs, z1, nd, mean, flags, stream);
+  // once more on the launch-per-block path (check_info has switched the single-launch kernel off for the process)
+  if (rc == LUGS_RETRY) rc = lugs_create_impl(out, vg, centroids, N, dlocs, z1, nd, mean, flags, stream);
+  if (rc == LUGS_RETRY) {
+    set_error("gss_lugs_create: the factorisation kernel keeps giving up at a grid barrier");
+    rc = GSS_ERR_HIP;
+  }
+  return rc;
 }
 
 int32_t gss_lugs_destroy(gss_lugs_t* h) {

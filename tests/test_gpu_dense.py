@@ -153,7 +153,7 @@ def test_potrf_inverse_launch_per_block_path_stays_alive():
 def test_recovery_when_the_single_launch_kernel_gives_up():
     """A launch whose workgroups do not all arrive within the bounded spin reports -1 (GSS_PANEL_FAIL=1 fakes exactly
     that for the first launch of the process): the kriging fit retries on the launch-per-block path by itself and the
-    results are the usual ones; gss_lugs_create reports the condition once and works on the next call."""
+    results are the usual ones; gss_lugs_create runs its preprocess a second time by itself."""
     import os
     import subprocess
     import sys
@@ -185,15 +185,10 @@ def test_recovery_when_the_single_launch_kernel_gives_up():
         "from gss.engine import LUGSHandle\n"
         "cent = gss.CartesianGrid(40, 30).centroids()\n"
         "dl = np.arange(0, 1200, 3)[:300]; z1 = np.random.default_rng(1).normal(size=300)\n"
-        "try:\n"
-        "    LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, dl, z1)\n"
-        "    print('NO ERROR')\n"
-        "except _lib.GSSError as e:\n"
-        "    assert 'switched off' in str(e), str(e)\n"
-        "    h = LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, dl, z1)\n"
-        "    r = h.realize(1, 0, 2)\n"
-        "    assert np.array_equal(r[0][:, dl] if isinstance(r, tuple) else r[:, dl], np.tile(z1, (2, 1)))\n"
-        "    print('LUGS RECOVERED')\n"
+        "h = LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, dl, z1)\n"
+        "r = h.realize(1, 0, 2)\n"
+        "assert np.array_equal(r[0][:, dl] if isinstance(r, tuple) else r[:, dl], np.tile(z1, (2, 1)))\n"
+        "print('LUGS RECOVERED')\n"
     ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
     r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, GSS_PANEL_FAIL="1"), capture_output=True,
                        text=True, timeout=300)
