@@ -1461,7 +1461,7 @@ int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_
   Pb[0] = Pt[1] + nd * B;
   Pb[1] = Pb[0] + mb * B;
   hipStream_t side = lookahead_stream();
-  GSS_REQUIRE(side != nullptr, "potrf_joint: cannot create the helper stream");
+  if (!side) side = s;   // no helper stream: the same work in the same order on the caller's stream
   ScopedEvent ev_s, ev_b;
   GSS_HIP(ev_s.create());
   GSS_HIP(ev_b.create());
