@@ -173,6 +173,185 @@ __global__ __launch_bounds__(64) void sgs_weights_kernel(VgDev vg, const double*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// More than 64 neighbours (seq.jl:91-98 accepts any maxneighbors; available with the search-then-filter reading of
+// `mask = simulated`, whose search is unmasked and runs in passes of 64, knn.hip).  One workgroup of 256 threads per
+// node: the kept neighbours in order (wave 0: ballot compaction by 64s), the packed covariance triangle in LDS while
+// it fits (up to 180 neighbours) or in a slab of HBM, Cholesky by columns, forward and back substitution.  A
+// functional path like krig_local_big_kernel: two barriers per column.
+// ---------------------------------------------------------------------------------------------
+constexpr int SGS_BIG_NT = 256;
+constexpr int SGS_BIG_LDS_DOUBLES = 16384 + 256;   // packed triangle + the right-hand side of <= 180 neighbours
+constexpr int SGS_BIG_MAX_K = 1024;
+
+template <int DIM>
+__global__ __launch_bounds__(SGS_BIG_NT) void sgs_weights_big_kernel(
+    VgDev vg, const double* __restrict__ cent, const int* __restrict__ rank, int64_t N, int k, int minneighbors,
+    const int* __restrict__ idx, const int* __restrict__ count, int* __restrict__ ncond, double* __restrict__ w_out,
+    double* __restrict__ sigma_out, int* __restrict__ idx_rw, double* __restrict__ scratch, int64_t slab, int use_lds) {
+  extern __shared__ double sgs_big_sm[];
+  __shared__ int s_cnt, s_bad;
+  __shared__ double s_red[SGS_BIG_NT / 64];
+  const int tid = threadIdx.x;
+  const double smarg = sqrt(vg.sill);  // sgs.jl:66
+  for (int64_t p = blockIdx.x; p < N; p += gridDim.x) {
+    __syncthreads();  // the previous node's shared words have been read
+    if (rank[p] < 0) {  // data cell: never simulated (seq.jl:103)
+      if (tid == 0) {
+        ncond[p] = 0;
+        sigma_out[p] = 0.0;
+      }
+      continue;
+    }
+    if (tid < 64) {  // keep, in order, the neighbours already simulated when the node is visited
+      const int cnt0 = count[p];
+      const int rp = rank[p];
+      int off = 0;
+      for (int base = 0; base < cnt0; base += 64) {
+        const int j = base + tid;
+        const bool in = j < cnt0;
+        const int nb = in ? idx[p * k + j] : 0;
+        const bool keep = in && rank[nb] < rp;
+        const unsigned long long bm = __ballot(keep);
+        if (keep) idx_rw[p * k + off + __popcll(bm & ((1ull << tid) - 1ull))] = nb;
+        off += __popcll(bm);
+      }
+      for (int j = off + tid; j < k; j += 64) idx_rw[p * k + j] = -1;
+      if (tid == 0) {
+        s_cnt = off;
+        s_bad = 0;
+      }
+    }
+    __syncthreads();
+    const int c = s_cnt;
+    if (c < minneighbors || c <= 0) {  // seq.jl:107-109
+      if (tid == 0) {
+        ncond[p] = 0;
+        sigma_out[p] = smarg;
+      }
+      continue;
+    }
+    const int* nb = idx_rw + p * k;
+    double* M = use_lds ? sgs_big_sm : scratch + (int64_t)blockIdx.x * slab;
+    const int ntri = c * (c + 1) / 2;
+    double* b = M + ntri;
+    double c0[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) c0[a] = cent[p * DIM + a];
+    for (int e = tid; e < ntri; e += SGS_BIG_NT) {
+      int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+      while (sgs_tri(i + 1) <= e) ++i;
+      while (sgs_tri(i) > e) --i;
+      const int j = e - sgs_tri(i);
+      const int ni = nb[i], nj = nb[j];
+      double xi[DIM], xj[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        xi[a] = cent[(int64_t)ni * DIM + a];
+        xj[a] = cent[(int64_t)nj * DIM + a];
+      }
+      M[e] = cov_pair<DIM>(vg, xi, xj);
+    }
+    for (int j = tid; j < c; j += SGS_BIG_NT) {
+      double xj[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) xj[a] = cent[(int64_t)nb[j] * DIM + a];
+      b[j] = cov_pair<DIM>(vg, xj, c0);
+    }
+    __syncthreads();
+    // Cholesky, left-looking by columns; rows are dealt to the threads
+    for (int j = 0; j < c; ++j) {
+      const double* rowj = M + sgs_tri(j);
+      for (int i = j + tid; i < c; i += SGS_BIG_NT) {
+        double* rowi = M + sgs_tri(i);
+        double acc = rowi[j];
+        for (int q = 0; q < j; ++q) acc = fma(-rowi[q], rowj[q], acc);
+        rowi[j] = acc;
+      }
+      __syncthreads();
+      const double d = rowj[j];
+      if (!(d > 0.0)) {
+        if (tid == 0) s_bad = 1;
+        break;   // d is read by every thread alike: the whole workgroup leaves the loop
+      }
+      __syncthreads();
+      const double sq = sqrt(d);
+      for (int i = j + tid; i < c; i += SGS_BIG_NT) {
+        double* rowi = M + sgs_tri(i);
+        rowi[j] = (i == j) ? sq : rowi[j] / sq;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (s_bad) {  // status(fitted) == false -> marginal (seq.jl:124-128)
+      if (tid == 0) {
+        ncond[p] = 0;
+        sigma_out[p] = smarg;
+      }
+      continue;
+    }
+    // y = L^-1 c0 by columns
+    for (int j = 0; j < c; ++j) {
+      const double yj = b[j] / M[sgs_tri(j) + j];
+      __syncthreads();
+      if (tid == 0) b[j] = yj;
+      for (int i = j + 1 + tid; i < c; i += SGS_BIG_NT) b[i] = fma(-M[sgs_tri(i) + j], yj, b[i]);
+      __syncthreads();
+    }
+    double q = 0.0;
+    for (int j = tid; j < c; j += SGS_BIG_NT) q = fma(b[j], b[j], q);
+    q = sgs_wave_sum(q);
+    if ((tid & 63) == 0) s_red[tid >> 6] = q;
+    // lambda = L^-T y (row j of L is contiguous)
+    for (int j = c - 1; j >= 0; --j) {
+      const double lj = b[j] / M[sgs_tri(j) + j];
+      __syncthreads();
+      if (tid == 0) b[j] = lj;
+      const double* rowj = M + sgs_tri(j);
+      for (int i = tid; i < j; i += SGS_BIG_NT) b[i] = fma(-rowj[i], lj, b[i]);
+      __syncthreads();
+    }
+    for (int j = tid; j < c; j += SGS_BIG_NT) w_out[p * k + j] = b[j];
+    if (tid == 0) {
+      double qq = 0.0;
+      for (int wv = 0; wv < SGS_BIG_NT / 64; ++wv) qq += s_red[wv];
+      const double v = vg.sill - qq;
+      ncond[p] = c;
+      sigma_out[p] = sqrt(v > 0.0 ? v : 0.0);
+    }
+  }
+}
+
+// stage B for more than 64 neighbours, shared visiting order: the same recursion without the lane-held lists
+__global__ __launch_bounds__(64) void sgs_sweep_big_kernel(const int64_t* __restrict__ path, const int* __restrict__ rank,
+                                                           const int* __restrict__ idx, const int* __restrict__ ncond,
+                                                           const double* __restrict__ w, const double* __restrict__ sigma,
+                                                           int k, int64_t N, int R, double mean, double* __restrict__ zt) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  const bool live = r < R;
+  const int rr = live ? r : R - 1;
+  for (int64_t t = 0; t < N; ++t) {
+    const int64_t node = path[t];
+    if (rank[node] < 0) continue;  // conditioning cell
+    const int c = ncond[node];
+    const int* nb = idx + node * k;
+    const double* ww = w + node * k;
+    double acc = 0.0;
+    int j = 0;
+    for (; j + 4 <= c; j += 4) {   // four gathers in flight
+      const double z0 = zt[(int64_t)nb[j] * R + rr], z1 = zt[(int64_t)nb[j + 1] * R + rr];
+      const double z2 = zt[(int64_t)nb[j + 2] * R + rr], z3 = zt[(int64_t)nb[j + 3] * R + rr];
+      acc = fma(ww[j], z0 - mean, acc);
+      acc = fma(ww[j + 1], z1 - mean, acc);
+      acc = fma(ww[j + 2], z2 - mean, acc);
+      acc = fma(ww[j + 3], z3 - mean, acc);
+    }
+    for (; j < c; ++j) acc = fma(ww[j], zt[(int64_t)nb[j] * R + rr] - mean, acc);
+    const double v = mean + acc + sigma[node] * zt[node * R + rr];
+    if (live) zt[node * R + r] = v;
+  }
+}
+
 // zt[dloc][r] = zdata for the conditioning cells
 __global__ __launch_bounds__(256) void sgs_seed_data_kernel(const int64_t* __restrict__ dlocs,
                                                             const double* __restrict__ zd, int64_t nd, int64_t N,
@@ -363,8 +542,11 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   GSS_REQUIRE(nd >= 0 && nd <= N && (nd == 0 || (dlocs && zdata)), "gss_sgs_create: bad conditioning data");
   GSS_REQUIRE(maxneighbors >= 1 && maxneighbors <= N, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, "
               "ui.jl:18-20)", maxneighbors, (long long)N);
-  GSS_REQUIRE(maxneighbors <= SGS_MAX_K, "maxneighbors = %d: the neighbour kernels hold at most %d neighbours",
-              maxneighbors, SGS_MAX_K);
+  GSS_REQUIRE(maxneighbors <= SGS_MAX_K || (flags & GSS_SGS_MASK_AFTER_SEARCH),
+              "maxneighbors = %d: the masked neighbour search holds at most %d neighbours (more with "
+              "GSS_SGS_MASK_AFTER_SEARCH, whose search is not masked)", maxneighbors, SGS_MAX_K);
+  GSS_REQUIRE(maxneighbors <= SGS_BIG_MAX_K, "maxneighbors = %d: at most %d neighbours in SGS", maxneighbors,
+              SGS_BIG_MAX_K);
   hipStream_t s = to_stream(stream);
   auto* h = new gss_sgs();
   struct Guard {
@@ -427,6 +609,7 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   else GSS_TRY(knn_index_build(centroids, N, dim, &ix, s));
   GSS_TRY(bmin.alloc(sizeof(int) * (size_t)ix.nb));
   DevBuf rawidx;   // GSS_SGS_MASK_AFTER_SEARCH: the unmasked neighbour lists, shared by every path
+  DevBuf bigscr;   // more than 180 neighbours: covariance triangles of the workgroups of sgs_weights_big_kernel
   for (int64_t pp = 0; pp < P; ++pp) {   // stage A once per visiting order
     int* rk = h->rank.as<int>() + pp * N;
     int* idxp = h->idx.as<int>() + pp * N * h->k;
@@ -438,7 +621,11 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
       if (h->filter_after) {   // one unmasked search serves every path: k nearest cells of the whole domain
         if (pp == 0) {
           GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
-          GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s));
+          if (h->k > SGS_MAX_K)
+            GSS_TRY(knn_search_indexed_any(ix, cent.as<double>(), cent.as<double>(), N, h->k, radius, inv_radii,
+                                           rawidx.as<int>(), cnt.as<int>(), s, GSS_METRIC_EUCLIDEAN));
+          else
+            GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s));
         }
       } else {
         GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
@@ -451,10 +638,42 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
                      (h->filter_after ? rawidx.as<int>() : idxp), cnt.as<int>(), \
                      h->ncond.as<int>() + pp * N, h->w.as<double>() + pp * N * h->k, h->sigma.as<double>() + pp * N, \
                      idxp, h->filter_after
+      if (h->k > SGS_MAX_K) {
+        // one workgroup per node, grid-stride; the triangle in LDS when it fits, else a slab of HBM per workgroup
+        const int64_t need = (int64_t)h->k * (h->k + 1) / 2 + h->k;
+        const int use_lds = need <= SGS_BIG_LDS_DOUBLES ? 1 : 0;
+        int64_t nwg = N < 1024 ? N : 1024;
+        if (!use_lds) {
+          const int64_t cap = ((int64_t)1 << 30) / (int64_t)(sizeof(double) * (size_t)need);   // 1 GiB of slabs
+          if (nwg > cap) nwg = cap > 1 ? cap : 1;
+          if (bigscr.bytes < sizeof(double) * (size_t)(need * nwg)) {
+            bigscr.release();
+            GSS_TRY(bigscr.alloc(sizeof(double) * (size_t)(need * nwg)));
+          }
+        }
+        const size_t lds = use_lds ? sizeof(double) * (size_t)need : 0;
+#define GSS_SGS_BIG(D)                                                                                                  \
+  do {                                                                                                                   \
+    if (lds > 48 * 1024)                                                                                                 \
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sgs_weights_big_kernel<D>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    hipLaunchKernelGGL((sgs_weights_big_kernel<D>), dim3((unsigned)nwg), dim3(SGS_BIG_NT), lds, s, h->vg,              \
+                       cent.as<double>(), rk, N, h->k, minneighbors, rawidx.as<int>(), cnt.as<int>(),                   \
+                       h->ncond.as<int>() + pp * N, h->w.as<double>() + pp * N * h->k, h->sigma.as<double>() + pp * N,  \
+                       idxp, bigscr.as<double>(), need, use_lds);                                                        \
+  } while (0)
+        switch (dim) {
+          case 1: GSS_SGS_BIG(1); break;
+          case 2: GSS_SGS_BIG(2); break;
+          default: GSS_SGS_BIG(3); break;
+        }
+#undef GSS_SGS_BIG
+      } else {
       switch (dim) {
         case 1: hipLaunchKernelGGL((sgs_weights_kernel<1>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
         case 2: hipLaunchKernelGGL((sgs_weights_kernel<2>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
         default: hipLaunchKernelGGL((sgs_weights_kernel<3>), dim3((unsigned)N), dim3(64), 0, s, GSS_SGS_ARGS); break;
+      }
       }
 #undef GSS_SGS_ARGS
       GSS_HIP(hipGetLastError());
@@ -554,9 +773,14 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
   }
   {
     ProfScope ps("sgs_sweep", s);
-    hipLaunchKernelGGL(sgs_sweep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
-                       h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
-                       h->sigma.as<double>(), h->k, N, R, h->mean, zt.as<double>());
+    if (h->k > SGS_MAX_K)
+      hipLaunchKernelGGL(sgs_sweep_big_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
+                         h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
+                         h->sigma.as<double>(), h->k, N, R, h->mean, zt.as<double>());
+    else
+      hipLaunchKernelGGL(sgs_sweep_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
+                         h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
+                         h->sigma.as<double>(), h->k, N, R, h->mean, zt.as<double>());
     GSS_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(sgs_transpose_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, s,
