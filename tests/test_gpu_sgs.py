@@ -92,6 +92,18 @@ def test_more_than_64_neighbours_with_the_search_then_filter_mask(dims, k, rpath
         assert np.max(np.abs(zp[r] - refp)) < 1e-9
 
 
+def test_solver_front_end_with_ninety_neighbours():
+    import gss
+    grid = gss.CartesianGrid((40, 40), (0.5, 0.5), (1.0, 1.0))
+    pts = [(10.0, 10.0), (20.0, 30.0), (30.0, 20.0)]
+    data = gss.georef(dict(z=[1.0, 0.0, 1.0]), pts)
+    solver = gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=15.0), maxneighbors=90)), rng=3)
+    sol = gss.solve(gss.SimulationProblem(data, grid, "z", 2), solver)
+    li = lambda i, j: (j - 1) * 40 + (i - 1)
+    for r in sol["z"]:
+        assert np.all(np.isfinite(r)) and r[li(10, 10)] == 1.0 and r[li(20, 30)] == 0.0 and r[li(30, 20)] == 1.0
+
+
 def test_weights_are_the_simple_kriging_weights():
     from gss.engine import SGSHandle
     gvg, ovg = _vg("spherical", range=10.0)
