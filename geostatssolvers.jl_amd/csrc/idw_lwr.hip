@@ -648,11 +648,10 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   if (k > 64 && (int64_t)k < n) {
     // 65 .. n - 1 neighbours (ui.jl:16-23 accepts any count): the search runs in passes of 64, the estimator walks
     // the lists with one thread per point
-    GSS_REQUIRE(sp.metric != GSS_METRIC_HAVERSINE,
-                "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
     const int64_t chunk = k > 512 ? (1 << 16) : (1 << 19);
+    const bool hav = sp.metric == GSS_METRIC_HAVERSINE;   // no box bounds for the indexed search: exhaustive passes
     KnnIndex ix;
-    GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
+    if (!hav) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
     DevBuf idx_s, cnt_s;
     GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
     GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
@@ -660,8 +659,12 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
       const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
       {
         ProfScope ps("knn", s);
-        GSS_TRY(knn_search_indexed_any(ix, xdata, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
-                                       cnt_s.as<int>(), s, sp.metric));
+        if (hav)
+          GSS_TRY(knn_search_dev(xdata, n, dim, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                                 cnt_s.as<int>(), s, sp.metric));
+        else
+          GSS_TRY(knn_search_indexed_any(ix, xdata, x0 + off * dim, mv, k, radius, inv_radii_host, idx_s.as<int>(),
+                                         cnt_s.as<int>(), s, sp.metric));
       }
       ProfScope pl(pname, s);
       const dim3 grid((unsigned)((mv + 255) / 256));

@@ -110,7 +110,10 @@ template <int DIM, int METRIC>
 __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xdata, int n,
                                                   const double* __restrict__ centers, int64_t m, int k, double r2,
                                                   int use_ball, int aniso, double ir0, double ir1, double ir2,
-                                                  int* __restrict__ idx_out, int* __restrict__ count_out) {
+                                                  int* __restrict__ idx_out, int* __restrict__ count_out,
+                                                  const double* __restrict__ lowd, const int* __restrict__ lowi) {
+  // lowd / lowi (may be NULL): per query, only candidates whose key (distance, index) lies strictly above this one
+  // take part -- the passes of 64 of a search for more than 64 neighbours
   __shared__ double tile[3][KNN_TILE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -129,14 +132,17 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
     for (int a = 0; a < DIM; ++a) qc[q][a] = centers[pc * DIM + a];
   }
   const double INF = __longlong_as_double(0x7ff0000000000000LL);
-  double ld[KNN_Q], tau_d[KNN_Q];
-  int li[KNN_Q], tau_i[KNN_Q];
+  double ld[KNN_Q], tau_d[KNN_Q], low_d[KNN_Q];
+  int li[KNN_Q], tau_i[KNN_Q], low_i[KNN_Q];
 #pragma unroll
   for (int q = 0; q < KNN_Q; ++q) {
     ld[q] = INF;
     li[q] = INT_MAX;
     tau_d[q] = INF;
     tau_i[q] = INT_MAX;
+    const int64_t pc = qvalid[q] ? qbase + q : m - 1;
+    low_d[q] = lowd ? lowd[pc] : -1.0;
+    low_i[q] = lowd ? lowi[pc] : -1;
   }
 
   for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const double* __restrict__ xda
 #pragma unroll
       for (int q = 0; q < KNN_Q; ++q) {
         const double d2 = metric_key<DIM, METRIC>(c, qc[q], ir, aniso != 0);
-        const bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, gidx, tau_d[q], tau_i[q]);
+        const bool qual = valid && (!use_ball || d2 <= r2) && key_less(d2, gidx, tau_d[q], tau_i[q]) &&
+                          key_less(low_d[q], low_i[q], d2, gidx);
         unsigned long long mask = __ballot(qual);
         while (mask) {
           const int src = __builtin_ctzll(mask);
@@ -568,6 +575,7 @@ __global__ __launch_bounds__(256) void knn_any_append_kernel(const double* __res
   double key;
   if (metric == GSS_METRIC_CITYBLOCK) key = metric_key<DIM, GSS_METRIC_CITYBLOCK>(x, q, ir, false);
   else if (metric == GSS_METRIC_CHEBYSHEV) key = metric_key<DIM, GSS_METRIC_CHEBYSHEV>(x, q, ir, false);
+  else if (metric == GSS_METRIC_HAVERSINE) key = metric_key<DIM, GSS_METRIC_HAVERSINE>(x, q, ir, false);
   else key = metric_key<DIM, GSS_METRIC_EUCLIDEAN>(x, q, ir, aniso != 0);
   lowd[p] = key;
   lowi[p] = last;
@@ -627,44 +635,83 @@ int32_t check_metric(int metric, double metric_param, int dim, double radius, co
 
 template <int DIM, int METRIC>
 static void launch_brute(dim3 grid, hipStream_t s, const double* xdata, int n, const double* centers, int64_t m, int k,
-                         double r2, int use_ball, int aniso, const double* ir, int* idx, int* count) {
+                         double r2, int use_ball, int aniso, const double* ir, int* idx, int* count,
+                         const double* lowd = nullptr, const int* lowi = nullptr) {
   hipLaunchKernelGGL((knn_kernel<DIM, METRIC>), grid, dim3(256), 0, s, xdata, n, centers, m, k, r2, use_ball, aniso,
-                     ir[0], ir[1], ir[2], idx, count);
+                     ir[0], ir[1], ir[2], idx, count, lowd, lowi);
 }
 
 template <int DIM>
 static void launch_brute_metric(int metric, dim3 grid, hipStream_t s, const double* xdata, int n,
                                 const double* centers, int64_t m, int k, double r2, int use_ball, int aniso,
-                                const double* ir, int* idx, int* count) {
+                                const double* ir, int* idx, int* count, const double* lowd = nullptr,
+                                const int* lowi = nullptr) {
   switch (metric) {
     case GSS_METRIC_CITYBLOCK:
-      launch_brute<DIM, GSS_METRIC_CITYBLOCK>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      launch_brute<DIM, GSS_METRIC_CITYBLOCK>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count, lowd, lowi);
       break;
     case GSS_METRIC_CHEBYSHEV:
-      launch_brute<DIM, GSS_METRIC_CHEBYSHEV>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      launch_brute<DIM, GSS_METRIC_CHEBYSHEV>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count, lowd, lowi);
       break;
     case GSS_METRIC_HAVERSINE:
-      launch_brute<DIM, GSS_METRIC_HAVERSINE>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      launch_brute<DIM, GSS_METRIC_HAVERSINE>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count, lowd, lowi);
       break;
     default:
-      launch_brute<DIM, GSS_METRIC_EUCLIDEAN>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count);
+      launch_brute<DIM, GSS_METRIC_EUCLIDEAN>(grid, s, xdata, n, centers, m, k, r2, use_ball, aniso, ir, idx, count, lowd, lowi);
       break;
   }
+}
+
+// more than 64 neighbours on the exhaustive kernel (the haversine distance has no box bounds for the indexed search):
+// passes of 64, each restricted to the keys above the last neighbour of the pass before
+static int32_t knn_search_brute_any(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
+                                    double r2, int use_ball, int aniso, const double* ir, int* idx, int* count,
+                                    hipStream_t s, int metric) {
+  DevBuf tidx, tcnt, lowd, lowi, cnt_own;
+  GSS_TRY(tidx.alloc(sizeof(int) * (size_t)(m * 64)));
+  GSS_TRY(tcnt.alloc(sizeof(int) * (size_t)m));
+  GSS_TRY(lowd.alloc(sizeof(double) * (size_t)m));
+  GSS_TRY(lowi.alloc(sizeof(int) * (size_t)m));
+  if (!count) {
+    GSS_TRY(cnt_own.alloc(sizeof(int) * (size_t)m));
+    count = cnt_own.as<int>();
+  }
+  const dim3 g1((unsigned)((m + 255) / 256));
+  const dim3 grid((unsigned)((m + 4 * KNN_Q - 1) / (4 * KNN_Q)));
+  hipLaunchKernelGGL(knn_any_init_kernel, g1, dim3(256), 0, s, m, count, lowd.as<double>(), lowi.as<int>());
+  for (int base = 0; base < k; base += 64) {
+    const int kk = (k - base) < 64 ? (k - base) : 64;
+#define GSS_BRUTE_PASS(D)                                                                                               \
+  do {                                                                                                                   \
+    launch_brute_metric<D>(metric, grid, s, xdata, (int)n, centers, m, kk, r2, use_ball, aniso, ir, tidx.as<int>(),     \
+                           tcnt.as<int>(), lowd.as<double>(), lowi.as<int>());                                          \
+    hipLaunchKernelGGL(knn_any_append_kernel<D>, g1, dim3(256), 0, s, xdata, centers, m, k, base, kk, tidx.as<int>(),   \
+                       tcnt.as<int>(), metric, aniso, ir[0], ir[1], ir[2], idx, count, lowd.as<double>(),               \
+                       lowi.as<int>());                                                                                  \
+  } while (0)
+    switch (dim) {
+      case 1: GSS_BRUTE_PASS(1); break;
+      case 2: GSS_BRUTE_PASS(2); break;
+      default: GSS_BRUTE_PASS(3); break;
+    }
+#undef GSS_BRUTE_PASS
+    GSS_HIP(hipGetLastError());
+  }
+  GSS_HIP(hipStreamSynchronize(s));  // the pass buffers are released on return
+  return GSS_OK;
 }
 
 // Euclidean: pruned search (exhaustive kernel with GSS_KNN_BRUTE=1, kept for A/B checks); other metrics: exhaustive
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s, int metric) {
   GSS_REQUIRE(k >= 1, "maxneighbors = %d", k);
-  GSS_REQUIRE(k <= 64 || metric != GSS_METRIC_HAVERSINE,
-              "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
   GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3, "knn: bad sizes");
   if (m <= 0) return GSS_OK;
   const char* e = std::getenv("GSS_KNN_BRUTE");
   // few queries into a large set (e.g. the data -> grid-cell lookup of conditional simulation, fft.jl:129-132):
   // one brute-force sweep of the set costs less than ordering it on the host for the index
   const bool few_queries = m <= 4096 && n >= 32768 && k <= 64;
-  if (k > 64 || (metric != GSS_METRIC_HAVERSINE && !(e && e[0] == '1') && !few_queries)) {
+  if (metric != GSS_METRIC_HAVERSINE && (k > 64 || (!(e && e[0] == '1') && !few_queries))) {
     KnnIndex ix;
     GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
     GSS_TRY(knn_search_indexed_any(ix, xdata, centers, m, k, radius, inv_radii_host, idx, count, s, metric));
@@ -677,6 +724,7 @@ int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* ce
   double ir[3] = {1.0, 1.0, 1.0};
   if (aniso)
     for (int a = 0; a < dim; ++a) ir[a] = inv_radii_host[a];
+  if (k > 64) return knn_search_brute_any(xdata, n, dim, centers, m, k, r2, use_ball, aniso, ir, idx, count, s, metric);
   dim3 grid((unsigned)((m + 4 * KNN_Q - 1) / (4 * KNN_Q)));
   switch (dim) {
     case 1: launch_brute_metric<1>(metric, grid, s, xdata, (int)n, centers, m, k, r2, use_ball, aniso, ir, idx, count); break;

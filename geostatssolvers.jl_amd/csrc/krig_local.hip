@@ -781,9 +781,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   const int64_t chunk = big ? (k > 512 ? (1 << 14) : (1 << 17)) : (1 << 20);
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
-  const bool use_index = big || (metric != GSS_METRIC_HAVERSINE && !(brute && brute[0] == '1'));
-  GSS_REQUIRE(!big || metric != GSS_METRIC_HAVERSINE,
-              "maxneighbors = %d with the haversine distance: the exhaustive search holds at most 64 neighbours", k);
+  // (the haversine distance always searches exhaustively, in passes of 64 beyond 64 neighbours)
+  const bool use_index = metric != GSS_METRIC_HAVERSINE && (big || !(brute && brute[0] == '1'));
   const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
   const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));

@@ -199,7 +199,7 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
  *   weight(h) = exp(-weight_a * h^weight_p) for GSS_WEIGHT_EXP (reference default a = 3, p = 2,
  *   lwr.jl:58) or (1 - h^3)^3 for GSS_WEIGHT_TRICUBE.
  * k = number of neighbours the searcher returns (ui.jl:16-23): 1..n; k == n is `maxneighbors = nothing` (every
- * sample, no search); beyond 64 the search runs in passes of 64 (haversine: at most 64).  radius / inv_radii /
+ * sample, no search); beyond 64 the search runs in passes of 64 (haversine: on the exhaustive kernel).  radius / inv_radii /
  * metric as gss_knn_search;
  * the weights use the distances of that metric (searchdists!, idw.jl:120).
  * status: GSS_PT_MISSING when fewer than minneighbors were found (idw.jl:123, lwr.jl:126),

@@ -107,8 +107,6 @@ def test_solvers_through_solve_and_argument_errors():
     rmu, rvar, _ = E.lwr(xs[keep], zs[keep], grid)
     assert sol.names() == ["z", "z_variance"] and _close(sol["z"], rmu, 1e-9) and _close(sol["z_variance"], rvar, 1e-9)
     from gss.engine import HipEngine
-    with pytest.raises(_lib.GSSError, match="at most 64"):      # only the exhaustive (haversine) search is limited
-        HipEngine.idw(rng.uniform(size=(200, 2)), rng.uniform(size=200), grid, 100, distance=("haversine", 1.0))
     with pytest.raises(_lib.GSSError, match="exponent must be positive"):
         HipEngine.idw(xs[keep], zs[keep], grid, 5, 1, 0.0)
 
@@ -133,11 +131,11 @@ def test_search_metrics_indices_and_estimators(distance):
         c = rng.uniform(0, 100, (400, 3))
     c[:3] = x[:3]
     z = np.sin(x[:, 0] / 20.0) + 0.01 * x[:, 1]
-    for k in (1, 7, 64):
+    for k in (1, 7, 64, 100, 200):   # beyond 64: passes of 64 (indexed search, or the exhaustive kernel for haversine)
         idx, cnt = HipEngine.knn_search(x, c, k, distance=distance)
         ridx, rcnt = K.knn_search(x, c, k, distance=distance)
         assert np.array_equal(idx, ridx) and np.array_equal(cnt, rcnt)
-    for k in (9, None):
+    for k in (9, 150, None):
         kk = 700 if k is None else k
         mu, sd, st = HipEngine.idw(x, z, c, kk, 1, 2.0, distance=distance)
         rmu, rsd, rst = E.idw(x, z, c, k, 1, 2.0, distance=distance)
