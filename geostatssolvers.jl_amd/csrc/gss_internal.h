@@ -742,9 +742,11 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
                            const int* lowi = nullptr /* per-query lower bound of the accepted keys */);
 // any k <= n: passes of 64 neighbours, each bounded below by the last key of the pass before (idx is m x k);
 // xdata = the samples in their original order (device)
+// rank / qrank / bminrank: the mask of SGS (candidates whose rank is below the query's), as in knn_search_indexed
 int32_t knn_search_indexed_any(const KnnIndex& ix, const double* xdata, const double* centers, int64_t m, int k,
                                double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
-                               int metric = 0);
+                               int metric = 0, const int* rank = nullptr, const int* qrank = nullptr,
+                               const int* bminrank = nullptr);
 // Haversine: exhaustive kernel (no box bounds for that key); non-Euclidean metrics do not combine with balls
 int32_t knn_search_dev(const double* xdata, int64_t n, int dim, const double* centers, int64_t m, int k,
                        double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,

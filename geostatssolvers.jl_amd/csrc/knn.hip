@@ -583,9 +583,9 @@ __global__ __launch_bounds__(256) void knn_any_append_kernel(const double* __res
 
 int32_t knn_search_indexed_any(const KnnIndex& ix, const double* xdata, const double* centers, int64_t m, int k,
                                double radius, const double* inv_radii_host, int* idx, int* count, hipStream_t s,
-                               int metric) {
-  if (k <= 64) return knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s, nullptr, nullptr,
-                                         nullptr, metric);
+                               int metric, const int* rank, const int* qrank, const int* bminrank) {
+  if (k <= 64) return knn_search_indexed(ix, centers, m, k, radius, inv_radii_host, idx, count, s, rank, qrank,
+                                         bminrank, metric);
   if (m <= 0) return GSS_OK;
   DevBuf tidx, tcnt, lowd, lowi, cnt_own;
   GSS_TRY(tidx.alloc(sizeof(int) * (size_t)(m * 64)));
@@ -604,8 +604,8 @@ int32_t knn_search_indexed_any(const KnnIndex& ix, const double* xdata, const do
   hipLaunchKernelGGL(knn_any_init_kernel, grid, dim3(256), 0, s, m, count, lowd.as<double>(), lowi.as<int>());
   for (int base = 0; base < k; base += 64) {
     const int kk = (k - base) < 64 ? (k - base) : 64;
-    GSS_TRY(knn_search_indexed(ix, centers, m, kk, radius, inv_radii_host, tidx.as<int>(), tcnt.as<int>(), s, nullptr,
-                               nullptr, nullptr, metric, lowd.as<double>(), lowi.as<int>()));
+    GSS_TRY(knn_search_indexed(ix, centers, m, kk, radius, inv_radii_host, tidx.as<int>(), tcnt.as<int>(), s, rank,
+                               qrank, bminrank, metric, lowd.as<double>(), lowi.as<int>()));
 #define GSS_APPEND(D)                                                                                                  \
   hipLaunchKernelGGL(knn_any_append_kernel<D>, grid, dim3(256), 0, s, xdata, centers, m, k, base, kk, tidx.as<int>(),  \
                      tcnt.as<int>(), metric, aniso, ir[0], ir[1], ir[2], idx, count, lowd.as<double>(), lowi.as<int>())

@@ -542,9 +542,6 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   GSS_REQUIRE(nd >= 0 && nd <= N && (nd == 0 || (dlocs && zdata)), "gss_sgs_create: bad conditioning data");
   GSS_REQUIRE(maxneighbors >= 1 && maxneighbors <= N, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, "
               "ui.jl:18-20)", maxneighbors, (long long)N);
-  GSS_REQUIRE(maxneighbors <= SGS_MAX_K || (flags & GSS_SGS_MASK_AFTER_SEARCH),
-              "maxneighbors = %d: the masked neighbour search holds at most %d neighbours (more with "
-              "GSS_SGS_MASK_AFTER_SEARCH, whose search is not masked)", maxneighbors, SGS_MAX_K);
   GSS_REQUIRE(maxneighbors <= SGS_BIG_MAX_K, "maxneighbors = %d: at most %d neighbours in SGS", maxneighbors,
               SGS_BIG_MAX_K);
   hipStream_t s = to_stream(stream);
@@ -627,6 +624,10 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
           else
             GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s));
         }
+      } else if (h->k > SGS_MAX_K) {   // masked search in passes of 64; the lists go through the big weights kernel
+        if (pp == 0) GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
+        GSS_TRY(knn_search_indexed_any(ix, cent.as<double>(), cent.as<double>(), N, h->k, radius, inv_radii,
+                                       rawidx.as<int>(), cnt.as<int>(), s, GSS_METRIC_EUCLIDEAN, rk, rk, bmin.as<int>()));
       } else {
         GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
                                    bmin.as<int>()));

@@ -279,9 +279,8 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
  *   fewer than minneighbors simulated neighbours, or a failed fit, draw from the marginal (seq.jl:107-109,
  *   124-128).  centroids N x d (host), path = visiting order (N 0-based cell indices, NULL = LinearPath),
  *   dlocs / zdata = conditioning cells and their values (initbuff with NearestInit, seq.jl:85);
- *   maxneighbors <= 64 with the masked search (flags = 0), <= 1024 with GSS_SGS_MASK_AFTER_SEARCH (unmasked search
- *   in passes of 64, one workgroup per node for the weights); radius / inv_radii as gss_knn_search.  All
- *   realisations of a handle share the path.
+ *   maxneighbors <= 1024 (beyond 64: the search in passes of 64, one workgroup per node for the weights);
+ *   radius / inv_radii as gss_knn_search.  All realisations of a handle share the path.
  * gss_sgs_realize replaces solvesingle (seq.jl:76-141) for realisations first_real..first_real+nreals-1:
  *   z[node] = mean + sum_j lambda_j (z[nb_j] - mean) + sigma eps, eps = Philox normal (seed, realisation,
  *   cell) or noise[r * N + cell] when given.  out is nreals x N.  The handle keeps its node-major working field

@@ -59,12 +59,13 @@ def test_realisations_match_oracle(dims, vgspec, mean, k, nmin, ball, nd, rpath,
     h.close()
 
 
+@pytest.mark.parametrize("mask_after", [True, False])
 @pytest.mark.parametrize("dims,k,rpath,nd", [((30, 20), 80, False, 5), ((14, 12, 6), 100, True, 0), ((40, 25), 200, True, 7)])
-def test_more_than_64_neighbours_with_the_search_then_filter_mask(dims, k, rpath, nd):
-    """seq.jl:91-98 accepts any maxneighbors.  With `mask = simulated` applied after the search (the front-ends'
-    default) the search is unmasked and runs in passes of 64; the weights come from the one-workgroup-per-node
-    kernel (covariance triangle in LDS up to 180 neighbours, in HBM beyond: k = 200), the sweep from its plain
-    variant.  Oracle = the reference's loop; same 1e-9 as the 64-neighbour kernels."""
+def test_more_than_64_neighbours(dims, k, rpath, nd, mask_after):
+    """seq.jl:91-98 accepts any maxneighbors.  Beyond 64 the search -- unmasked for `mask = simulated` applied after
+    the search (the front-ends' default), masked otherwise -- runs in passes of 64; the weights come from the
+    one-workgroup-per-node kernel (covariance triangle in LDS up to 180 neighbours, in HBM beyond: k = 200), the sweep
+    from its plain variant.  Oracle = the reference's loop; same 1e-9 as the 64-neighbour kernels."""
     from gss.engine import SGSHandle
     gvg, ovg = _vg("spherical", range=0.4 * max(dims), sill=1.2, nugget=0.1)
     cent = offt.grid_centroids(dims)
@@ -73,22 +74,22 @@ def test_more_than_64_neighbours_with_the_search_then_filter_mask(dims, k, rpath
     dl = np.sort(rng.choice(N, nd, replace=False)) if nd else np.empty(0, dtype=np.int64)
     zd = rng.normal(size=nd)
     path = rng.permutation(N) if rpath else None
-    h = SGSHandle(gvg, cent, path, dl, zd, 0.3, k, 1, mask_after_search=True)
+    h = SGSHandle(gvg, cent, path, dl, zd, 0.3, k, 1, mask_after_search=mask_after)
     z = h.realize(7, 0, 3)
     idx, nc, w, sg = h.weights()
     h.close()
-    ref = S.realize(ovg, 0.3, cent, path, dl, zd, 7, 0, 3, maxneighbors=k, minneighbors=1, mask_after_search=True)
+    ref = S.realize(ovg, 0.3, cent, path, dl, zd, 7, 0, 3, maxneighbors=k, minneighbors=1, mask_after_search=mask_after)
     assert np.max(np.abs(z - ref)) < 1e-9
     assert nc.max() > 64 or k > N // 2          # the lists really are longer than one pass of the search
     if nd:
         assert np.array_equal(z[:, dl], np.tile(zd, (3, 1)))
     # one visiting order per realisation on the same kernels
     paths = np.stack([np.random.default_rng([9, r]).permutation(N) for r in range(2)])
-    hp = SGSHandle(gvg, cent, paths, dl, zd, 0.3, k, 1, path_base=0, mask_after_search=True)
+    hp = SGSHandle(gvg, cent, paths, dl, zd, 0.3, k, 1, path_base=0, mask_after_search=mask_after)
     zp = hp.realize(7, 0, 2)
     hp.close()
     for r in range(2):
-        refp = S.realize(ovg, 0.3, cent, paths[r], dl, zd, 7, r, 1, maxneighbors=k, mask_after_search=True)[0]
+        refp = S.realize(ovg, 0.3, cent, paths[r], dl, zd, 7, r, 1, maxneighbors=k, mask_after_search=mask_after)[0]
         assert np.max(np.abs(zp[r] - refp)) < 1e-9
 
 
@@ -170,9 +171,9 @@ def test_solver_through_solve_and_errors():
     assert all(r[li(25, 25)] == 1.0 and r[li(50, 75)] == 0.0 and r[li(75, 50)] == 1.0 for r in reals)
     assert len(sol2["z"]) == 3 and np.all(np.isfinite(sol2["z"][2]))
     cent = grid.centroids()
-    with pytest.raises(_lib.GSSError, match="at most 64"):        # the MASKED search holds 64; search-then-filter more
+    with pytest.raises(_lib.GSSError, match="at most 1024"):
         from gss.engine import SGSHandle
-        SGSHandle(gss.SphericalVariogram(range=35.0), cent, None, None, None, 0.0, 65)
+        SGSHandle(gss.SphericalVariogram(range=35.0), cent, None, None, None, 0.0, 1025)
     with pytest.raises(_lib.GSSError, match="not a permutation"):
         SGSHandle(gss.SphericalVariogram(range=35.0), cent[:10], np.zeros(10, dtype=np.int64), None, None, 0.0, 3)
 
