@@ -500,33 +500,23 @@ int32_t knn_search_indexed(const KnnIndex& ix, const double* centers, int64_t m,
                      centers, m, k, r2, use_ball, aniso, ir[0], ir[1], ir[2], rank, qrank, bminrank, idx, count, lowd, lowi
   GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV,
               "the indexed search has box bounds for the Euclidean, Cityblock and Chebyshev keys only");
-  if (rank) {
-    GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN, "the masked search is Euclidean");
-    GSS_REQUIRE(qrank && bminrank, "masked search needs query ranks and per-batch minimum ranks");
-    switch (ix.dim) {
-      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      default: hipLaunchKernelGGL((knn_pruned_kernel<3, true>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    }
-  } else if (metric == GSS_METRIC_CITYBLOCK) {
-    switch (ix.dim) {
-      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false, GSS_METRIC_CITYBLOCK>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    }
-  } else if (metric == GSS_METRIC_CHEBYSHEV) {
-    switch (ix.dim) {
-      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false, GSS_METRIC_CHEBYSHEV>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    }
-  } else {
-    switch (ix.dim) {
-      case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-      default: hipLaunchKernelGGL((knn_pruned_kernel<3, false>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;
-    }
+  if (rank) GSS_REQUIRE(qrank && bminrank, "masked search needs query ranks and per-batch minimum ranks");
+#define GSS_KNN_LAUNCH(MASKED, METRIC)                                                                               \
+  switch (ix.dim) {                                                                                                   \
+    case 1: hipLaunchKernelGGL((knn_pruned_kernel<1, MASKED, METRIC>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;   \
+    case 2: hipLaunchKernelGGL((knn_pruned_kernel<2, MASKED, METRIC>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;   \
+    default: hipLaunchKernelGGL((knn_pruned_kernel<3, MASKED, METRIC>), grid, dim3(256), 0, s, GSS_KNN_ARGS); break;  \
   }
+  if (rank) {   // SGS: candidates whose rank lies below the query's
+    if (metric == GSS_METRIC_CITYBLOCK) { GSS_KNN_LAUNCH(true, GSS_METRIC_CITYBLOCK) }
+    else if (metric == GSS_METRIC_CHEBYSHEV) { GSS_KNN_LAUNCH(true, GSS_METRIC_CHEBYSHEV) }
+    else { GSS_KNN_LAUNCH(true, GSS_METRIC_EUCLIDEAN) }
+  } else {
+    if (metric == GSS_METRIC_CITYBLOCK) { GSS_KNN_LAUNCH(false, GSS_METRIC_CITYBLOCK) }
+    else if (metric == GSS_METRIC_CHEBYSHEV) { GSS_KNN_LAUNCH(false, GSS_METRIC_CHEBYSHEV) }
+    else { GSS_KNN_LAUNCH(false, GSS_METRIC_EUCLIDEAN) }
+  }
+#undef GSS_KNN_LAUNCH
 #undef GSS_KNN_ARGS
   GSS_HIP(hipGetLastError());
   return GSS_OK;

@@ -561,6 +561,11 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   h->npaths = npaths;
   h->path_base = path_base;
   h->filter_after = (flags & GSS_SGS_MASK_AFTER_SEARCH) ? 1 : 0;
+  const int metric = (flags >> GSS_SGS_METRIC_SHIFT) & 7;
+  GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV,
+              "gss_sgs_create: search distance %d -- Euclidean, Cityblock or Chebyshev (the haversine distance has no "
+              "masked search)", metric);
+  GSS_TRY(check_metric(metric, 0.0, dim, radius, inv_radii));   // a ball only with the Euclidean distance (ui.jl:25-31)
   const int64_t P = npaths;
 
   // visiting rank of every cell (-1 = conditioning cell) per path; each path must be a permutation of 0..N-1
@@ -620,17 +625,18 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
           GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
           if (h->k > SGS_MAX_K)
             GSS_TRY(knn_search_indexed_any(ix, cent.as<double>(), cent.as<double>(), N, h->k, radius, inv_radii,
-                                           rawidx.as<int>(), cnt.as<int>(), s, GSS_METRIC_EUCLIDEAN));
+                                           rawidx.as<int>(), cnt.as<int>(), s, metric));
           else
-            GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s));
+            GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, rawidx.as<int>(), cnt.as<int>(), s,
+                                       nullptr, nullptr, nullptr, metric));
         }
       } else if (h->k > SGS_MAX_K) {   // masked search in passes of 64; the lists go through the big weights kernel
         if (pp == 0) GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
         GSS_TRY(knn_search_indexed_any(ix, cent.as<double>(), cent.as<double>(), N, h->k, radius, inv_radii,
-                                       rawidx.as<int>(), cnt.as<int>(), s, GSS_METRIC_EUCLIDEAN, rk, rk, bmin.as<int>()));
+                                       rawidx.as<int>(), cnt.as<int>(), s, metric, rk, rk, bmin.as<int>()));
       } else {
         GSS_TRY(knn_search_indexed(ix, cent.as<double>(), N, h->k, radius, inv_radii, idxp, cnt.as<int>(), s, rk, rk,
-                                   bmin.as<int>()));
+                                   bmin.as<int>(), metric));
       }
     }
     {

@@ -27,6 +27,7 @@ FFTGS_NO_SPECTRUM = 1
 LUGS_NO_FACTOR = 1
 LUGS_FACT_LU = 2
 SGS_MASK_AFTER_SEARCH = 1
+SGS_METRIC_SHIFT = 4
 
 
 class GSSError(RuntimeError):

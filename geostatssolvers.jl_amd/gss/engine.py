@@ -300,9 +300,10 @@ class SGSHandle:
     one visiting order per realisation -- row p belongs to realisation `path_base + p` (seq.jl:99-102)."""
 
     def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
-                 radii=None, path_base=0, mask_after_search=False):
+                 radii=None, path_base=0, mask_after_search=False, distance=None):
         """`mask_after_search`: GSS_SGS_MASK_AFTER_SEARCH (the k nearest cells of the whole domain, then the simulated
-        ones) instead of the k nearest among the simulated cells."""
+        ones) instead of the k nearest among the simulated cells.  `distance`: the search metric (euclidean,
+        cityblock, chebyshev)."""
         self._l = _lib.lib()
         c = np.ascontiguousarray(centroids, dtype=np.float64)
         if c.ndim == 1:
@@ -323,7 +324,8 @@ class SGSHandle:
         h = C.c_void_p()
         check(self._l.gss_sgs_create_paths(C.byref(h), C.byref(v), float(mean), ptr(c), self.N, dim, ptr(pa), npaths,
                                            int(path_base), ptr(dl), ptr(zd), dl.size, self.k, int(minneighbors), r,
-                                           ptr(ir), _lib.SGS_MASK_AFTER_SEARCH if mask_after_search else 0,
+                                           ptr(ir), (_lib.SGS_MASK_AFTER_SEARCH if mask_after_search else 0) |
+                                           (_lib.metric_spec(distance)[0] << _lib.SGS_METRIC_SHIFT),
                                            current_stream()))
         self._h = h
 

@@ -659,10 +659,12 @@ class _SGSPlan:
     the reference draws a new permutation in every solvesingle (seq.jl:99-102), so realisation r gets the permutation
     `default_rng([seed, r])` and the handles are built per block of realisations, on demand."""
 
-    def __init__(self, engine, make_args, N, path_seed=None, order=None, mask_after=True):
+    def __init__(self, engine, make_args, N, path_seed=None, order=None, mask_after=True, distance=None):
         self.engine, self.args, self.N = engine, make_args, N
         self.path_seed, self.order = path_seed, order
         self.kw = dict(mask_after_search=True) if mask_after else {}
+        if distance not in (None, "euclidean"):
+            self.kw["distance"] = distance
         self.shared = None
 
     def path_of(self, r):
@@ -714,8 +716,9 @@ class SGS(_Solver):
         pre = {}
         for (var,) in [g for g in self.covariables(problem)]:
             p = self.params(var)
-            if p["distance"] not in ("euclidean", None):
-                raise NotImplementedError("only the Euclidean search distance is available on the device")
+            dist = _distance(p)                                                        # seq.jl:91-98
+            if dist is not None and not isinstance(dist, str):
+                raise NotImplementedError("the haversine search distance is not available in SGS on the device")
             path = p["path"]
             order = path_seed = None
             if path is None or (isinstance(path, str) and path == "linear"):
@@ -746,7 +749,8 @@ class SGS(_Solver):
             if mask not in ("after", "during"):
                 raise ValueError(f"mask={mask!r}: 'after' or 'during'")
             pre[var] = _SGSPlan(self.engine, (p["variogram"], cent, dlocs, zd, float(p["mean"]), nmax,
-                                              p["minneighbors"], radius, radii), N, path_seed, order, mask == "after")
+                                              p["minneighbors"], radius, radii), N, path_seed, order, mask == "after",
+                                dist)
         pre["_run"] = _run_state(self, problem)
         return pre
 

@@ -41,6 +41,7 @@ const GSS_MEM_HOST = Int32(0)
 const GSS_KRIG_NO_FACTOR = Int32(1)
 const GSS_LUGS_FACT_LU = Int32(2)
 const GSS_SGS_MASK_AFTER_SEARCH = Int32(1)
+const GSS_SGS_METRIC_SHIFT = 4
 
 # ---- units (src/utils.jl:5-15): affine units are made absolute before the values are stripped for the device;
 #      estimates get the unit back, variances its square (krig.jl:94,160; idw.jl:109; lwr.jl:112,153) --------------
@@ -599,7 +600,9 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
   preproc = Dict{Any,Any}()
   for covars in covariables(problem, solver), var in covars.names
     p = covars.params[Set([var])]
-    p.distance isa Euclidean || throw(ArgumentError("SGSHIP: only the Euclidean search distance is available"))
+    metric, _ = searchmetric(p)                                           # seq.jl:91-98; a ball replaces the metric
+    metric == Int32(3) &&   # GSS_METRIC_HAVERSINE
+      throw(ArgumentError("SGSHIP: the haversine search distance is not available (no masked exhaustive search)"))
     dlocs = Int64.(findall(mask[var]) .- 1)
     zdata = Float64.(buff[var][mask[var]])
     k = p.maxneighbors
@@ -612,7 +615,7 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
     # as the reference does inside solvesingle (seq.jl:99-102), so a RandomPath gives every realisation its own order
     preproc[var] = (pdomain=pdomain, path=p.path, C=C, N=N, d=d, dlocs=dlocs, zdata=zdata, k=Int32(k),
                     minneighbors=Int32(p.minneighbors), radius=radius, ir=ir, vg=cvariogram(p.variogram, d),
-                    mean=Float64(p.mean), shared=Ref{Union{Nothing,Handle}}(nothing))
+                    mean=Float64(p.mean), metric=metric, shared=Ref{Union{Nothing,Handle}}(nothing))
   end
   preproc[:_run] = RunState(problem, solver)
   preproc
@@ -626,7 +629,8 @@ function sgs_handle(par, paths::Matrix{Int64}, base::Int)
     (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Float64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Int64, Int64, Ptr{Int64},
      Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64}, Int32, Ptr{Cvoid}),
     h, vg, par.mean, C, par.N, Int32(par.d), paths, size(paths, 2), Int64(base), dlocs, zdata, length(dlocs), par.k,
-    par.minneighbors, par.radius, ir, GSS_SGS_MASK_AFTER_SEARCH, C_NULL))   # search!(...; mask=simulated): mask after the query
+    par.minneighbors, par.radius, ir, GSS_SGS_MASK_AFTER_SEARCH | (par.metric << GSS_SGS_METRIC_SHIFT),
+    C_NULL))   # search!(...; mask=simulated): mask after the query; bits 4..6: the search metric
   Handle(h[], :sgs)
 end
 

@@ -17,13 +17,14 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import philox
-from .kriging import sqdist
+from .kriging import metric_key
 from .variogram import cov_pairwise
 
 
 def solvesingle(vg, mean: float, cent: np.ndarray, path: np.ndarray, dlocs: np.ndarray, zdata: np.ndarray,
                 eps: np.ndarray, maxneighbors: int = 10, minneighbors: int = 1, radius: Optional[float] = None,
-                radii: Optional[Sequence[float]] = None, mask_after_search: bool = False) -> np.ndarray:
+                radii: Optional[Sequence[float]] = None, mask_after_search: bool = False,
+                distance=None) -> np.ndarray:
     """seq.jl:76-141 for one realisation; `eps[cell]` is the standard normal consumed at that cell.
     `mask_after_search`: how `search!(neighbors, p, searcher, mask=simulated)` (seq.jl:105) treats the mask -- False: the k
     nearest among the simulated cells; True: the k nearest cells of the whole domain (p itself included), of which the
@@ -49,15 +50,15 @@ def solvesingle(vg, mean: float, cent: np.ndarray, path: np.ndarray, dlocs: np.n
         if simulated[ind]:
             continue
         if mask_after_search:
-            d2 = sqdist(cent, cent[ind], inv)
+            d2 = metric_key(cent, cent[ind], distance, inv)                 # `distance` parameter, seq.jl:91-98
             order = np.argsort(d2, kind="stable")[:k]
             if r2 is not None:
                 order = order[d2[order] <= r2]
             nb = order[simulated[order]]
         else:
             cand = np.flatnonzero(simulated)                                # search!(..., mask=simulated) seq.jl:105
-            d2 = sqdist(cent[cand], cent[ind], inv)
-            order = np.argsort(d2, kind="stable")[:k]                       # (d2, index) ascending
+            d2 = metric_key(cent[cand], cent[ind], distance, inv)
+            order = np.argsort(d2, kind="stable")[:k]                       # (key, index) ascending
             if r2 is not None:
                 order = order[d2[order] <= r2]
             nb = cand[order]

@@ -102,13 +102,13 @@ class _LUGS:
 
 class _SGS:
     def __init__(self, vg, centroids, path, dlocs, zdata, mean=0.0, maxneighbors=10, minneighbors=1, radius=None,
-                 radii=None, path_base=0, mask_after_search=False):
+                 radii=None, path_base=0, mask_after_search=False, distance=None):
         self.a = (_ovg(vg), mean, np.asarray(centroids, dtype=np.float64))
         self.path = None if path is None else np.asarray(path, dtype=np.int64)
         self.path_base = path_base
         self.d = (np.asarray(dlocs, dtype=np.int64), np.asarray(zdata, dtype=np.float64))
         self.kw = dict(maxneighbors=maxneighbors, minneighbors=minneighbors, radius=radius, radii=radii,
-                       mask_after_search=mask_after_search)
+                       mask_after_search=mask_after_search, distance=distance)
 
     def close(self):
         pass

@@ -93,6 +93,43 @@ def test_more_than_64_neighbours(dims, k, rpath, nd, mask_after):
         assert np.max(np.abs(zp[r] - refp)) < 1e-9
 
 
+@pytest.mark.parametrize("distance", ["cityblock", "chebyshev"])
+@pytest.mark.parametrize("mask_after", [True, False])
+def test_search_distance_parameter(distance, mask_after):
+    """`distance` of SeqSim's neighbour search (seq.jl:91-98; [DEP] Distances.jl Cityblock / Chebyshev): the masked and
+    the unmasked indexed search rank by that metric's key; off-lattice cell centres keep the keys free of ties.
+    Through the handle (12 and 70 neighbours) and through solve; a ball does not combine with it (ui.jl:25-31)."""
+    import gss
+    from gss import _lib
+    from gss.engine import SGSHandle
+    gvg, ovg = _vg("exponential", range=9.0, sill=0.8)
+    rng = np.random.default_rng(17)
+    cent = offt.grid_centroids((26, 19)) + rng.uniform(-0.3, 0.3, (26 * 19, 2))
+    N = cent.shape[0]
+    dl = np.sort(rng.choice(N, 8, replace=False))
+    zd = rng.normal(size=8)
+    path = rng.permutation(N)
+    for k in (12, 70):
+        h = SGSHandle(gvg, cent, path, dl, zd, 0.0, k, 1, mask_after_search=mask_after, distance=distance)
+        z = h.realize(5, 0, 2)
+        h.close()
+        ref = S.realize(ovg, 0.0, cent, path, dl, zd, 5, 0, 2, maxneighbors=k, mask_after_search=mask_after,
+                        distance=distance)
+        assert np.max(np.abs(z - ref)) < 1e-9
+        refe = S.realize(ovg, 0.0, cent, path, dl, zd, 5, 0, 2, maxneighbors=k, mask_after_search=mask_after)
+        assert np.max(np.abs(ref - refe)) > 1e-6                  # the metric does change the neighbourhoods
+    grid = gss.CartesianGrid(20, 15)
+    prob = gss.SimulationProblem(gss.georef({"z": zd[:3]}, grid.centroids()[[7, 111, 250]]), grid, "z", 2)
+    kw = dict(variogram=gvg, maxneighbors=9, distance=distance)
+    sol = gss.solve(prob, gss.SGS(("z", kw), rng=4, mask="after" if mask_after else "during"))
+    sole = gss.solve(prob, gss.SGS(("z", dict(kw, distance="euclidean")), rng=4, mask="after" if mask_after else "during"))
+    assert np.all(np.isfinite(sol["z"][1])) and np.max(np.abs(sol["z"][1] - sole["z"][1])) > 1e-6
+    with pytest.raises(_lib.GSSError, match="ball"):
+        SGSHandle(gvg, cent, None, dl, zd, 0.0, 8, 1, 5.0, distance=distance)
+    with pytest.raises(_lib.GSSError, match="haversine"):
+        SGSHandle(gvg, cent, None, dl, zd, 0.0, 8, 1, distance=("haversine", 1.0))
+
+
 def test_solver_front_end_with_ninety_neighbours():
     import gss
     grid = gss.CartesianGrid((40, 40), (0.5, 0.5), (1.0, 1.0))
