@@ -132,6 +132,35 @@ def _distance(p):
     return None if p["neighborhood"] is not None else d
 
 
+def _initbuff(engine, init, cent, pdata, var):
+    """`initbuff(domain, vars, init; data)` (lu.jl:86, seq.jl:85; [DEP] GeoStatsBase): which cells receive which data.
+    "nearest" (NearestInit, the default): every non-missing datum goes to the cell whose centroid is nearest, later
+    rows overwrite earlier ones; ("explicit", orig, dest) (ExplicitInit): row orig[i] of the data goes to cell dest[i]
+    (0-based here).  Returns the occupied cells in ascending order and their values."""
+    if pdata is None or var not in pdata.table:
+        return np.empty(0, dtype=np.int64), np.empty(0)
+    zv = np.asarray(pdata[var], dtype=np.float64)
+    buff = {}
+    if init is None or (isinstance(init, str) and init == "nearest"):
+        keep = ~np.isnan(zv)
+        idx, _ = engine.knn_search(cent, pdata.domain.centroids()[keep], 1)
+        for j, v in zip(idx[:, 0], zv[keep]):
+            buff[int(j)] = v
+    elif isinstance(init, (tuple, list)) and len(init) == 3 and init[0] == "explicit":
+        orig, dest = np.asarray(init[1], dtype=np.int64), np.asarray(init[2], dtype=np.int64)
+        if orig.shape != dest.shape or orig.ndim != 1:
+            raise ValueError("ExplicitInit: orig and dest must be index vectors of one length")
+        if orig.size and (orig.min() < 0 or orig.max() >= zv.size or dest.min() < 0 or dest.max() >= cent.shape[0]):
+            raise ValueError("ExplicitInit: index outside the data or the domain")
+        for i, j in zip(orig, dest):
+            if not np.isnan(zv[i]):
+                buff[int(j)] = zv[i]
+    else:
+        raise NotImplementedError(f"init={init!r}: 'nearest' or ('explicit', orig, dest)")
+    dlocs = np.array(sorted(buff), dtype=np.int64)
+    return dlocs, np.array([buff[j] for j in dlocs])
+
+
 def multigrid_order(dims):
     """Coarse-to-fine visiting order of a Cartesian grid ([DEP] Meshes `MultiGridPath`, test/estimation/krig.jl:87):
     cells whose indices are all multiples of the largest power-of-two stride first, then stride / 2, ... down to 1,
@@ -574,8 +603,7 @@ class LUGS(_Solver):
         pdom = problem.domain
         cent = pdom.centroids()
         N = cent.shape[0]
-        if self.globals.get("init", "nearest") != "nearest":
-            raise NotImplementedError("only NearestInit is available")
+        init = self.globals.get("init", "nearest")
         pre = {}
         for conames in self.covariables(problem):
             assert len(conames) in (1, 2), "invalid number of covariables"          # lu.jl:96
@@ -587,19 +615,7 @@ class LUGS(_Solver):
                 fact = p["factorization"]                                            # lu.jl:107
                 if fact not in ("cholesky", "lu"):
                     raise ValueError(f"factorization={fact!r}: 'cholesky' or 'lu' (lu.jl:70)")
-                buff = np.zeros(N)
-                mask = np.zeros(N, dtype=bool)
-                pdata = problem.data
-                if pdata is not None and var in pdata.table:                         # initbuff, lu.jl:86
-                    xd = pdata.domain.centroids()
-                    zd = np.asarray(pdata[var], dtype=np.float64)
-                    keep = ~np.isnan(zd)
-                    idx, _ = self.engine.knn_search(cent, xd[keep], 1)
-                    for j, v in zip(idx[:, 0], zd[keep]):
-                        buff[j] = v
-                        mask[j] = True
-                dlocs = np.flatnonzero(mask)                                          # lu.jl:113
-                z1 = buff[dlocs]                                                      # lu.jl:114
+                dlocs, z1 = _initbuff(self.engine, init, cent, problem.data, var)     # lu.jl:86,113-114
                 if p["mean"] is not None and dlocs.size > 0:
                     warnings.warn("mean can only be specified in unconditional simulation")   # lu.jl:142-144
                 mu = 0.0 if p["mean"] is None else float(p["mean"])                   # lu.jl:147
@@ -711,8 +727,7 @@ class SGS(_Solver):
         pdom = problem.domain
         cent = pdom.centroids()
         N = cent.shape[0]
-        if self.globals.get("init", "nearest") != "nearest":
-            raise NotImplementedError("only NearestInit is available")
+        init = self.globals.get("init", "nearest")
         pre = {}
         for (var,) in [g for g in self.covariables(problem)]:
             p = self.params(var)
@@ -731,18 +746,7 @@ class SGS(_Solver):
                 raise NotImplementedError(f"path {path!r}: give 'linear', 'multigrid', ('random', seed) or a visiting order")
             else:
                 order = np.asarray(path, dtype=np.int64)
-            dlocs, zd = np.empty(0, dtype=np.int64), np.empty(0)
-            pdata = problem.data
-            if pdata is not None and var in pdata.table:                              # initbuff, seq.jl:85
-                xd = pdata.domain.centroids()
-                zv = np.asarray(pdata[var], dtype=np.float64)
-                keep = ~np.isnan(zv)
-                idx, _ = self.engine.knn_search(cent, xd[keep], 1)
-                buff = {}
-                for j, v in zip(idx[:, 0], zv[keep]):
-                    buff[int(j)] = v
-                dlocs = np.array(sorted(buff), dtype=np.int64)
-                zd = np.array([buff[j] for j in dlocs])
+            dlocs, zd = _initbuff(self.engine, init, cent, problem.data, var)         # seq.jl:85
             _, nmax = searcher_ui(pdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # seq.jl:65
             radius, radii = _ball(p["neighborhood"])
             mask = self.globals.get("mask", "after")

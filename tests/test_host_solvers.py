@@ -157,3 +157,25 @@ def test_custom_paths_return_results_in_traversal_order():
     assert np.array_equal(ip["z"], ib["z"][order]) and np.array_equal(ip["z_distance"], ib["z_distance"][order])
     with pytest.raises(ValueError, match="permutation"):
         gss.solve(prob, gss.LWRSolver(("z", dict(path=np.zeros(48, dtype=int))), engine=OracleEngine))
+
+
+def test_explicit_init_places_the_data_where_told():
+    """`init = ExplicitInit(orig, dest)` ([DEP] GeoStatsBase, initbuff at lu.jl:86 / seq.jl:85): row orig[i] of the
+    data goes to cell dest[i], wherever its coordinates are; NearestInit stays the default; missing values are skipped."""
+    data = gss.georef({"z": [0.0, np.nan, 2.0, 3.0]}, np.array([[0.1], [5.2], [9.2], [50.3]]))
+    grid = gss.CartesianGrid(60)
+    init = ("explicit", [3, 1, 0], [5, 6, 40])      # datum 3 -> cell 5, datum 1 (missing) -> nowhere, datum 0 -> cell 40
+    vg = gss.SphericalVariogram(range=8.0)
+    for solver in (gss.LUGS(("z", dict(variogram=vg)), engine=OracleEngine, init=init, rng=1),
+                   gss.SGS(("z", dict(variogram=vg, maxneighbors=6)), engine=OracleEngine, init=init, rng=1)):
+        sol = gss.solve(gss.SimulationProblem(data, grid, "z", 2), solver)
+        for r in sol["z"]:
+            assert r[5] == 3.0 and r[40] == 0.0 and r[6] != 2.0 and np.all(np.isfinite(r))
+    near = gss.solve(gss.SimulationProblem(data, grid, "z", 1), gss.SGS(("z", dict(variogram=vg)), engine=OracleEngine, rng=1))
+    assert near["z"][0][0] == 0.0 and near["z"][0][9] == 2.0 and near["z"][0][50] == 3.0      # NearestInit
+    with pytest.raises(NotImplementedError):
+        gss.solve(gss.SimulationProblem(data, grid, "z", 1), gss.LUGS(("z", dict(variogram=vg)), engine=OracleEngine,
+                                                                      init="random"))
+    with pytest.raises(ValueError, match="outside"):
+        gss.solve(gss.SimulationProblem(data, grid, "z", 1), gss.SGS(("z", dict(variogram=vg)), engine=OracleEngine,
+                                                                     init=("explicit", [0], [60])))
