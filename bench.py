@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--ndata", type=int, default=1000)
     ap.add_argument("--npoints", type=int, default=1_000_000, help="domain points per GPU per step")
     ap.add_argument("--factor-broadcast", action="store_true")
+    ap.add_argument("--sync-fit", action="store_true", help="gss_krig_create waits for the fit (default: "
+                    "GSS_KRIG_ASYNC_FIT, the fit beside the first assembly, as the solver front-end runs it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=30000, help="points of the CPU baseline sample")
     ap.add_argument("--fftgs", type=int, default=512, help="FFTGS grid edge (0 disables the leg)")
@@ -140,7 +142,7 @@ def main():
             parallel.broadcast_(h.factor_tensor(), 0)
             h.adopt_factor()
         else:
-            h = KrigHandle(vg, OK, x, z)
+            h = KrigHandle(vg, OK, x, z, async_fit=not a.sync_fit)   # as solve() does: the fit beside the assembly
         out = h.predict_global(x0_dev)
         return h, out
 

@@ -16,6 +16,8 @@
 //                         and accumulates the dual-form mean on the fly
 //   krig_quadform_kernel  K3: FP64 MFMA triangular GEMM W' * R fused with the signed column norms
 #include "gss_internal.h"
+
+#include <mutex>
 #include "mfma_f64.h"
 
 #include <cmath>
@@ -557,9 +559,14 @@ struct gss_krig {
   bool fit_pending = false;
   int* fit_info = nullptr;
   hipStream_t fit_stream = nullptr;  // stream of the fit in flight (a retry goes back on it)
+  // GSS_KRIG_ASYNC_FIT: the fit runs on the library's fit stream beside whatever the caller queues next (K1 of the
+  // first prediction); its two status words travel to pinned host memory on that stream, in front of fit_done
+  bool fit_async = false;
+  int* fit_info_host = nullptr;
   ~gss_krig() {
     if (fit_pending && fit_done) (void)hipEventSynchronize(fit_done);
     if (fit_done) (void)hipEventDestroy(fit_done);
+    if (fit_info_host) (void)hipHostFree(fit_info_host);
   }
   bool factored = false;
   double* Wp() const { return factor.as<double>(); }
@@ -783,16 +790,53 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
   return GSS_OK;
 }
 
-static int32_t krig_factorize(gss_krig* h, hipStream_t s) {
+// high-priority stream of the process for asynchronous fits (fenced by events against the caller's stream)
+static hipStream_t krig_fit_stream() {
+  static std::mutex mu;
+  static hipStream_t st = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!st) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
+  }
+  return st;
+}
+
+// async: on the fit stream, behind everything `s` holds now; the caller's stream is joined by krig_join_device
+static int32_t krig_factorize(gss_krig* h, hipStream_t s, bool async = false) {
+  hipStream_t fs = s;
+  if (async) {
+    fs = krig_fit_stream();
+    if (!fs) {
+      async = false;
+      fs = s;
+    }
+  }
+  if (async) {
+    ScopedEvent e0;
+    GSS_HIP(e0.create());
+    GSS_HIP(hipEventRecord(e0, s));
+    GSS_HIP(hipStreamWaitEvent(fs, e0, 0));
+    if (!h->fit_info_host) GSS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->fit_info_host), 2 * sizeof(int), hipHostMallocDefault));
+  }
   FitPlan fp;
   GSS_TRY(krig_fit_plan(h, &fp));
-  GSS_TRY(krig_fit_enqueue(h, fp, s));
+  GSS_TRY(krig_fit_enqueue(h, fp, fs));
   h->fit_info = fp.info;
-  h->fit_stream = s;
+  h->fit_stream = fs;
+  h->fit_async = async;
+  if (async) GSS_HIP(hipMemcpyAsync(h->fit_info_host, fp.info, 2 * sizeof(int), hipMemcpyDeviceToHost, fs));
   if (!h->fit_done) GSS_HIP(hipEventCreateWithFlags(&h->fit_done, hipEventDisableTiming));
-  GSS_HIP(hipEventRecord(h->fit_done, s));
+  GSS_HIP(hipEventRecord(h->fit_done, fs));
   h->fit_pending = true;
   h->factored = true;
+  return GSS_OK;
+}
+
+// device side of the join: what `s` receives next runs behind the fit
+static int32_t krig_join_device(gss_krig* h, hipStream_t s) {
+  if (h->fit_pending && h->fit_done && h->fit_stream != s) GSS_HIP(hipStreamWaitEvent(s, h->fit_done, 0));
   return GSS_OK;
 }
 
@@ -802,7 +846,12 @@ static int32_t krig_fit_wait(gss_krig* h) {
   h->fit_pending = false;
   GSS_HIP(hipEventSynchronize(h->fit_done));
   int hinfo[2] = {0, 0};
-  GSS_HIP(hipMemcpy(hinfo, h->fit_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  if (h->fit_async) {   // the words were copied on the fit stream in front of the event: no blocking copy (it would
+    hinfo[0] = h->fit_info_host[0];   // wait for the caller's stream as well)
+    hinfo[1] = h->fit_info_host[1];
+  } else {
+    GSS_HIP(hipMemcpy(hinfo, h->fit_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
+  }
   h->fit_ws.release();
   h->fit_info = nullptr;
   if (hinfo[0] < 0) {
@@ -813,7 +862,7 @@ static int32_t krig_fit_wait(gss_krig* h) {
     if (!retrying) {
       potrf_panel_disable();
       retrying = true;
-      int32_t rc = krig_factorize(h, h->fit_stream);
+      int32_t rc = krig_factorize(h, h->fit_stream, false);
       if (rc == GSS_OK) rc = krig_fit_wait(h);
       retrying = false;
       return rc;
@@ -924,8 +973,9 @@ int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t var
   // the factor buffer always exists so that a broadcast can land in it
   GSS_TRY(h->factor.alloc(sizeof(double) * (size_t)(h->ldw * h->N1pad + h->N1pad)));
   if ((flags & GSS_KRIG_NO_FACTOR) == 0) {
-    GSS_TRY(krig_factorize(h, s));
-    GSS_TRY(krig_fit_wait(h));
+    const bool async = (flags & GSS_KRIG_ASYNC_FIT) != 0;
+    GSS_TRY(krig_factorize(h, s, async));
+    if (!async) GSS_TRY(krig_fit_wait(h));   // otherwise joined by the first call that needs the factor
   }
   guard.h = nullptr;
   *out = h;
@@ -946,6 +996,7 @@ int32_t gss_krig_info(const gss_krig_t* h, int64_t* n, int32_t* nc) {
 
 int32_t gss_krig_factor_buffer(gss_krig_t* h, void** dev_ptr, int64_t* bytes) {
   GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
+  GSS_TRY(krig_fit_wait(h));   // (an asynchronous fit: the buffer is handed out complete)
   *dev_ptr = h->factor.p;
   *bytes = (int64_t)(sizeof(double) * (size_t)(h->ldw * h->N1pad + h->N1pad));
   return GSS_OK;
@@ -1018,6 +1069,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
       GSS_TRY(launch_drift_rows(h, x0, dv, mv, cols, Rws + h->n * ldr, ldr, nrows, s));
     }
     }
+    GSS_TRY(krig_join_device(h, s));   // an asynchronous fit ran beside the assembly; the quadratic form needs it
     ProfScope pq("krig_quadform", s);
     {
       const int nstrips = (int)(cols / BN);
@@ -1059,7 +1111,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
   GSS_TRY(sstat.back(status, (size_t)m, mem, s));
-  return GSS_OK;
+  return krig_fit_wait(h);   // status of an asynchronous fit (it finished while the assembly ran)
 }
 
 
@@ -1109,6 +1161,8 @@ int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t
   if (m == 0 || nbatch == 0) return GSS_OK;
   GSS_REQUIRE(xdom && zbatch && mean_out, "gss_krig_predict_global_batch: NULL array");
   hipStream_t s = to_stream(stream);
+  GSS_TRY(krig_join_device(h, s));
+  GSS_TRY(krig_fit_wait(h));
   const int dim = h->dim;
   const int64_t n = h->n, N1 = h->N1, ldw = h->ldw;
   Staged sx, sz, so;

@@ -23,6 +23,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libgss_hip.so"))
 MEM_HOST, MEM_DEVICE = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ALLOC = range(7)
 KRIG_NO_FACTOR = 1
+KRIG_ASYNC_FIT = 2
 FFTGS_NO_SPECTRUM = 1
 LUGS_NO_FACTOR = 1
 LUGS_FACT_LU = 2

@@ -87,7 +87,10 @@ def _alias_tensor(owner, dev_ptr, nbytes):
 class KrigHandle:
     """gss_krig_t*: fitted kriging system living in HBM."""
 
-    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True):
+    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True, async_fit=False):
+        """`async_fit`: GSS_KRIG_ASYNC_FIT -- the constructor returns once the fit is queued; the first global
+        prediction assembles its right-hand sides beside it and reports the fit's status itself (the order of
+        `solve`: fit, then predict, krig.jl:166-186)."""
         self._l = _lib.lib()
         x = np.ascontiguousarray(xdata, dtype=np.float64)
         if x.ndim == 1:
@@ -101,7 +104,8 @@ class KrigHandle:
         v = _vg_struct(vg, self.dim, extent=_extent(x))
         check(self._l.gss_krig_create(C.byref(h), C.byref(v), variant, float(mean or 0.0), int(degree or 0),
                                       self.ndrift, ptr(x), ptr(zz), ptr(dd), self.n,
-                                      0 if factor else _lib.KRIG_NO_FACTOR, current_stream()))
+                                      (0 if factor else _lib.KRIG_NO_FACTOR) |
+                                      (_lib.KRIG_ASYNC_FIT if (async_fit and factor) else 0), current_stream()))
         self._h = h
 
     def close(self):

@@ -294,7 +294,8 @@ class KrigingSolver(_Solver):
                 drift_dom = np.stack([[f(c) for f in p["drifts"]] for c in xdom]).astype(np.float64)
             exact = q["maxneighbors"] is None                          # krig.jl:151
             mk = lambda compute: self.engine.Krig(p["variogram"], q["variant"], q["x"], q["z"], mean=p["mean"],  # noqa: E731
-                                                  degree=p["degree"], drift_data=drift_data, factor=compute)
+                                                  degree=p["degree"], drift_data=drift_data, factor=compute,
+                                                  async_fit=exact)   # fit and the first assembly side by side
             # the fit (krig.jl:176) is replicated by default: below n ~ 2 000 recomputing the factor on every GPU is
             # cheaper than any collective; share="broadcast" sends rank 0's factor instead
             h = parallel.replicate_state(mk, self._share("recompute")) if exact else mk(False)

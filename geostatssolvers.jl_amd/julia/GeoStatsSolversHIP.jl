@@ -39,6 +39,7 @@ const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 
 const GSS_MEM_HOST = Int32(0)
 const GSS_KRIG_NO_FACTOR = Int32(1)
+const GSS_KRIG_ASYNC_FIT = Int32(2)     # fit beside the first assembly; status at the first global prediction
 const GSS_LUGS_FACT_LU = Int32(2)
 const GSS_SGS_MASK_AFTER_SEARCH = Int32(1)
 const GSS_SGS_METRIC_SHIFT = 4
@@ -252,7 +253,7 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
       check(ccall((:gss_krig_create, libgss), Int32,
                   (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Int32, Float64, Int32, Int32, Ptr{Float64}, Ptr{Float64},
                    Ptr{Float64}, Int64, Int32, Ptr{Cvoid}),
-                  h, vg, variant, skmean, degree, ndrift, X, z, Fd, n, exact ? Int32(0) : GSS_KRIG_NO_FACTOR, C_NULL))
+                  h, vg, variant, skmean, degree, ndrift, X, z, Fd, n, exact ? GSS_KRIG_ASYNC_FIT : GSS_KRIG_NO_FACTOR, C_NULL))
       try
         if exact                                                         # krig.jl:166-186
           check(ccall((:gss_krig_predict_global, libgss), Int32,

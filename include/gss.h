@@ -152,7 +152,14 @@ int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double
  *   coordinates for the drift centring / scaling and the search index, then uploads them); only the predict calls
  *   take `mem`.
  */
-enum { GSS_KRIG_NO_FACTOR = 1 /* moving-neighbourhood use only, or factor arrives by broadcast */ };
+enum {
+  GSS_KRIG_NO_FACTOR = 1, /* moving-neighbourhood use only, or factor arrives by broadcast */
+  /* gss_krig_create returns once the fit is queued (on a stream of the library, behind what `stream` holds): the
+   * first gss_krig_predict_global assembles its right-hand sides beside it, and reports the fit's status
+   * (GSS_ERR_NOT_POSDEF) itself; any other use of the factor waits for the fit first.  The reference's `solve`
+   * fits and predicts in one call (krig.jl:166-186), so nothing changes for it. */
+  GSS_KRIG_ASYNC_FIT = 2
+};
 
 int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t variant, double sk_mean,
                         int32_t degree, int32_t ndrift, const double* xdata, const double* z,

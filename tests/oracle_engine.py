@@ -16,7 +16,7 @@ def _ovg(vg):
 
 
 class _Krig:
-    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True):
+    def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True, async_fit=False):
         self.vg, self.variant = _ovg(vg), variant
         self.x = np.atleast_2d(np.asarray(xdata, dtype=np.float64))
         self.z = np.asarray(z, dtype=np.float64)

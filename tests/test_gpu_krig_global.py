@@ -266,3 +266,40 @@ def test_calls_on_different_streams_are_ordered():
         assert all(torch.equal(p, q) for p, q in zip(ob, ref_b))
     ha.close()
     hb.close()
+
+
+def test_asynchronous_fit_same_results_and_status_at_the_first_prediction():
+    """GSS_KRIG_ASYNC_FIT: the constructor returns once the fit is queued on the library's fit stream, the first global
+    prediction assembles its right-hand sides beside it and joins before the quadratic form -- bit-identical results;
+    a covariance matrix that is not positive definite is reported by that prediction (by the constructor otherwise);
+    the factor buffer (broadcast) and the batched means wait for the fit too."""
+    import torch
+    import gss
+    from gss import _lib
+    from gss.engine import KrigHandle, OK, UK
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 100, (700, 3))
+    z = rng.normal(size=700)
+    x0 = torch.as_tensor(rng.uniform(0, 100, (40000, 3)), device="cuda")
+    vg = gss.MaternVariogram(range=30.0, order=1.5)
+    for variant, kw in ((OK, {}), (UK, dict(degree=1))):
+        a = KrigHandle(vg, variant, x, z, **kw).predict_global(x0)
+        h = KrigHandle(vg, variant, x, z, async_fit=True, **kw)
+        b = h.predict_global(x0)
+        c = h.predict_global(x0)                       # the fit has been joined: an ordinary call
+        assert all(torch.equal(u, v) and torch.equal(u, w) for u, v, w in zip(a, b, c))
+        h.close()
+    h = KrigHandle(vg, OK, x, z, async_fit=True)
+    assert h.factor_tensor().numel() > 0               # waits for the fit
+    zb = torch.as_tensor(rng.normal(size=(3, 700)), device="cuda")
+    ref = KrigHandle(vg, OK, x, z).predict_global_batch(x0[:500], zb)
+    got = KrigHandle(vg, OK, x, z, async_fit=True).predict_global_batch(x0[:500], zb)
+    assert torch.equal(ref, got)
+    xd = np.vstack([x[:50], x[:1]])                    # a duplicate sample: singular covariance matrix
+    zd = np.r_[z[:50], z[0]]
+    with pytest.raises(_lib.GSSError, match="positive definite"):
+        KrigHandle(gss.GaussianVariogram(range=30.0), OK, xd, zd)
+    hbad = KrigHandle(gss.GaussianVariogram(range=30.0), OK, xd, zd, async_fit=True)
+    with pytest.raises(_lib.GSSError, match="positive definite"):
+        hbad.predict_global(x0[:1000])
+    hbad.close()
