@@ -529,22 +529,25 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
                                                              double* __restrict__ mean_out,
                                                              double* __restrict__ var_out,
                                                              uint8_t* __restrict__ status_out) {
-  __shared__ double nx_[K5_WAVES][LMAX_K][3];
-  __shared__ double nxs_[K5_WAVES][LMAX_K][3];   // the same coordinates divided by the radii of the model's ball (KIND >= 0)
-  __shared__ double colv_[K5_WAVES][2][LMAX_K];  // c0 column and data column, one entry per neighbour
-  __shared__ int nidx_[K5_WAVES][LMAX_K];
+  __shared__ double nxs_[K5_WAVES][LMAX_K][3];   // neighbour coordinates, divided by the radii of the model's ball (KIND >= 0)
   __shared__ signed char se[LMAX_NC][4];
   __shared__ double S4[2][K5_WAVES][16 * 17];    // diagonal tiles in / inverse factors out, double buffered by step parity
   __shared__ int badflag[2][K5_WAVES];
   __shared__ double G_[K5_WAVES][16][17];
+  // The right-hand-side columns [c0 | z | F] are evaluated with lane = neighbour (one value per lane and column, the
+  // exponents of a drift term being uniform) and pass through LDS into tile layout.  Column q of wave w lives in the
+  // wave's OWN pieces of the buffers above -- S4[0][w], S4[1][w], G_[w], four columns of 64 each -- which nobody
+  // touches before the wave has read them back, so the hand-over needs no barrier.
+  static_assert(4 * LMAX_K <= 16 * 17 && LMAX_RHS <= 12, "right-hand-side columns do not fit the wave's own tiles");
 
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  double (*nx)[3] = nx_[wave];
   double (*nxs)[3] = nxs_[wave];
-  double (*colv)[LMAX_K] = colv_[wave];
-  int* nidx = nidx_[wave];
   double (*G)[17] = G_[wave];
+  auto rhs_col = [&](int q) -> double* {   // column q (0 = c0, 1 = data, 2 + t = drift term t) of this wave
+    double* base = q < 4 ? &S4[0][wave][0] : (q < 8 ? &S4[1][wave][0] : &G_[wave][0][0]);
+    return base + (q & 3) * LMAX_K;
+  };
   const int64_t pw = (int64_t)blockIdx.x * K5_WAVES + wave;
   const bool inrange = pw < m;
   const int64_t p = inrange ? pw : m - 1;
@@ -578,14 +581,30 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
     for (int a = 0; a < DIM; ++a) {
       xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
       xjs[a] = (KIND >= 0 && vg.aniso) ? xj[a] * vg.ir[a] : xj[a];
-      nx[lane][a] = xj[a];
       nxs[lane][a] = xjs[a];
     }
-    nidx[lane] = nj;
     double zz = act ? z[nj] : 0.0;
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-    colv[0][lane] = act ? cov_pair_k<DIM, KIND>(vg, xjs, c0s) : 0.0;
-    colv[1][lane] = act ? zz : 0.0;
+    rhs_col(0)[lane] = act ? cov_pair_k<DIM, KIND>(vg, xjs, c0s) : 0.0;
+    rhs_col(1)[lane] = act ? zz : 0.0;
+    // drift columns: monomials about the estimation point (uniform exponents), external drifts, or the constant
+    double um[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) um[a] = (xj[a] - c0[a]) * sp.inv_scale;
+#pragma unroll
+    for (int t = 0; t < LMAX_NC; ++t) {
+      if (t < nc) {
+        double f = 1.0;
+        if (sp.variant == GSS_KRIG_UNIVERSAL) {
+#pragma unroll
+          for (int a = 0; a < DIM; ++a)
+            for (int w = 0; w < sp.e[t][a]; ++w) f *= um[a];
+        } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
+          f = act ? drift_data[(int64_t)nj * nc + t] : 0.0;
+        }
+        rhs_col(2 + t)[lane] = act ? f : 0.0;
+      }
+    }
     if (threadIdx.x == 0) {  // static indices only: a lane-indexed read would force the argument struct into scratch
 #pragma unroll
       for (int cc = 0; cc < LMAX_NC; ++cc)
@@ -623,45 +642,22 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
     }
   }
-  // right-hand sides: column 0 = c0, 1 = data, 2 + q = drift q
+  // right-hand sides: column 0 = c0, 1 = data, 2 + q = drift q, zero beyond; rows beyond the neighbour count are zero
   d4_t B[4];
-  const int q = c - 2;
-  int e0 = 0, e1 = 0, e2 = 0;
-  if (q >= 0 && q < nc) {
-    e0 = se[q][0];
-    e1 = se[q][1];
-    e2 = se[q][2];
-  }
+  {
+    const double* colc = rhs_col(c < LMAX_RHS ? c : 0);
+    const bool used = c < 2 + nc;
 #pragma unroll
-  for (int K = 0; K < 4; ++K) {
-    if (K < nt) {
+    for (int K = 0; K < 4; ++K) {
+      if (K < nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * K + g + 4 * r;
-        double v = 0.0;
-        if (row < cnt) {
-          if (c < 2) v = colv[c][row];
-          else if (q < nc) {
-            if (sp.variant == GSS_KRIG_UNIVERSAL) {
-              const int ee[3] = {e0, e1, e2};
-              v = 1.0;
-#pragma unroll
-              for (int a = 0; a < DIM; ++a) {
-                const double u = (nx[row][a] - c0[a]) * sp.inv_scale;
-                for (int w = 0; w < ee[a]; ++w) v *= u;
-              }
-            } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
-              v = drift_data[(int64_t)nidx[row] * nc + q];
-            } else {
-              v = 1.0;  // ordinary kriging: the constant drift
-            }
-          }
+        for (int r = 0; r < 4; ++r) {
+          const double v = colc[16 * K + g + 4 * r];
+          B[K][r] = used ? v : 0.0;
         }
-        B[K][r] = v;
       }
     }
   }
-
   bool bad = false;
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   // fully unrolled block steps (a rolled loop around one copy of the diagonal factorisation, with switch-selected
