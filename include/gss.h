@@ -16,7 +16,7 @@
  *     without a copy.
  *   - all floating point is FP64, indices are int32/int64 as declared, 0-based on this side.
  *   - `mem` says where the LARGE arrays of the call live: GSS_MEM_HOST (library copies through
- *     PCIe) or GSS_MEM_DEVICE (pointers are HBM addresses on the current device; nothing is
+ *     PCIe; gss_krig_predict_global overlaps the copies with the computation, piece by piece) or GSS_MEM_DEVICE (pointers are HBM addresses on the current device; nothing is
  *     copied and the call is asynchronous on `stream`).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls may arrive on different streams:
  *     the library recycles its scratch memory across calls, so a call on a new stream is ordered (event wait,

@@ -303,3 +303,48 @@ def test_asynchronous_fit_same_results_and_status_at_the_first_prediction():
     with pytest.raises(_lib.GSSError, match="positive definite"):
         hbad.predict_global(x0[:1000])
     hbad.close()
+
+
+def test_host_arrays_in_pieces_equal_device_arrays():
+    """Host arrays beyond 131 072 points are handed over in pieces whose transfers overlap the computation of their
+    neighbours (krig.hip, HOST_PIPE_POINTS): same results as one call on device arrays, also with a last piece that is
+    not full, external drifts riding along, and with the switch off."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    import gss
+    from gss.engine import KrigHandle, OK, EDK
+    rng = np.random.default_rng(12)
+    x = rng.uniform(0, 100, (300, 3))
+    z = rng.normal(size=300)
+    m = 131072 * 2 + 4321
+    x0 = rng.uniform(0, 100, (m, 3))
+    vg = gss.SphericalVariogram(range=40.0, nugget=0.05)
+    h = KrigHandle(vg, OK, x, z)
+    dev = h.predict_global(torch.as_tensor(x0, device="cuda"))
+    host = h.predict_global(x0)
+    for a, b in zip(dev, host):
+        assert isinstance(b, np.ndarray) and np.array_equal(a.cpu().numpy(), b)
+    fd, f0 = rng.normal(size=(300, 2)), rng.normal(size=(m, 2))
+    he = KrigHandle(vg, EDK, x, z, drift_data=fd)
+    dev = he.predict_global(torch.as_tensor(x0, device="cuda"), torch.as_tensor(f0, device="cuda"))
+    host = he.predict_global(x0, f0)
+    for a, b in zip(dev, host):
+        assert np.array_equal(a.cpu().numpy(), b)
+    code = ("import numpy as np, gss; from gss.engine import KrigHandle, OK\n"
+            "rng = np.random.default_rng(12); x = rng.uniform(0, 100, (300, 3)); z = rng.normal(size=300)\n"
+            "x0 = rng.uniform(0, 100, (%d, 3))\n"
+            "mu, var, st = KrigHandle(gss.SphericalVariogram(range=40.0, nugget=0.05), OK, x, z).predict_global(x0)\n"
+            "np.save(%r, np.stack([mu, var]))\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, GSS_KRIG_HOST_PIPELINE="0",
+                   PYTHONPATH=os.pathsep.join([os.path.join(root, "geostatssolvers.jl_amd"), os.environ.get("PYTHONPATH", "")]))
+        subprocess.run([sys.executable, "-c", code % (m, out)], check=True, env=env, timeout=300)
+        ref = np.load(out)
+    h2 = KrigHandle(vg, OK, x, z)
+    mu, var, _ = h2.predict_global(x0)
+    assert np.array_equal(ref[0], mu) and np.array_equal(ref[1], var)
