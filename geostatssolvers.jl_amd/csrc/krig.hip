@@ -1058,7 +1058,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
     piped = cin != nullptr && cout != nullptr;
   }
   static const int64_t piece = std::getenv("GSS_KRIG_HOST_PIECE") ? atoll(std::getenv("GSS_KRIG_HOST_PIECE")) : HOST_PIPE_POINTS;   // A/B switch
-  if (piped && mc > piece) mc = piece;
+  if (piped && piece >= 256 && mc > piece) mc = piece;
   double *Rws = nullptr, *mpart = nullptr;
   GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
   const int64_t ldr = mc;
