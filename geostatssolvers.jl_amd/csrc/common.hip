@@ -1,6 +1,8 @@
 // Library context, error reporting, memory staging, variogram validation.
 #include "gss_internal.h"
 
+#include <mutex>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -177,6 +179,84 @@ int32_t Staged::out(void* dst, size_t bytes, int32_t mem) {
 int32_t Staged::back(void* dst, size_t bytes, int32_t mem, hipStream_t s) {
   if (dst == nullptr || mem == GSS_MEM_DEVICE) return GSS_OK;
   GSS_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+// ---- HostPipe (gss_internal.h) ---------------------------------------------------------------------------------
+static hipStream_t host_copy_stream(int i) {
+  static std::mutex mu;
+  static hipStream_t st[2] = {nullptr, nullptr};
+  std::lock_guard<std::mutex> lock(mu);
+  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
+  return st[i];
+}
+
+HostPipe::~HostPipe() {
+  if (ev_in) (void)hipEventDestroy(ev_in);
+  if (ev_done) (void)hipEventDestroy(ev_done);
+}
+
+int32_t HostPipe::begin(int32_t mem, int64_t m, hipStream_t s) {
+  static const bool enabled = !(std::getenv("GSS_HOST_PIPELINE") && std::getenv("GSS_HOST_PIPELINE")[0] == '0');
+  on = false;
+  if (mem != GSS_MEM_HOST || !enabled || m <= PIECE) return GSS_OK;
+  cin = host_copy_stream(0);
+  cout = host_copy_stream(1);
+  if (!cin || !cout) return GSS_OK;
+  if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
+    return GSS_OK;
+  // the scratch behind the device images may still be in use by work queued on s: the copy streams start behind it
+  GSS_HIP(hipEventRecord(ev_done, s));
+  GSS_HIP(hipStreamWaitEvent(cin, ev_done, 0));
+  GSS_HIP(hipStreamWaitEvent(cout, ev_done, 0));
+  on = true;
+  return GSS_OK;
+}
+
+void HostPipe::add_in(const void* host, void* dev, size_t stride) {
+  if (!host || !dev || nin >= 4) return;
+  ins[nin++] = Arr{static_cast<const char*>(host), nullptr, static_cast<char*>(dev), stride};
+}
+
+void HostPipe::add_out(void* host, void* dev, size_t stride) {
+  if (!host || !dev || nout >= 6) return;
+  outs[nout++] = Arr{nullptr, static_cast<char*>(host), static_cast<char*>(dev), stride};
+}
+
+int32_t HostPipe::fetch(int64_t off, int64_t n, hipStream_t s) {
+  if (!on) return GSS_OK;
+  for (int i = 0; i < nin; ++i)
+    GSS_HIP(hipMemcpyAsync(ins[i].dev + (size_t)off * ins[i].stride, ins[i].host_in + (size_t)off * ins[i].stride,
+                           (size_t)n * ins[i].stride, hipMemcpyHostToDevice, cin));
+  GSS_HIP(hipEventRecord(ev_in, cin));
+  GSS_HIP(hipStreamWaitEvent(s, ev_in, 0));
+  return GSS_OK;
+}
+
+int32_t HostPipe::deliver(int64_t off, int64_t n, hipStream_t s) {
+  if (!on) return GSS_OK;
+  // the piece before (its fence is already on the copy stream), behind this piece's launches
+  for (int i = 0; i < nout && pend_n > 0; ++i)
+    GSS_HIP(hipMemcpyAsync(outs[i].host_out + (size_t)pend_off * outs[i].stride,
+                           outs[i].dev + (size_t)pend_off * outs[i].stride, (size_t)pend_n * outs[i].stride,
+                           hipMemcpyDeviceToHost, cout));
+  GSS_HIP(hipEventRecord(ev_done, s));
+  GSS_HIP(hipStreamWaitEvent(cout, ev_done, 0));
+  pend_off = off;
+  pend_n = n;
+  return GSS_OK;
+}
+
+int32_t HostPipe::finish(hipStream_t s) {
+  if (!on) return GSS_OK;
+  for (int i = 0; i < nout && pend_n > 0; ++i)
+    GSS_HIP(hipMemcpyAsync(outs[i].host_out + (size_t)pend_off * outs[i].stride,
+                           outs[i].dev + (size_t)pend_off * outs[i].stride, (size_t)pend_n * outs[i].stride,
+                           hipMemcpyDeviceToHost, cout));
+  pend_n = 0;
+  GSS_HIP(hipStreamSynchronize(cout));
   GSS_HIP(hipStreamSynchronize(s));
   return GSS_OK;
 }

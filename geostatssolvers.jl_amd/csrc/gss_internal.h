@@ -83,6 +83,39 @@ struct Staged {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Host arrays of a large call, handed over in pieces: the copy of piece i + 1 (host -> device, copy stream 0 of the
+// process) and the results of piece i - 1 (device -> host, copy stream 1) cross the bus while piece i is computed on
+// the caller's stream.  The device images of the arrays are whole-call scratch (Staged::out); `stride` = bytes per
+// point.  A copy to or from pageable memory holds the calling thread until it is done, which is why the results of
+// a piece only leave once the NEXT piece has been queued.  Usage: begin(); add_in / add_out; per piece fetch(),
+// launches, deliver(); finish().  `on` is false (and every method a no-op) for device arrays, short calls,
+// GSS_HOST_PIPELINE=0, or when the copy streams cannot be had: the caller then copies in one go as before.
+struct HostPipe {
+  static constexpr int64_t PIECE = 131072;
+  struct Arr {
+    const char* host_in;
+    char* host_out;
+    char* dev;
+    size_t stride;
+  };
+  Arr ins[4], outs[6];
+  int nin = 0, nout = 0;
+  hipStream_t cin = nullptr, cout = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr;
+  int64_t pend_off = 0, pend_n = 0;
+  bool on = false;
+  HostPipe() = default;
+  HostPipe(const HostPipe&) = delete;
+  HostPipe& operator=(const HostPipe&) = delete;
+  ~HostPipe();
+  int32_t begin(int32_t mem, int64_t m, hipStream_t s);
+  void add_in(const void* host, void* dev, size_t stride);
+  void add_out(void* host, void* dev, size_t stride);   // NULL host or dev: skipped
+  int32_t fetch(int64_t off, int64_t n, hipStream_t s);
+  int32_t deliver(int64_t off, int64_t n, hipStream_t s);
+  int32_t finish(hipStream_t s);
+};
+
 // Every C-ABI entry converts its `stream` argument here.  Scratch memory (the DevBuf pool, the kriging workspace) is
 // recycled without per-block events, which is only safe if everything the library queues is ordered; when a call
 // arrives on a different stream than the previous one, the new stream is made to wait for the work queued on the old

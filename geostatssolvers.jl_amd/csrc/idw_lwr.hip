@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
 static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int dim,
                              const double* x0, int64_t m, int k, int minneighbors, double radius,
                              const double* inv_radii_host, double* mean, double* aux, uint8_t* status,
-                             hipStream_t s) {
+                             hipStream_t s, HostPipe* pipe = nullptr /* k <= 64 only */) {
   const int use_ball = (radius >= 0.0 || inv_radii_host != nullptr) ? 1 : 0;
   const int aniso = inv_radii_host != nullptr ? 1 : 0;
   const double r2 = aniso ? 1.0 : radius * radius;
@@ -724,7 +724,8 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
     return GSS_OK;
   }
 
-  const int64_t chunk = 1 << 20;
+  const bool piped = pipe && pipe->on;   // host arrays of the domain arrive and leave piece by piece (gss_internal.h)
+  const int64_t chunk = piped ? HostPipe::PIECE : (1 << 20);
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call (Euclidean / Mahalanobis search only)
   const bool use_index = sp.metric != GSS_METRIC_HAVERSINE;
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
@@ -733,6 +734,7 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   GSS_TRY(cnt_s.alloc(sizeof(int) * (size_t)(m < chunk ? m : chunk)));
   for (int64_t off = 0; off < m; off += chunk) {
     const int64_t mv = (m - off) < chunk ? (m - off) : chunk;
+    if (piped) GSS_TRY(pipe->fetch(off, mv, s));
     {
       ProfScope ps("knn", s);
       if (use_index)
@@ -762,7 +764,9 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
     }
 #undef GSS_EST_KNN_ARGS
     GSS_HIP(hipGetLastError());
+    if (piped) GSS_TRY(pipe->deliver(off, mv, s));
   }
+  if (piped) GSS_TRY(pipe->finish(s));
   GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return
   return GSS_OK;
 }
@@ -783,7 +787,10 @@ static int32_t est_predict(const EstSpec& sp, const double* xdata, const double*
   Staged sxd, sz, sx, smean, saux, sstat;
   GSS_TRY(sxd.in(xdata, sizeof(double) * n * dim, mem, s));
   GSS_TRY(sz.in(z, sizeof(double) * n, mem, s));
-  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  HostPipe pipe;   // host arrays of the domain: in and out piece by piece beside the computation (k <= 64)
+  GSS_TRY(pipe.begin(k <= 64 ? mem : GSS_MEM_DEVICE, m, s));
+  if (pipe.on) GSS_TRY(sx.out(const_cast<double*>(xdom), sizeof(double) * m * dim, mem));   // device scratch only
+  else GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
   GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
   GSS_TRY(saux.out(aux, sizeof(double) * m, mem));
   DevBuf st_own;
@@ -795,8 +802,15 @@ static int32_t est_predict(const EstSpec& sp, const double* xdata, const double*
     GSS_TRY(st_own.alloc((size_t)m));
     st = st_own.as<uint8_t>();
   }
+  if (pipe.on) {
+    pipe.add_in(xdom, sx.p, sizeof(double) * dim);
+    pipe.add_out(mean, smean.p, sizeof(double));
+    pipe.add_out(aux, saux.p, sizeof(double));
+    pipe.add_out(status, status ? sstat.p : nullptr, 1);
+  }
   GSS_TRY(est_local_dev(sp, sxd.as<double>(), sz.as<double>(), n, dim, sx.as<double>(), m, k, minneighbors, radius,
-                        inv_radii, smean.as<double>(), saux.as<double>(), st, s));
+                        inv_radii, smean.as<double>(), saux.as<double>(), st, s, &pipe));
+  if (pipe.on) return GSS_OK;   // everything is home (est_local_dev ends with pipe.finish and a synchronisation)
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(saux.back(aux, sizeof(double) * m, mem, s));
   if (status) GSS_TRY(sstat.back(status, (size_t)m, mem, s));

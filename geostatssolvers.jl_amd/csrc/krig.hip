@@ -578,7 +578,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s, int metric);
+                       int* count_out, hipStream_t s, int metric, HostPipe* pipe = nullptr);
 }
 
 static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
@@ -802,18 +802,6 @@ static hipStream_t krig_fit_stream() {
   }
   return st;
 }
-
-// copy streams of the process for host arrays (0: host -> device, 1: device -> host), fenced by events
-static hipStream_t krig_copy_stream(int i) {
-  static std::mutex mu;
-  static hipStream_t st[2] = {nullptr, nullptr};
-  std::lock_guard<std::mutex> lock(mu);
-  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
-  return st[i];
-}
-// Host arrays are handed over in pieces of this many points (two rounds of resident workgroups of the quadratic
-// form): the copy of piece i + 1 and the results of piece i - 1 cross the bus while piece i is computed.
-constexpr int64_t HOST_PIPE_POINTS = 131072;
 
 // async: on the fit stream, behind everything `s` holds now; the caller's stream is joined by krig_join_device
 static int32_t krig_factorize(gss_krig* h, hipStream_t s, bool async = false) {
@@ -1048,16 +1036,12 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   }
 
   int64_t mc = krig_chunk_points(h->N1pad, m);
-  // host arrays: pieces of the call overlap their transfers with the computation of their neighbours
-  static const bool host_pipe = !(std::getenv("GSS_KRIG_HOST_PIPELINE") && std::getenv("GSS_KRIG_HOST_PIPELINE")[0] == '0');
-  hipStream_t cin = nullptr, cout = nullptr;
-  bool piped = mem == GSS_MEM_HOST && host_pipe && m > HOST_PIPE_POINTS;
-  if (piped) {
-    cin = krig_copy_stream(0);
-    cout = krig_copy_stream(1);
-    piped = cin != nullptr && cout != nullptr;
-  }
-  static const int64_t piece = std::getenv("GSS_KRIG_HOST_PIECE") ? atoll(std::getenv("GSS_KRIG_HOST_PIECE")) : HOST_PIPE_POINTS;   // A/B switch
+  // host arrays: pieces of the call (two rounds of resident workgroups of the quadratic form each) overlap their
+  // transfers with the computation of their neighbours
+  HostPipe pipe;
+  GSS_TRY(pipe.begin(mem, m, s));
+  const bool piped = pipe.on;
+  static const int64_t piece = std::getenv("GSS_KRIG_HOST_PIECE") ? atoll(std::getenv("GSS_KRIG_HOST_PIECE")) : HostPipe::PIECE;   // A/B switch
   if (piped && piece >= 256 && mc > piece) mc = piece;
   double *Rws = nullptr, *mpart = nullptr;
   GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
@@ -1065,17 +1049,10 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   const int seg_len = (int)((h->n + NSEG - 1) / NSEG);
 
   Staged sx, sd, smean, svar, sstat;
-  ScopedEvent ev_in, ev_done;
   if (piped) {
     GSS_TRY(sx.out(const_cast<double*>(xdom), sizeof(double) * m * dim, mem));   // device scratch only
     if (h->variant == GSS_KRIG_EXTDRIFT)
       GSS_TRY(sd.out(const_cast<double*>(drift_dom), sizeof(double) * m * h->ndrift, mem));
-    GSS_HIP(ev_in.create());
-    GSS_HIP(ev_done.create());
-    // the scratch may have been in use by work queued on s: the copy streams start behind it
-    GSS_HIP(hipEventRecord(ev_done, s));
-    GSS_HIP(hipStreamWaitEvent(cin, ev_done, 0));
-    GSS_HIP(hipStreamWaitEvent(cout, ev_done, 0));
   } else {
     GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
     if (h->variant == GSS_KRIG_EXTDRIFT) GSS_TRY(sd.in(drift_dom, sizeof(double) * m * h->ndrift, mem, s));
@@ -1083,28 +1060,19 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
   GSS_TRY(svar.out(var, sizeof(double) * m, mem));
   GSS_TRY(sstat.out(status, (size_t)m, mem));
+  if (piped) {
+    pipe.add_in(xdom, sx.p, sizeof(double) * dim);
+    if (h->variant == GSS_KRIG_EXTDRIFT) pipe.add_in(drift_dom, sd.p, sizeof(double) * h->ndrift);
+    pipe.add_out(mean, smean.p, sizeof(double));
+    pipe.add_out(var, svar.p, sizeof(double));
+    pipe.add_out(status, sstat.p, 1);
+  }
 
-  int64_t pend_off = 0, pend_mv = 0;
-  auto results_home = [&](int64_t o, int64_t cnt) -> int32_t {
-    if (cnt <= 0) return GSS_OK;
-    GSS_HIP(hipMemcpyAsync(mean + o, smean.as<double>() + o, sizeof(double) * cnt, hipMemcpyDeviceToHost, cout));
-    GSS_HIP(hipMemcpyAsync(var + o, svar.as<double>() + o, sizeof(double) * cnt, hipMemcpyDeviceToHost, cout));
-    if (status) GSS_HIP(hipMemcpyAsync(status + o, sstat.as<uint8_t>() + o, (size_t)cnt, hipMemcpyDeviceToHost, cout));
-    return GSS_OK;
-  };
   for (int64_t off = 0; off < m; off += mc) {
     const int64_t mv = (m - off) < mc ? (m - off) : mc;
     const int64_t cols = round_up(mv, 256);  // multiple of BN as well
     const double* x0 = sx.as<double>() + off * dim;
-    if (piped) {
-      GSS_HIP(hipMemcpyAsync(sx.as<double>() + off * dim, xdom + off * dim, sizeof(double) * mv * dim,
-                             hipMemcpyHostToDevice, cin));
-      if (h->variant == GSS_KRIG_EXTDRIFT)
-        GSS_HIP(hipMemcpyAsync(sd.as<double>() + off * h->ndrift, drift_dom + off * h->ndrift,
-                               sizeof(double) * mv * h->ndrift, hipMemcpyHostToDevice, cin));
-      GSS_HIP(hipEventRecord(ev_in, cin));
-      GSS_HIP(hipStreamWaitEvent(s, ev_in, 0));
-    }
+    GSS_TRY(pipe.fetch(off, mv, s));
     const int nblk = (int)(cols / 256);
     dim3 g1((unsigned)(nblk * NSEG));
     const int nrows = (int)(h->N1pad - h->n);
@@ -1160,20 +1128,10 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
 #undef GSS_K3_ARGS
     }
     GSS_HIP(hipGetLastError());
-    if (piped) {
-      // a copy to pageable memory holds the host until it is done: the results of the piece BEFORE leave now, behind
-      // this piece's launches, so that the device always has the next piece queued
-      GSS_TRY(results_home(pend_off, pend_mv));
-      GSS_HIP(hipEventRecord(ev_done, s));
-      GSS_HIP(hipStreamWaitEvent(cout, ev_done, 0));
-      pend_off = off;
-      pend_mv = mv;
-    }
+    GSS_TRY(pipe.deliver(off, mv, s));
   }
   if (piped) {
-    GSS_TRY(results_home(pend_off, pend_mv));
-    GSS_HIP(hipStreamSynchronize(cout));
-    GSS_HIP(hipStreamSynchronize(s));
+    GSS_TRY(pipe.finish(s));
   } else {
     GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
     GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
@@ -1197,17 +1155,35 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
   hipStream_t s = to_stream(stream);
   const int dim = h->dim;
   Staged sx, sd, smean, svar, sstat, sidx, scnt;
-  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
-  if (h->variant == GSS_KRIG_EXTDRIFT) GSS_TRY(sd.in(drift_dom, sizeof(double) * m * h->ndrift, mem, s));
+  HostPipe pipe;   // host arrays: in and out piece by piece beside the computation (gss_internal.h)
+  GSS_TRY(pipe.begin(mem, m, s));
+  if (pipe.on) {
+    GSS_TRY(sx.out(const_cast<double*>(xdom), sizeof(double) * m * dim, mem));   // device scratch only
+    if (h->variant == GSS_KRIG_EXTDRIFT)
+      GSS_TRY(sd.out(const_cast<double*>(drift_dom), sizeof(double) * m * h->ndrift, mem));
+  } else {
+    GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+    if (h->variant == GSS_KRIG_EXTDRIFT) GSS_TRY(sd.in(drift_dom, sizeof(double) * m * h->ndrift, mem, s));
+  }
   GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
   GSS_TRY(svar.out(var, sizeof(double) * m, mem));
   GSS_TRY(sstat.out(status, (size_t)m, mem));
   GSS_TRY(sidx.out(idx_out, sizeof(int32_t) * (size_t)(m * k), mem));
   GSS_TRY(scnt.out(count_out, sizeof(int32_t) * (size_t)m, mem));
+  if (pipe.on) {
+    pipe.add_in(xdom, sx.p, sizeof(double) * dim);
+    if (h->variant == GSS_KRIG_EXTDRIFT) pipe.add_in(drift_dom, sd.p, sizeof(double) * h->ndrift);
+    pipe.add_out(mean, smean.p, sizeof(double));
+    pipe.add_out(var, svar.p, sizeof(double));
+    pipe.add_out(status, sstat.p, 1);
+    pipe.add_out(idx_out, sidx.p, sizeof(int32_t) * (size_t)k);
+    pipe.add_out(count_out, scnt.p, sizeof(int32_t));
+  }
   GSS_TRY(krig_local_dev(h->vg, h->variant, h->nc, dim, &h->ds.e[0][0], h->ds.inv_scale[0], h->sk_mean,
                          h->xdata.as<double>(), h->z.as<double>(), h->drift_data.as<double>(), h->n,
                          sx.as<double>(), sd.as<double>(), m, k, minneighbors, radius, inv_radii, smean.as<double>(),
-                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s, metric));
+                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s, metric, &pipe));
+  if (pipe.on) return GSS_OK;   // everything is home (krig_local_dev ends with pipe.finish)
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
   GSS_TRY(sstat.back(status, (size_t)m, mem, s));

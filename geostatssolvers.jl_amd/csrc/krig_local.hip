@@ -759,7 +759,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s, int metric) {
+                       int* count_out, hipStream_t s, int metric, HostPipe* pipe) {
   GSS_REQUIRE(nc <= LMAX_NC, "moving-neighbourhood kriging supports at most %d drift terms (got %d)", LMAX_NC, nc);
   GSS_REQUIRE(k >= 1 && k <= BIG_MAX_K, "maxneighbors = %d: moving neighbourhoods hold at most %d neighbours "
                                         "(use the global neighbourhood beyond that)", k, BIG_MAX_K);
@@ -774,7 +774,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   sp.inv_scale = inv_scale;
   sp.sk_mean = sk_mean;
 
-  const int64_t chunk = big ? (k > 512 ? (1 << 14) : (1 << 17)) : (1 << 20);
+  const bool piped = pipe && pipe->on;   // host arrays arrive and leave piece by piece (gss_internal.h)
+  const int64_t chunk = big ? (k > 512 ? (1 << 14) : (1 << 17)) : (piped ? HostPipe::PIECE : (1 << 20));
   KnnIndex ix;  // k-d ordered batches + boxes, built once per call
   const char* brute = std::getenv("GSS_KNN_BRUTE");
   // (the haversine distance always searches exhaustively, in passes of 64 beyond 64 neighbours)
@@ -791,6 +792,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     int* idx = idx_out ? idx_out + off * k : idx_s.as<int>();
     int* cnt = count_out ? count_out + off : cnt_s.as<int>();
     uint8_t* st = status ? status + off : st_s.as<uint8_t>();
+    if (piped) GSS_TRY(pipe->fetch(off, mv, s));
     {
       ProfScope ps("knn", s);
       if (use_index)
@@ -828,6 +830,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
       }
 #undef GSS_BIG_LAUNCH
       GSS_HIP(hipGetLastError());
+      if (piped) GSS_TRY(pipe->deliver(off, mv, s));
       GSS_HIP(hipStreamSynchronize(s));   // the slab is released at the end of this iteration
       continue;
     }
@@ -863,6 +866,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
 #undef GSS_K5_LAUNCH
 #undef GSS_K5_ARGS
       GSS_HIP(hipGetLastError());
+      if (piped) GSS_TRY(pipe->deliver(off, mv, s));
       continue;
     }
     switch (dim) {
@@ -880,7 +884,9 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
         break;
     }
     GSS_HIP(hipGetLastError());
+    if (piped) GSS_TRY(pipe->deliver(off, mv, s));
   }
+  if (piped) GSS_TRY(pipe->finish(s));
   GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return
   return GSS_OK;
 }

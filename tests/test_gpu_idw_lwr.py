@@ -194,3 +194,20 @@ def test_metric_search_with_box_bounds_equals_exhaustive_search(monkeypatch, dis
     assert np.array_equal(idx, bidx) and np.array_equal(cnt, bcnt)
     ridx, rcnt = K.knn_search(x, c[::50], k, distance=distance)
     assert np.array_equal(idx[::50], ridx) and np.array_equal(cnt[::50], rcnt)
+
+
+def test_host_arrays_in_pieces_equal_device_arrays_idw_lwr():
+    """Host domain arrays beyond 131 072 points travel piece by piece beside the computation (HostPipe): same
+    results as device arrays, bit for bit."""
+    import torch
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(22)
+    x = rng.uniform(0, 100, (3000, 2))
+    z = rng.normal(size=3000)
+    m = 131072 * 3 + 5
+    x0 = rng.uniform(0, 100, (m, 2))
+    for fn, kw in ((HipEngine.idw, dict(exponent=2.0)), (HipEngine.lwr, {})):
+        dev = fn(x, z, torch.as_tensor(x0, device="cuda"), 12, **kw)
+        host = fn(x, z, x0, 12, **kw)
+        for a, b in zip(dev, host):
+            assert isinstance(b, np.ndarray) and np.array_equal(a.cpu().numpy(), b, equal_nan=True)

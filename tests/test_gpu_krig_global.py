@@ -341,7 +341,7 @@ def test_host_arrays_in_pieces_equal_device_arrays():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "o.npy")
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env = dict(os.environ, GSS_KRIG_HOST_PIPELINE="0",
+        env = dict(os.environ, GSS_HOST_PIPELINE="0",
                    PYTHONPATH=os.pathsep.join([os.path.join(root, "geostatssolvers.jl_amd"), os.environ.get("PYTHONPATH", "")]))
         subprocess.run([sys.executable, "-c", code % (m, out)], check=True, env=env, timeout=300)
         ref = np.load(out)

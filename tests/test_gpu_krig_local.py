@@ -235,3 +235,22 @@ def test_config5_shape_small():
     rmu, rvar, rst, ridx, rcnt = K.approxsolve(K.UK, ovg, x, z, x0, 64, degree=1, return_idx=True)
     assert np.array_equal(idx, ridx) and not st.any()
     assert np.max(np.abs(mu - rmu)) < 1e-9 * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var - rvar)) < 1e-9
+
+
+def test_host_arrays_in_pieces_equal_device_arrays_moving_neighbourhood():
+    """Host arrays beyond 131 072 points travel piece by piece beside the computation (HostPipe): means, variances,
+    status, neighbour indices and counts equal those of one call on device arrays, bit for bit."""
+    import torch
+    import gss
+    from gss.engine import KrigHandle, UK
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 100, (2000, 3))
+    z = rng.normal(size=2000)
+    m = 131072 * 2 + 777
+    x0 = rng.uniform(0, 100, (m, 3))
+    h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), UK, x, z, degree=1)
+    dev = h.predict_knn(torch.as_tensor(x0, device="cuda"), 24, radius=40.0, return_idx=True)
+    host = h.predict_knn(x0, 24, radius=40.0, return_idx=True)
+    assert len(dev) == len(host) == 5
+    for a, b in zip(dev, host):
+        assert isinstance(b, np.ndarray) and np.array_equal(a.cpu().numpy(), b, equal_nan=True)
