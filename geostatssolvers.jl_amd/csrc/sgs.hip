@@ -19,6 +19,8 @@
 #include "gss_internal.h"
 #include "philox.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -352,6 +354,82 @@ __global__ __launch_bounds__(64) void sgs_sweep_big_kernel(const int64_t* __rest
   }
 }
 
+// ---- level schedule of the path recursion (shared visiting order) ----------------------------------------------
+// z[node] only needs the values of the node's own neighbours, all visited earlier: the recursion is a sparse
+// triangular solve, and its dependency graph is shallow -- a node's level is 1 + the highest level among its
+// neighbours (conditioning cells: level 0); a random path over 512 x 512 cells with 16 neighbours has about 250
+// levels of about 1 000 nodes.  Nodes of one level are independent, so stage B runs level by level with one wave per
+// (node, 64 realisations) instead of one wave per 64 realisations walking all N nodes: the same sums in the same
+// order (bit-identical fields), N k gathers per realisation spread over the whole device.
+__global__ __launch_bounds__(256) void sgs_level_init_kernel(const int* __restrict__ rank, int64_t N,
+                                                             int* __restrict__ level, int* __restrict__ node) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < N) {
+    level[p] = rank[p] < 0 ? 0 : 1;
+    node[p] = (int)p;
+  }
+}
+
+// one relaxation: levels only grow, in place (a neighbour's newer level may or may not be seen: either way the
+// fixed point is the longest chain below the node); *changed says whether another round is needed
+__global__ __launch_bounds__(256) void sgs_level_relax_kernel(const int* __restrict__ rank, const int* __restrict__ idx,
+                                                              const int* __restrict__ ncond, int k, int64_t N,
+                                                              int* level, int* __restrict__ changed) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= N || rank[p] < 0) return;
+  const int c = ncond[p];
+  const int* nb = idx + p * k;
+  int mx = 0;
+  for (int j = 0; j < c; ++j) {
+    const int l = __hip_atomic_load(&level[nb[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mx = l > mx ? l : mx;
+  }
+  if (mx + 1 > level[p]) {
+    __hip_atomic_store(&level[p], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *changed = 1;
+  }
+}
+
+// first position of every level in the level-sorted node list
+__global__ __launch_bounds__(256) void sgs_level_offsets_kernel(const int* __restrict__ lvl_sorted, int64_t N,
+                                                                int* __restrict__ off) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int l = lvl_sorted[i];
+  if (i == 0 || lvl_sorted[i - 1] != l) off[l] = (int)i;
+}
+
+// one level: wave = (node of the level, block of 64 realisations); the recursion step of sgs_sweep_kernel
+__global__ __launch_bounds__(256) void sgs_level_sweep_kernel(const int* __restrict__ order, int first, int count,
+                                                              const int* __restrict__ idx, const int* __restrict__ ncond,
+                                                              const double* __restrict__ w,
+                                                              const double* __restrict__ sigma, int k, int R, int rb,
+                                                              double mean, double* __restrict__ zt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)count * rb) return;   // whole wave
+  const int64_t node = order[first + (int)(item / rb)];
+  const int r = (int)(item % rb) * 64 + lane;
+  const bool live = r < R;
+  const int rr = live ? r : R - 1;
+  const int c = ncond[node];
+  const int* nb = idx + node * k;      // wave-uniform: scalar loads
+  const double* ww = w + node * k;
+  const double eps = zt[node * R + rr];   // the cell's own slot holds its normal until it is simulated
+  double acc = 0.0;
+  int j = 0;
+  for (; j + 8 <= c; j += 8) {   // eight gathers in flight
+    double zz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) zz[u] = zt[(int64_t)nb[j + u] * R + rr];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fma(ww[j + u], zz[u] - mean, acc);
+  }
+  for (; j < c; ++j) acc = fma(ww[j], zt[(int64_t)nb[j] * R + rr] - mean, acc);
+  const double v = mean + acc + sigma[node] * eps;
+  if (live) zt[node * R + r] = v;
+}
+
 // zt[dloc][r] = zdata for the conditioning cells
 __global__ __launch_bounds__(256) void sgs_seed_data_kernel(const int64_t* __restrict__ dlocs,
                                                             const double* __restrict__ zd, int64_t nd, int64_t N,
@@ -525,7 +603,59 @@ struct gss_sgs {
   int64_t npaths = 1, path_base = 0;  // npaths > 1: one visiting order per realisation, path p <-> realisation path_base + p
   DevBuf path, rank, idx, ncond, w, sigma, dlocs, zd;   // per path: N entries (path, rank, ncond, sigma), N k (idx, w)
   DevBuf field;  // node-major [N][R] working field of gss_sgs_realize, kept between calls (grows to the largest R seen)
+  DevBuf order;  // shared visiting order: nodes sorted by level of the dependency graph
+  std::vector<int> lvl_off;   // lvl_off[l] .. lvl_off[l + 1] - 1: positions of level l in `order` (level 0 = conditioning cells)
 };
+
+// levels of the dependency graph of path 0 (see sgs_level_sweep_kernel); leaves h->lvl_off empty when switched off
+static int32_t sgs_build_levels(gss_sgs* h, hipStream_t s) {
+  static const bool enabled = !(std::getenv("GSS_SGS_LEVELS") && std::getenv("GSS_SGS_LEVELS")[0] == '0');
+  h->lvl_off.clear();
+  if (!enabled || h->npaths != 1) return GSS_OK;
+  const int64_t N = h->N;
+  DevBuf level, node, lvl_sorted, flag, off, tmp;
+  GSS_TRY(level.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(node.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(lvl_sorted.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(h->order.alloc(sizeof(int) * (size_t)N));
+  GSS_TRY(flag.alloc(sizeof(int)));
+  const dim3 grid((unsigned)((N + 255) / 256));
+  hipLaunchKernelGGL(sgs_level_init_kernel, grid, dim3(256), 0, s, h->rank.as<int>(), N, level.as<int>(), node.as<int>());
+  GSS_HIP(hipGetLastError());
+  for (int64_t round = 0;; ++round) {
+    GSS_REQUIRE(round * 16 <= N + 16, "level schedule of the path did not settle");   // a chain cannot be longer than N
+    GSS_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+    for (int it = 0; it < 16; ++it)
+      hipLaunchKernelGGL(sgs_level_relax_kernel, grid, dim3(256), 0, s, h->rank.as<int>(), h->idx.as<int>(),
+                         h->ncond.as<int>(), h->k, N, level.as<int>(), flag.as<int>());
+    GSS_HIP(hipGetLastError());
+    int changed = 0;
+    GSS_HIP(hipMemcpyAsync(&changed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    GSS_HIP(hipStreamSynchronize(s));
+    if (!changed) break;
+  }
+  size_t tb = 0;
+  GSS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, level.as<int>(), lvl_sorted.as<int>(), node.as<int>(),
+                                             h->order.as<int>(), (int)N, 0, 32, s));
+  GSS_TRY(tmp.alloc(tb > 0 ? tb : 16));
+  GSS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, level.as<int>(), lvl_sorted.as<int>(), node.as<int>(),
+                                             h->order.as<int>(), (int)N, 0, 32, s));
+  int L = 0;
+  GSS_HIP(hipMemcpyAsync(&L, lvl_sorted.as<int>() + (N - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  GSS_TRY(off.alloc(sizeof(int) * (size_t)(L + 2)));
+  GSS_HIP(hipMemsetAsync(off.p, 0xff, sizeof(int) * (size_t)(L + 2), s));
+  hipLaunchKernelGGL(sgs_level_offsets_kernel, grid, dim3(256), 0, s, lvl_sorted.as<int>(), N, off.as<int>());
+  GSS_HIP(hipGetLastError());
+  std::vector<int> ho((size_t)L + 2);
+  GSS_HIP(hipMemcpyAsync(ho.data(), off.p, sizeof(int) * (size_t)(L + 2), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  ho[(size_t)L + 1] = (int)N;
+  for (int l = L; l >= 0; --l)   // a level without nodes (only level 0 can be: no conditioning cells) starts where the next does
+    if (ho[(size_t)l] < 0) ho[(size_t)l] = ho[(size_t)l + 1];
+  h->lvl_off = std::move(ho);
+  return GSS_OK;
+}
 
 extern "C" {
 
@@ -686,6 +816,10 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
       GSS_HIP(hipGetLastError());
     }
   }
+  {
+    ProfScope ps("sgs_levels", s);
+    GSS_TRY(sgs_build_levels(h, s));
+  }
   GSS_HIP(hipStreamSynchronize(s));  // host staging vectors and scratch are released on return
   guard.p = nullptr;
   *out = h;
@@ -778,7 +912,20 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
                        h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zt.as<double>());
     GSS_HIP(hipGetLastError());
   }
-  {
+  if (!h->lvl_off.empty()) {
+    ProfScope ps("sgs_sweep", s);
+    const int L = (int)h->lvl_off.size() - 2;
+    const int rb = (R + 63) / 64;
+    for (int l = 1; l <= L; ++l) {
+      const int first = h->lvl_off[(size_t)l], count = h->lvl_off[(size_t)l + 1] - first;
+      if (count <= 0) continue;
+      const int64_t waves = (int64_t)count * rb;
+      hipLaunchKernelGGL(sgs_level_sweep_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, h->order.as<int>(),
+                         first, count, h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(), h->sigma.as<double>(),
+                         h->k, R, rb, h->mean, zt.as<double>());
+    }
+    GSS_HIP(hipGetLastError());
+  } else {
     ProfScope ps("sgs_sweep", s);
     if (h->k > SGS_MAX_K)
       hipLaunchKernelGGL(sgs_sweep_big_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),

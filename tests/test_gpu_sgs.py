@@ -252,3 +252,40 @@ def test_one_visiting_order_per_realisation_matches_oracle(monkeypatch):
                         maxneighbors=7, mask_after_search=True)[0]     # front-end default: mask = "after"
         assert np.max(np.abs(sol["z"][r] - ref)) < 1e-9 and np.array_equal(sol["z"][r], loop["z"][r])
     assert np.max(np.abs(sol["z"][0] - sol["z"][1])) > 1e-3
+
+
+def test_level_schedule_is_bit_identical_to_the_walk_along_the_path():
+    """Stage B runs level by level over the dependency graph of the shared visiting order (sgs.hip,
+    sgs_level_sweep_kernel): the same sums in the same order as one wave walking the path (GSS_SGS_LEVELS=0, in a
+    child process), for 16 and for 80 neighbours, with conditioning data, an odd number of realisations and both
+    readings of the mask."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = ("import sys, numpy as np, gss\n"
+            "from gss.engine import SGSHandle\n"
+            "out = sys.argv[1]\n"
+            "res = []\n"
+            "for dims, k, after in (((96, 80), 16, False), ((64, 50), 80, True), ((20, 18, 10), 12, True)):\n"
+            "    N = int(np.prod(dims)); rng = np.random.default_rng(N)\n"
+            "    g = np.meshgrid(*[np.arange(d) + 0.5 for d in dims], indexing='ij')\n"
+            "    cent = np.stack([a.ravel(order='F') for a in g], 1)\n"
+            "    dl = np.sort(rng.choice(N, 25, replace=False)); zd = rng.normal(size=25)\n"
+            "    h = SGSHandle(gss.SphericalVariogram(range=12.0, nugget=0.05), cent, rng.permutation(N), dl, zd, 0.3, k, 1,\n"
+            "                  mask_after_search=after)\n"
+            "    res.append(h.realize(7, 2, 67)); h.close()\n"
+            "np.savez(out, *res)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for sw in ("1", "0"):
+            out = os.path.join(d, f"o{sw}.npz")
+            env = dict(os.environ, GSS_SGS_LEVELS=sw, PYTHONPATH=os.pathsep.join(
+                [os.path.join(root, "geostatssolvers.jl_amd"), os.environ.get("PYTHONPATH", "")]))
+            subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+            with np.load(out) as f:
+                outs.append([f[k] for k in f.files])
+    assert len(outs[0]) == 3
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.array_equal(a, b)
