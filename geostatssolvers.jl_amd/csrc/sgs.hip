@@ -361,32 +361,71 @@ __global__ __launch_bounds__(64) void sgs_sweep_big_kernel(const int64_t* __rest
 // levels of about 1 000 nodes.  Nodes of one level are independent, so stage B runs level by level with one wave per
 // (node, 64 realisations) instead of one wave per 64 realisations walking all N nodes: the same sums in the same
 // order (bit-identical fields), N k gathers per realisation spread over the whole device.
-__global__ __launch_bounds__(256) void sgs_level_init_kernel(const int* __restrict__ rank, int64_t N,
+__global__ __launch_bounds__(256) void sgs_level_init_kernel(const int* __restrict__ rank, int64_t N /* all paths */,
                                                              int* __restrict__ level, int* __restrict__ node) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < N) {
-    level[p] = rank[p] < 0 ? 0 : 1;
+    level[p] = rank[p] < 0 ? 0 : -1;   // -1: not known yet
     node[p] = (int)p;
   }
 }
 
-// one relaxation: levels only grow, in place (a neighbour's newer level may or may not be seen: either way the
-// fixed point is the longest chain below the node); *changed says whether another round is needed
-__global__ __launch_bounds__(256) void sgs_level_relax_kernel(const int* __restrict__ rank, const int* __restrict__ idx,
+// Levels in one launch: thread t owns the t-th node of the path and polls its neighbours' levels until all of them
+// are known (-1 = not yet), then publishes its own.  A node only waits for nodes visited earlier, i.e. for threads
+// of its own or of earlier workgroups, and workgroups start in index order: the earliest unfinished workgroup never
+// waits for one that is not resident.  The store sits INSIDE the polling loop -- lanes of one wave wait for each
+// other (consecutive nodes of a path are neighbours), and a lane parked behind the loop could not publish.
+__global__ __launch_bounds__(256) void sgs_level_chain_kernel(const int64_t* __restrict__ path,
+                                                              const int* __restrict__ rank, const int* __restrict__ idx,
                                                               const int* __restrict__ ncond, int k, int64_t N,
-                                                              int* level, int* __restrict__ changed) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= N || rank[p] < 0) return;
+                                                              int64_t npaths, int* level, int* __restrict__ gave_up) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;   // paths one after the other, N nodes each
+  if (g >= N * npaths) return;
+  const int64_t base = g / N * N;                    // first entry of this thread's path in the per-path arrays
+  const int64_t p = base + path[g];                  // (path, node) as one index
+  if (rank[p] < 0) return;   // conditioning cell: level 0 (sgs_level_init_kernel)
   const int c = ncond[p];
-  const int* nb = idx + p * k;
-  int mx = 0;
-  for (int j = 0; j < c; ++j) {
-    const int l = __hip_atomic_load(&level[nb[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mx = l > mx ? l : mx;
-  }
-  if (mx + 1 > level[p]) {
-    __hip_atomic_store(&level[p], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *changed = 1;
+  const int* nb = idx + p * k;                       // node numbers within the path
+  level += base;
+  // neighbours are polled 64 at a time and a neighbour whose level is known is never asked again: with hundreds of
+  // thousands of threads in flight, polling everything on every round makes the polls the bottleneck
+  // The loop is left by the whole wave at once (__all): a lane that has published must not be parked behind the
+  // loop's exit while lanes of its own wave still wait for what it published -- and a store on a path that leaves
+  // the loop is, for the compiler, a store after the loop.
+  bool done = false;
+  int polls = 0, mx = 0, j0 = 0;
+  int cc = c < 64 ? c : 64;
+  unsigned long long pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
+  for (;;) {
+    if (!done) {
+      unsigned long long m = pend;
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const int l = __hip_atomic_load(&level[nb[j0 + j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l >= 0) {
+          mx = l > mx ? l : mx;
+          pend &= ~(1ull << j);
+        }
+      }
+      if (pend == 0) {
+        j0 += 64;
+        if (j0 >= c) {
+          __hip_atomic_store(&level[p - base], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          done = true;
+        } else {
+          cc = c - j0 < 64 ? c - j0 : 64;
+          pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
+        }
+      } else if (++polls > (1 << 18)) {
+        // never seen; the wait is bounded all the same: publish, report, and the host drops the schedule
+        __hip_atomic_store(&level[p - base], 1 << 29, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *gave_up = 1;
+        done = true;
+      }
+    }
+    if (__all(done)) break;
+    __builtin_amdgcn_s_sleep(8);
   }
 }
 
@@ -428,6 +467,38 @@ __global__ __launch_bounds__(256) void sgs_level_sweep_kernel(const int* __restr
   for (; j < c; ++j) acc = fma(ww[j], zt[(int64_t)nb[j] * R + rr] - mean, acc);
   const double v = mean + acc + sigma[node] * eps;
   if (live) zt[node * R + r] = v;
+}
+
+// one level of every visiting order at once (one order per realisation): thread = (path, node) of the level; the
+// recursion step of sgs_sweep_paths_kernel on the realisation-major field
+__global__ __launch_bounds__(256) void sgs_level_sweep_paths_kernel(const int* __restrict__ order, int first, int count,
+                                                                    const int* __restrict__ idx,
+                                                                    const int* __restrict__ ncond,
+                                                                    const double* __restrict__ w,
+                                                                    const double* __restrict__ sigma, int k, int64_t N,
+                                                                    int R, int64_t path0, double mean,
+                                                                    double* __restrict__ zr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int64_t g = order[first + i];
+  const int64_t pi = g / N, node = g - pi * N;
+  const int64_t r = pi - path0;              // realisation r of this call walks path path0 + r
+  if (r < 0 || r >= R) return;
+  const int c = ncond[g];
+  const int* nb = idx + g * k;
+  const double* ww = w + g * k;
+  double* z = zr + r * N;
+  double acc = 0.0;
+  int j = 0;
+  for (; j + 4 <= c; j += 4) {                // four gathers in flight
+    const double z0 = z[nb[j]], z1 = z[nb[j + 1]], z2 = z[nb[j + 2]], z3 = z[nb[j + 3]];
+    acc = fma(ww[j], z0 - mean, acc);
+    acc = fma(ww[j + 1], z1 - mean, acc);
+    acc = fma(ww[j + 2], z2 - mean, acc);
+    acc = fma(ww[j + 3], z3 - mean, acc);
+  }
+  for (; j < c; ++j) acc = fma(ww[j], z[nb[j]] - mean, acc);
+  z[node] = mean + acc + sigma[g] * z[node];  // the cell's own slot holds its normal until it is simulated
 }
 
 // zt[dloc][r] = zdata for the conditioning cells
@@ -611,28 +682,27 @@ struct gss_sgs {
 static int32_t sgs_build_levels(gss_sgs* h, hipStream_t s) {
   static const bool enabled = !(std::getenv("GSS_SGS_LEVELS") && std::getenv("GSS_SGS_LEVELS")[0] == '0');
   h->lvl_off.clear();
-  if (!enabled || h->npaths != 1) return GSS_OK;
-  const int64_t N = h->N;
-  DevBuf level, node, lvl_sorted, flag, off, tmp;
+  if (!enabled || h->N * h->npaths >= ((int64_t)1 << 30)) return GSS_OK;
+  const int64_t N = h->N * h->npaths;   // (path, node) pairs, path-major like the per-path arrays
+  DevBuf level, node, lvl_sorted, off, tmp, flag;
   GSS_TRY(level.alloc(sizeof(int) * (size_t)N));
   GSS_TRY(node.alloc(sizeof(int) * (size_t)N));
   GSS_TRY(lvl_sorted.alloc(sizeof(int) * (size_t)N));
   GSS_TRY(h->order.alloc(sizeof(int) * (size_t)N));
-  GSS_TRY(flag.alloc(sizeof(int)));
   const dim3 grid((unsigned)((N + 255) / 256));
   hipLaunchKernelGGL(sgs_level_init_kernel, grid, dim3(256), 0, s, h->rank.as<int>(), N, level.as<int>(), node.as<int>());
   GSS_HIP(hipGetLastError());
-  for (int64_t round = 0;; ++round) {
-    GSS_REQUIRE(round * 16 <= N + 16, "level schedule of the path did not settle");   // a chain cannot be longer than N
-    GSS_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
-    for (int it = 0; it < 16; ++it)
-      hipLaunchKernelGGL(sgs_level_relax_kernel, grid, dim3(256), 0, s, h->rank.as<int>(), h->idx.as<int>(),
-                         h->ncond.as<int>(), h->k, N, level.as<int>(), flag.as<int>());
-    GSS_HIP(hipGetLastError());
-    int changed = 0;
-    GSS_HIP(hipMemcpyAsync(&changed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    GSS_HIP(hipStreamSynchronize(s));
-    if (!changed) break;
+  GSS_TRY(flag.alloc(sizeof(int)));
+  GSS_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+  hipLaunchKernelGGL(sgs_level_chain_kernel, grid, dim3(256), 0, s, h->path.as<int64_t>(), h->rank.as<int>(),
+                     h->idx.as<int>(), h->ncond.as<int>(), h->k, h->N, h->npaths, level.as<int>(), flag.as<int>());
+  GSS_HIP(hipGetLastError());
+  int gave_up = 0;
+  GSS_HIP(hipMemcpyAsync(&gave_up, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  if (gave_up) {   // stage B then walks the path as before
+    h->order.release();
+    return GSS_OK;
   }
   size_t tb = 0;
   GSS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, level.as<int>(), lvl_sorted.as<int>(), node.as<int>(),
@@ -884,7 +954,18 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
                          h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, N, R, zr);
       GSS_HIP(hipGetLastError());
     }
-    {
+    if (!h->lvl_off.empty()) {   // level by level, every visiting order at once
+      ProfScope ps("sgs_sweep", s);
+      const int L = (int)h->lvl_off.size() - 2;
+      for (int l = 1; l <= L; ++l) {
+        const int first = h->lvl_off[(size_t)l], count = h->lvl_off[(size_t)l + 1] - first;
+        if (count <= 0) continue;
+        hipLaunchKernelGGL(sgs_level_sweep_paths_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                           h->order.as<int>(), first, count, h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),
+                           h->sigma.as<double>(), h->k, N, R, p0, h->mean, zr);
+      }
+      GSS_HIP(hipGetLastError());
+    } else {
       ProfScope ps("sgs_sweep", s);
       hipLaunchKernelGGL(sgs_sweep_paths_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, h->path.as<int64_t>(),
                          h->rank.as<int>(), h->idx.as<int>(), h->ncond.as<int>(), h->w.as<double>(),

@@ -257,8 +257,8 @@ def test_one_visiting_order_per_realisation_matches_oracle(monkeypatch):
 def test_level_schedule_is_bit_identical_to_the_walk_along_the_path():
     """Stage B runs level by level over the dependency graph of the shared visiting order (sgs.hip,
     sgs_level_sweep_kernel): the same sums in the same order as one wave walking the path (GSS_SGS_LEVELS=0, in a
-    child process), for 16 and for 80 neighbours, with conditioning data, an odd number of realisations and both
-    readings of the mask."""
+    child process), for 16 and for 80 neighbours, with conditioning data, an odd number of realisations, both
+    readings of the mask, and with one visiting order per realisation (every order's levels in one schedule)."""
     import os
     import subprocess
     import sys
@@ -275,6 +275,9 @@ def test_level_schedule_is_bit_identical_to_the_walk_along_the_path():
             "    h = SGSHandle(gss.SphericalVariogram(range=12.0, nugget=0.05), cent, rng.permutation(N), dl, zd, 0.3, k, 1,\n"
             "                  mask_after_search=after)\n"
             "    res.append(h.realize(7, 2, 67)); h.close()\n"
+            "paths = np.stack([rng.permutation(N) for _ in range(5)])     # one visiting order per realisation\n"
+            "h = SGSHandle(gss.SphericalVariogram(range=12.0, nugget=0.05), cent, paths, dl, zd, 0.3, 10, 1)\n"
+            "res.append(h.realize(7, 0, 5)); res.append(h.realize(7, 1, 3)); h.close()\n"
             "np.savez(out, *res)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
@@ -286,6 +289,6 @@ def test_level_schedule_is_bit_identical_to_the_walk_along_the_path():
             subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
             with np.load(out) as f:
                 outs.append([f[k] for k in f.files])
-    assert len(outs[0]) == 3
+    assert len(outs[0]) == 5
     for a, b in zip(*outs):
         assert a.shape == b.shape and np.array_equal(a, b)
