@@ -241,11 +241,11 @@ def cfg_lwr(a, gss, _lib):
 
 def cfg_sgs(a, gss, _lib):
     """Section 8f.4 row: SGS on a 512 x 512 grid, spherical range 35, k = 16, ball 30, 200 conditioning cells,
-    1024 realisations per sweep (the recursion is sequential along the path, parallel over realisations)."""
+    1024 realisations per sweep (the recursion runs level by level over its dependency graph, sgs.hip)."""
     from gss.engine import SGSHandle
     from oracle import fftgs as offt
     e = 128 if a.quick else 512
-    R = a.sgs_reals   # one wave carries 64 realisations through the path; R / 64 waves run side by side
+    R = a.sgs_reals   # one wave carries 64 realisations of one node of a level
     cent = offt.grid_centroids((e, e))
     N = cent.shape[0]
     rng = np.random.default_rng(5)
@@ -285,7 +285,8 @@ def cfg_sgs(a, gss, _lib):
     return {"config": "8f.4 SGS %dx%d grid, spherical range 35, k=16, ball 30, 200 data, %d realisations" % (e, e, R),
             "metric": "simulated cells/s (all realisations)", "value": round(N * R / dt, 1), "unit": "cells/s",
             "preprocess_s": round(t_pre, 3), "realize_s": round(dt, 4),
-            "roofline": {"bound": "latency (path recursion)", "kernel": "sgs_sweep",
+            "roofline": {"bound": "hbm (gathers of the level sweep; launch gaps of the levels below ~2 000 realisations)",
+                         "kernel": "sgs_level_sweep_kernel, all levels",
                          "achieved": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9 / HBM_PEAK, 5)},
             "kernel_ms": {"sgs_sweep": round(sweep[0], 2)}, "us_per_path_node": round(sweep[0] * 1e3 / N, 3),
