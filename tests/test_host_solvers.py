@@ -179,3 +179,37 @@ def test_explicit_init_places_the_data_where_told():
     with pytest.raises(ValueError, match="outside"):
         gss.solve(gss.SimulationProblem(data, grid, "z", 1), gss.SGS(("z", dict(variogram=vg)), engine=OracleEngine,
                                                                      init=("explicit", [0], [60])))
+
+
+def test_nearest_cell_of_a_cartesian_grid_is_arithmetic_and_follows_the_search_rule():
+    """NearestInit / fft.jl:129-132 on a full CartesianGrid: the containing cell or a neighbour along an axis, chosen by
+    the search's rule (squared distance in dimension order, ties to the lower index) -- equal to the exhaustive search
+    over all centroids, also for data on cell boundaries (integer coordinates on a unit grid: ties), outside the grid,
+    with an origin and anisotropic spacing; views go through the search."""
+    import gss
+    from gss import solvers as S
+    from gss.geo import DomainView
+    from oracle_engine import OracleEngine
+    rng = np.random.default_rng(3)
+    for dims, origin, spacing in (((7, 5), (0.0, 0.0), (1.0, 1.0)), ((6, 4, 5), (-2.0, 3.0, 0.5), (0.5, 2.0, 1.25)),
+                                  ((9,), (1.0,), (0.25,))):
+        g = gss.CartesianGrid(dims, origin, spacing)
+        d = len(dims)
+        lo = np.asarray(origin)
+        hi = lo + np.asarray(dims) * np.asarray(spacing)
+        x = np.vstack([rng.uniform(lo - 1.0, hi + 1.0, (200, d)),
+                       lo + np.asarray(spacing) * rng.integers(0, np.asarray(dims) + 1, (100, d)),   # cell corners: ties
+                       lo + np.asarray(spacing) * (rng.integers(0, np.asarray(dims), (50, d)) + 0.5)])   # centroids
+        cent = g.centroids()
+        acc = np.zeros((x.shape[0], cent.shape[0]))
+        for a in range(d):
+            t = cent[None, :, a] - x[:, None, a]
+            acc = acc + t * t
+        ref = np.argmin(acc, axis=1)                     # first minimum = lowest index among ties
+        got = S._nearest_cells(None, g, None, x)         # no engine needed
+        assert np.array_equal(got, ref)
+        assert np.array_equal(S._nearest_cells(OracleEngine, g, cent, x[:0]), np.empty(0, dtype=np.int64))
+    g = gss.CartesianGrid((8, 6))
+    view = DomainView(g, np.array([3, 10, 11, 40]))
+    got = S._nearest_cells(OracleEngine, view, view.centroids(), np.array([[3.4, 0.2], [2.6, 1.4]]))
+    assert np.array_equal(got, [0, 1])                   # positions inside the view
