@@ -400,6 +400,37 @@ function nearest_elements(C::Matrix{Float64}, X::Matrix{Float64})
   Int.(idx) .+ 1
 end
 
+# The same on a whole CartesianGrid, by arithmetic (mirrors gss/solvers.py `_nearest_cells`): the cell that contains
+# the point or a neighbour along an axis, under the search's own rule -- squared distance accumulated in dimension
+# order, ties to the lower index -- so that no search index over millions of cells is built (33 ms at 128^3).
+# C holds the centroids of the grid (d x N, first axis fastest), used for the candidates' coordinates.
+function nearest_cells(C::Matrix{Float64}, dims::Vector{Int64}, origin::Vector{Float64}, sp::Vector{Float64},
+                       X::Matrix{Float64})
+  d, n = size(X)
+  out = Vector{Int}(undef, n)
+  strides = cumprod(vcat(1, dims[1:end-1]))
+  for i in 1:n
+    base = [(t = (X[a, i] - origin[a]) / sp[a]; isfinite(t) ? clamp(floor(Int, t), 0, dims[a] - 1) : 0) for a in 1:d]
+    bestd, besti = Inf, typemax(Int)
+    for offs in Iterators.product(ntuple(_ -> -1:1, d)...)
+      lin = 0
+      for a in 1:d
+        lin += clamp(base[a] + offs[a], 0, dims[a] - 1) * strides[a]
+      end
+      acc = 0.0
+      for a in 1:d
+        t = C[a, lin + 1] - X[a, i]
+        acc += t * t
+      end
+      if acc < bestd || (acc == bestd && lin < besti)
+        bestd, besti = acc, lin
+      end
+    end
+    out[i] = besti + 1
+  end
+  out
+end
+
 # ---- FFTGS ----------------------------------------------------------------------------------
 @simsolver FFTGSHIP begin
   @param variogram = GaussianVariogram()
@@ -440,7 +471,10 @@ function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
         krig = KrigingSolverHIP(var => (variogram=γ, mean=μ, minneighbors=p.minneighbors, maxneighbors=p.maxneighbors,
                                         neighborhood=p.neighborhood, distance=p.distance))
         z̄ = getproperty(solve(prob, krig), var)                          # fft.jl:125-126
-        found = nearest_elements(coordmatrix(pdomain), coordmatrix(ddomain))
+        C = coordmatrix(pdomain)
+        found = pdomain isa CartesianGrid ?
+                nearest_cells(C, dims, Float64[ustrip.(coordinates(minimum(pgrid)))...], sp, coordmatrix(ddomain)) :
+                nearest_elements(C, coordmatrix(ddomain))               # fft.jl:129-131
         dinds = unique(found)                                            # fft.jl:132
       end
     end
