@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   // exponents of a drift term being uniform) and pass through LDS into tile layout.  Column q of wave w lives in the
   // wave's OWN pieces of the buffers above -- S4[0][w], S4[1][w], G_[w], four columns of 64 each -- which nobody
   // touches before the wave has read them back, so the hand-over needs no barrier.
-  static_assert(4 * LMAX_K <= 16 * 17 && LMAX_RHS <= 12, "right-hand-side columns do not fit the wave's own tiles");
+  static_assert(4 * (LMAX_K + 4) <= 16 * 17 && LMAX_RHS <= 12, "right-hand-side columns do not fit the wave's own tiles");
 
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   double (*G)[17] = G_[wave];
   auto rhs_col = [&](int q) -> double* {   // column q (0 = c0, 1 = data, 2 + t = drift term t) of this wave
     double* base = q < 4 ? &S4[0][wave][0] : (q < 8 ? &S4[1][wave][0] : &G_[wave][0][0]);
-    return base + (q & 3) * LMAX_K;
+    return base + (q & 3) * (LMAX_K + 4);   // 68 doubles apart: the sixteen columns a row of lanes reads spread over the banks
   };
   const int64_t pw = (int64_t)blockIdx.x * K5_WAVES + wave;
   const bool inrange = pw < m;
