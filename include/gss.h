@@ -287,7 +287,10 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
  *   124-128).  centroids N x d (host), path = visiting order (N 0-based cell indices, NULL = LinearPath),
  *   dlocs / zdata = conditioning cells and their values (initbuff with NearestInit, seq.jl:85);
  *   maxneighbors <= 1024 (beyond 64: the search in passes of 64, one workgroup per node for the weights);
- *   radius / inv_radii as gss_knn_search.  All realisations of a handle share the path.
+ *   radius / inv_radii as gss_knn_search.  All realisations of a handle share the path.  The handle also keeps the
+ *   levels of the recursion's dependency graph (a node's level = 1 + the highest level among its neighbours): the
+ *   realisations are then simulated level by level, every node of a level at once, with the same sums in the same
+ *   order as the walk along the path (bit-identical fields).
  * gss_sgs_realize replaces solvesingle (seq.jl:76-141) for realisations first_real..first_real+nreals-1:
  *   z[node] = mean + sum_j lambda_j (z[nb_j] - mean) + sigma eps, eps = Philox normal (seed, realisation,
  *   cell) or noise[r * N + cell] when given.  out is nreals x N.  The handle keeps its node-major working field
@@ -311,7 +314,7 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
  * solvesingle (seq.jl:99-102): paths = npaths x N cell indices, path p belongs to realisation path_base + p; stage A
  * (search, fit, weights) runs once per path and gss_sgs_realize(first_real, nreals) needs
  * path_base <= first_real and first_real + nreals <= path_base + npaths.  npaths == 1 is gss_sgs_create (every
- * realisation shares the order, lanes = realisations, about R times faster per realisation). */
+ * realisation shares the order and one stage A serves them all). */
 int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids,
                              int64_t N, int32_t dim, const int64_t* paths, int64_t npaths, int64_t path_base,
                              const int64_t* dlocs, const double* zdata, int64_t nd, int32_t maxneighbors,
