@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -101,9 +102,19 @@ struct PoolBlock {
 };
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
-constexpr size_t POOL_MAX_BYTES = (size_t)3 << 30;
-constexpr size_t POOL_MAX_BLOCK = (size_t)1 << 30;
-constexpr size_t POOL_MAX_COUNT = 64;
+// Sized for 288 GB of HBM: up to 16 GiB of released blocks stay cached (GSS_POOL_MAX_MB overrides; a failing
+// hipMalloc gives them all back first), single blocks up to a quarter of that -- the 1.2 GB state of a configs[3]
+// LUGS handle and the 2 GiB FFTGS buffers are re-used instead of being freed (a device synchronisation) and
+// allocated again on the next solve.
+static size_t pool_max_bytes() {
+  static const size_t v = [] {
+    const char* e = std::getenv("GSS_POOL_MAX_MB");
+    const long long mb = e ? atoll(e) : 16384;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+  }();
+  return v;
+}
+constexpr size_t POOL_MAX_COUNT = 96;
 
 int32_t DevBuf::alloc(size_t nbytes) {
   release();
@@ -136,7 +147,7 @@ int32_t DevBuf::alloc(size_t nbytes) {
 
 void DevBuf::release() {
   if (p) {
-    if (bytes <= POOL_MAX_BLOCK && g_pool.size() < POOL_MAX_COUNT && g_pool_bytes + bytes <= POOL_MAX_BYTES) {
+    if (bytes <= pool_max_bytes() / 4 && g_pool.size() < POOL_MAX_COUNT && g_pool_bytes + bytes <= pool_max_bytes()) {
       g_pool.push_back(PoolBlock{p, bytes});
       g_pool_bytes += bytes;
     } else {
@@ -184,13 +195,41 @@ int32_t Staged::back(void* dst, size_t bytes, int32_t mem, hipStream_t s) {
 }
 
 // ---- HostPipe (gss_internal.h) ---------------------------------------------------------------------------------
-static hipStream_t host_copy_stream(int i) {
+// Helper streams of the process.  They are all created together, in one fixed order, the first time any of them is
+// asked for: which hardware queue a stream lands on depends on how many streams exist when it is created, and two
+// streams on one hardware queue do not overlap -- with per-subsystem streams created on demand, the look-ahead of the
+// LUGS preprocess lost its overlap (32.5 -> 35.5 ms) whenever an FFTGS realisation had created its slab streams
+// first.  Every use is fenced by events against the caller's stream on both sides.
+//   HELPER_LOOKAHEAD  low priority   look-ahead / side work of the blocked factorisations (dense_la.hip, lugs.hip)
+//   HELPER_GEN0..2    normal         FFTGS slabs, split products of gss_lugs_realize, host <-> device copies
+//   HELPER_FIT        high priority  asynchronous kriging fit
+hipStream_t helper_stream(int which) {
   static std::mutex mu;
-  static hipStream_t st[2] = {nullptr, nullptr};
+  static bool made = false;
+  static hipStream_t st[HELPER_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::lock_guard<std::mutex> lock(mu);
-  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
-  return st[i];
+  if (!made) {
+    made = true;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    const char* order = std::getenv("GSS_HELPER_ORDER");   // experiment: e.g. "LF012"
+    if (!order) order = "L012F";
+    for (const char* c = order; *c; ++c) {
+      int w = -1, pr = 0;
+      bool prio = false;
+      if (*c == 'L') { w = HELPER_LOOKAHEAD; pr = lo; prio = true; }
+      else if (*c == 'F') { w = HELPER_FIT; pr = hi; prio = true; }
+      else if (*c >= '0' && *c <= '2') w = HELPER_GEN0 + (*c - '0');
+      if (w < 0 || st[w]) continue;
+      const hipError_t e = prio ? hipStreamCreateWithPriority(&st[w], hipStreamNonBlocking, pr)
+                                : hipStreamCreateWithFlags(&st[w], hipStreamNonBlocking);
+      if (e != hipSuccess) st[w] = nullptr;
+    }
+  }
+  return (which >= 0 && which < HELPER_COUNT) ? st[which] : nullptr;
 }
+
+static hipStream_t host_copy_stream(int i) { return helper_stream(HELPER_GEN0 + i); }
 
 HostPipe::~HostPipe() {
   if (ev_in) (void)hipEventDestroy(ev_in);

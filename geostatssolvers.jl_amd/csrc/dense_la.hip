@@ -1351,18 +1351,6 @@ int64_t potrf_blocked_work_doubles(int64_t n) {
   return B * B + (w > B * B ? w : B * B) + 2 * n * B;
 }
 
-// low-priority helper stream of the process for the look-ahead of potrf_blocked_f64 (fenced by events on both sides)
-hipStream_t lookahead_stream() {
-  static std::mutex mu;
-  static hipStream_t st = nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!st) {
-    int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
-  }
-  return st;
-}
 
 // Look-ahead: the trailing update of panel k is split into (a) the next 1 024 columns, which the next panel needs,
 // and (b) everything to the right of them.  (b) runs on a helper stream beside the next panel's single-launch

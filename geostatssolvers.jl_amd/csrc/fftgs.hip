@@ -550,13 +550,7 @@ static int32_t fftgs_fused_p1(gss_fftgs* h, uint64_t seed, int64_t real, const d
 
 // helper streams of the slab order, shared by every handle of the process (creating a stream costs milliseconds);
 // what runs on them is fenced by the calling handle's events on both sides
-static hipStream_t slab_stream(int i) {
-  static std::mutex mu;
-  static hipStream_t st[gss_fftgs::SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
-  std::lock_guard<std::mutex> lock(mu);
-  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
-  return st[i];
-}
+static hipStream_t slab_stream(int i) { return helper_stream(HELPER_GEN0 + (i - 1) % 3); }   // i = 1, 2, ...
 
 static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
   // The three strided passes run slab by slab over the x tiles: P2, P3, P4 on the tiles of slab 0, then slab 1, ...

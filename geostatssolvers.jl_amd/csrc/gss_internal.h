@@ -724,7 +724,10 @@ struct ScopedEvent {
 
 // the process's low-priority helper stream of those look-aheads (nullptr if it cannot be created); work put on it
 // must be fenced by events against the caller's stream on both sides
-hipStream_t lookahead_stream();
+// helper streams of the process (common.hip), created together in a fixed order
+enum { HELPER_LOOKAHEAD = 0, HELPER_GEN0 = 1, HELPER_GEN1 = 2, HELPER_GEN2 = 3, HELPER_FIT = 4, HELPER_COUNT = 5 };
+hipStream_t helper_stream(int which);
+inline hipStream_t lookahead_stream() { return helper_stream(HELPER_LOOKAHEAD); }
 int64_t potrf_joint_work_doubles(int64_t nd, int64_t mb);
 int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_t ld21, double* C22, int64_t ns,
                         int* d_info, double* work, hipStream_t s);

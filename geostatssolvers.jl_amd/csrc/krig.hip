@@ -791,17 +791,7 @@ static int32_t krig_fit_enqueue(gss_krig* h, const FitPlan& fp, hipStream_t s) {
 }
 
 // high-priority stream of the process for asynchronous fits (fenced by events against the caller's stream)
-static hipStream_t krig_fit_stream() {
-  static std::mutex mu;
-  static hipStream_t st = nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!st) {
-    int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) hi = 0;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
-  }
-  return st;
-}
+static hipStream_t krig_fit_stream() { return helper_stream(HELPER_FIT); }
 
 // async: on the fit stream, behind everything `s` holds now; the caller's stream is joined by krig_join_device
 static int32_t krig_factorize(gss_krig* h, hipStream_t s, bool async = false) {

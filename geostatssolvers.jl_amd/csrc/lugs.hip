@@ -87,13 +87,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 }
 
 // helper streams of the process for gss_lugs_realize (fenced by events on both sides of every use)
-static hipStream_t realize_stream(int i) {
-  static std::mutex mu;
-  static hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::lock_guard<std::mutex> lock(mu);
-  if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
-  return st[i];
-}
+static hipStream_t realize_stream(int i) { return helper_stream(HELPER_GEN0 + (i - 1)); }   // i = 1 .. 3
 
 static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   int h = 0;
