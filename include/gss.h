@@ -23,7 +23,9 @@
  *     on the device) behind everything the library queued on the stream of the previous call.
  *     Some calls spread independent pieces of their work over helper streams of the process (gss_fftgs_realize:
  *     slabs of the strided FFT passes; gss_lugs_create / gss_lugs_realize: trailing updates beside the next panel,
- *     column blocks of L22 W).  Those streams are fenced by events on both sides: everything such a call does starts
+ *     column blocks of L22 W; the estimation calls on host arrays: copies beside the computation; gss_krig_create
+ *     with GSS_KRIG_ASYNC_FIT: the fit).  The process has five such streams, created together at the first use.
+ *     Those streams are fenced by events on both sides: everything such a call does starts
  *     after what `stream` held at the call and is complete, in stream order, before whatever is put on `stream` next.
  *   - handles are opaque, owned by the library, not thread-safe; the caller owns every buffer it
  *     passes and the library never returns memory it allocated.
