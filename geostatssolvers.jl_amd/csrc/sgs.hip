@@ -398,14 +398,25 @@ __global__ __launch_bounds__(256) void sgs_level_chain_kernel(const int64_t* __r
   unsigned long long pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
   for (;;) {
     if (!done) {
+      // up to eight of the unknown neighbours per round, their loads in flight together: a round is one memory
+      // round trip, and a round is what a hop of the chain costs (consecutive nodes of an order share a wave)
       unsigned long long m = pend;
-      while (m) {
-        const int j = __builtin_ctzll(m);
-        m &= m - 1;
-        const int l = __hip_atomic_load(&level[nb[j0 + j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (l >= 0) {
-          mx = l > mx ? l : mx;
-          pend &= ~(1ull << j);
+      int js[8], ls[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        js[u] = -1;
+        ls[u] = -1;
+        if (m) {
+          js[u] = __builtin_ctzll(m);
+          m &= m - 1;
+          ls[u] = __hip_atomic_load(&level[nb[j0 + js[u]]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (js[u] >= 0 && ls[u] >= 0) {
+          mx = ls[u] > mx ? ls[u] : mx;
+          pend &= ~(1ull << js[u]);
         }
       }
       if (pend == 0) {
