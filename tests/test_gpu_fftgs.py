@@ -303,3 +303,24 @@ def test_pipelined_realisations_equal_single_calls():
     inds = np.arange(5, 64 * 32 * 32, 11)
     assert np.array_equal(h.realize(21, 1, 4, inds=inds), single[1:5][:, inds])
     h.close()
+
+
+def test_rocfft_kernels_are_kept_for_later_processes():
+    """Grids outside the fused passes go through rocFFT, which compiles its kernels at run time; unless the user chose
+    a place, the library points ROCFFT_RTC_CACHE_PATH at ~/.cache/gss_hip (fftgs.hip) so that a later process finds
+    them (0.1 s instead of 1.7 s for its first plan)."""
+    import ctypes
+    import os
+    import gss
+    from gss.engine import FFTGSHandle
+    h = FFTGSHandle(gss.SphericalVariogram(range=8.0), (60, 50))
+    z = h.realize(3, 0, 2)
+    assert z.shape == (2, 3000) and np.isfinite(z).all()
+    h.close()
+    libc = ctypes.CDLL(None)
+    libc.getenv.restype = ctypes.c_char_p
+    path = libc.getenv(b"ROCFFT_RTC_CACHE_PATH")
+    assert path, "no kernel cache path in the process environment"
+    if os.environ.get("ROCFFT_RTC_CACHE_PATH") is None:          # not chosen by the user: the library's default
+        assert path.decode().endswith(os.path.join("gss_hip", "rocfft_kernels.db"))
+        assert os.path.exists(path.decode())
