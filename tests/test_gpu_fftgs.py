@@ -320,6 +320,10 @@ def test_rocfft_kernels_are_kept_for_later_processes():
     libc = ctypes.CDLL(None)
     libc.getenv.restype = ctypes.c_char_p
     path = libc.getenv(b"ROCFFT_RTC_CACHE_PATH")
+    if not path:
+        home = os.environ.get("XDG_CACHE_HOME") or os.path.expanduser("~")
+        if not os.access(home, os.W_OK):
+            pytest.skip("no writable cache directory on this machine: rocFFT keeps its kernels for the process only")
     assert path, "no kernel cache path in the process environment"
     if os.environ.get("ROCFFT_RTC_CACHE_PATH") is None:          # not chosen by the user: the library's default
         assert path.decode().endswith(os.path.join("gss_hip", "rocfft_kernels.db"))
