@@ -348,3 +348,24 @@ def test_host_arrays_in_pieces_equal_device_arrays():
     h2 = KrigHandle(vg, OK, x, z)
     mu, var, _ = h2.predict_global(x0)
     assert np.array_equal(ref[0], mu) and np.array_equal(ref[1], var)
+
+
+def test_host_arrays_in_pieces_without_a_status_array():
+    """The C-ABI accepts status = NULL; the piece-by-piece hand-over of host arrays then moves means and variances only."""
+    import ctypes as C
+    import gss
+    from gss import _lib
+    from gss.engine import KrigHandle, OK
+    rng = np.random.default_rng(31)
+    x = rng.uniform(0, 50, (200, 2))
+    z = rng.normal(size=200)
+    m = 131072 + 999
+    x0 = np.ascontiguousarray(rng.uniform(0, 50, (m, 2)))
+    h = KrigHandle(gss.ExponentialVariogram(range=15.0), OK, x, z)
+    ref = h.predict_global(x0)
+    mean = np.full(m, np.nan)
+    var = np.full(m, np.nan)
+    rc = _lib.lib().gss_krig_predict_global(h._h, x0.ctypes.data_as(C.c_void_p), None, m, mean.ctypes.data_as(C.c_void_p),
+                                            var.ctypes.data_as(C.c_void_p), None, 0, None)
+    assert rc == 0
+    assert np.array_equal(mean, ref[0]) and np.array_equal(var, ref[1])
