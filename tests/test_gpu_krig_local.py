@@ -254,3 +254,24 @@ def test_host_arrays_in_pieces_equal_device_arrays_moving_neighbourhood():
     assert len(dev) == len(host) == 5
     for a, b in zip(dev, host):
         assert isinstance(b, np.ndarray) and np.array_equal(a.cpu().numpy(), b, equal_nan=True)
+
+
+@pytest.mark.parametrize("dim,k,kw", [(3, 16, {}), (3, 1, {}), (2, 4, dict(radius=3.0)), (2, 16, dict(radii=(6.0, 2.0))),
+                                      (1, 9, {}), (3, 12, dict(radius=7.5))])
+def test_small_neighbour_counts_equal_the_exhaustive_search(monkeypatch, dim, k, kw):
+    """Up to sixteen neighbours (the IDW / LWR range): the indexed search returns the same lists, bit for bit, as the
+    exhaustive kernel -- random and lattice data (ties by index), duplicates, balls and ellipsoids, queries far outside
+    the data, a query count that is not a multiple of sixteen."""
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(100 * dim + k)
+    n, m = 30_000, 6007
+    x = rng.uniform(0, 100, (n, dim))
+    x[5000:9000] = np.round(x[5000:9000])                   # lattice points: equal distances, ties by index
+    x[20000:20300] = x[:300]                                  # exact duplicates
+    c = np.concatenate([rng.uniform(0, 100, (m - 2000, dim)), np.round(rng.uniform(0, 100, (1500, dim))) + 0.5,
+                        rng.uniform(-300, 400, (500, dim))])
+    idx, cnt = HipEngine.knn_search(x, c, k, **kw)
+    monkeypatch.setenv("GSS_KNN_BRUTE", "1")
+    bidx, bcnt = HipEngine.knn_search(x, c, k, **kw)
+    monkeypatch.delenv("GSS_KNN_BRUTE")
+    assert np.array_equal(cnt, bcnt) and np.array_equal(idx, bidx)
