@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
@@ -124,8 +125,7 @@ int32_t DevBuf::alloc(size_t nbytes) {
       p = g_pool[i].p;
       bytes = nbytes;
       g_pool_bytes -= nbytes;
-      g_pool[i] = g_pool.back();
-      g_pool.pop_back();
+      g_pool.erase(g_pool.begin() + (std::ptrdiff_t)i);   // keeps the list in order of release (oldest first)
       return GSS_OK;
     }
   }
@@ -147,7 +147,14 @@ int32_t DevBuf::alloc(size_t nbytes) {
 
 void DevBuf::release() {
   if (p) {
-    if (bytes <= pool_max_bytes() / 4 && g_pool.size() < POOL_MAX_COUNT && g_pool_bytes + bytes <= pool_max_bytes()) {
+    if (bytes <= pool_max_bytes() / 4) {
+      // a full cache gives up its oldest blocks: sizes change from solve to solve, and the sizes of the latest
+      // solves are the ones most likely to come back
+      while (!g_pool.empty() && (g_pool.size() >= POOL_MAX_COUNT || g_pool_bytes + bytes > pool_max_bytes())) {
+        (void)hipFree(g_pool.front().p);
+        g_pool_bytes -= g_pool.front().bytes;
+        g_pool.erase(g_pool.begin());
+      }
       g_pool.push_back(PoolBlock{p, bytes});
       g_pool_bytes += bytes;
     } else {
