@@ -120,14 +120,20 @@ constexpr size_t POOL_MAX_COUNT = 96;
 int32_t DevBuf::alloc(size_t nbytes) {
   release();
   if (nbytes == 0) nbytes = 8;
+  // best fit among the cached blocks: the smallest one that holds the request and is at most a quarter larger
+  // (sizes follow the problem: a point or a datum more must not cost a hipMalloc)
+  size_t best = (size_t)-1;
   for (size_t i = 0; i < g_pool.size(); ++i) {
-    if (g_pool[i].bytes == nbytes) {
-      p = g_pool[i].p;
-      bytes = nbytes;
-      g_pool_bytes -= nbytes;
-      g_pool.erase(g_pool.begin() + (std::ptrdiff_t)i);   // keeps the list in order of release (oldest first)
-      return GSS_OK;
-    }
+    const size_t b = g_pool[i].bytes;
+    if (b >= nbytes && b - nbytes <= nbytes / 4 && (best == (size_t)-1 || b < g_pool[best].bytes)) best = i;
+  }
+  if (best != (size_t)-1) {
+    p = g_pool[best].p;
+    bytes = nbytes;
+    cap = g_pool[best].bytes;
+    g_pool_bytes -= cap;
+    g_pool.erase(g_pool.begin() + (std::ptrdiff_t)best);   // keeps the list in order of release (oldest first)
+    return GSS_OK;
   }
   hipError_t e = hipMalloc(&p, nbytes);
   if (e != hipSuccess && !g_pool.empty()) {  // give cached blocks back and retry once
@@ -142,27 +148,29 @@ int32_t DevBuf::alloc(size_t nbytes) {
     return GSS_ERR_ALLOC;
   }
   bytes = nbytes;
+  cap = nbytes;
   return GSS_OK;
 }
 
 void DevBuf::release() {
   if (p) {
-    if (bytes <= pool_max_bytes() / 4) {
+    if (cap <= pool_max_bytes() / 4) {
       // a full cache gives up its oldest blocks: sizes change from solve to solve, and the sizes of the latest
       // solves are the ones most likely to come back
-      while (!g_pool.empty() && (g_pool.size() >= POOL_MAX_COUNT || g_pool_bytes + bytes > pool_max_bytes())) {
+      while (!g_pool.empty() && (g_pool.size() >= POOL_MAX_COUNT || g_pool_bytes + cap > pool_max_bytes())) {
         (void)hipFree(g_pool.front().p);
         g_pool_bytes -= g_pool.front().bytes;
         g_pool.erase(g_pool.begin());
       }
-      g_pool.push_back(PoolBlock{p, bytes});
-      g_pool_bytes += bytes;
+      g_pool.push_back(PoolBlock{p, cap});
+      g_pool_bytes += cap;
     } else {
       (void)hipFree(p);
     }
   }
   p = nullptr;
   bytes = 0;
+  cap = 0;
 }
 
 int32_t Staged::in(const void* src, size_t bytes, int32_t mem, hipStream_t s) {

@@ -60,7 +60,8 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 struct DevBuf {
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;   // what was asked for
+  size_t cap = 0;     // size of the block behind it (a cached block may be up to a quarter larger)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
