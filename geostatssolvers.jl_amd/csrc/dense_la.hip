@@ -1221,16 +1221,30 @@ void potrf_panel_disable() { g_panel_off.store(true); }
 static bool use_panel(int64_t n) { return !g_panel_off.load() && n >= PANEL_MIN && n <= panel_max_rows(); }
 constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets inside the kernel
 
-// scratch of potrf_inverse_f64 (doubles)
-int64_t potrf_inverse_work_doubles(int64_t n) {
+// scratch of potrf_inverse_f64 (doubles): enough for either way the recursion may go (the single-launch panel can be
+// switched off for good between the sizing and the use -- potrf_panel_disable)
+static int64_t inverse_work_mode(int64_t n, bool panel_on) {
   if (n <= 2 * LEAF) return 0;
-  if (use_panel(n)) {
+  if (panel_on && n >= PANEL_MIN && n <= panel_max_rows()) {
     const int64_t ldp = ((n + PANEL_NB - 1) / PANEL_NB) * PANEL_NB, n16 = (n + 15) / 16 * 16;
     return ldp * (ldp + PANEL_NB) + (n16 != n ? 2 * n16 * n16 : 0);  // + the zero-padded copies of a ragged size
   }
   const int64_t n1 = split_point(n), n2 = n - n1;
-  const int64_t a = potrf_inverse_work_doubles(n1), b = 2 * n1 * n2 + potrf_inverse_work_doubles(n2);
+  const int64_t a = inverse_work_mode(n1, panel_on), b = 2 * n1 * n2 + inverse_work_mode(n2, panel_on);
   return a > b ? a : b;
+}
+int64_t potrf_inverse_work_doubles(int64_t n) {
+  const int64_t a = inverse_work_mode(n, true), b = inverse_work_mode(n, false);
+  return a > b ? a : b;
+}
+// scratch region of the panel-wise factorisations: every diagonal block they hand to potrf_inverse_rec has B rows
+// except the last, which has n mod B -- and a ragged last block (not a multiple of 16) needs MORE than a full one (its
+// zero-padded copies: 2 n16^2 on top of the panel kernel's own ldp (ldp + 128))
+static int64_t panel_scratch_doubles(int64_t n, int64_t B) {
+  int64_t w = B * B;
+  if (potrf_inverse_work_doubles(B) > w) w = potrf_inverse_work_doubles(B);
+  if (n % B != 0 && potrf_inverse_work_doubles(n % B) > w) w = potrf_inverse_work_doubles(n % B);
+  return w;
 }
 
 // padded16: rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are zero (they stay zero)
@@ -1347,8 +1361,7 @@ constexpr int64_t POTRF_PANEL = 1024;
 
 int64_t potrf_blocked_work_doubles(int64_t n) {
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
-  const int64_t w = potrf_inverse_work_doubles(B);
-  return B * B + (w > B * B ? w : B * B) + 2 * n * B;
+  return B * B + panel_scratch_doubles(n, B) + 2 * n * B;
 }
 
 
@@ -1362,9 +1375,8 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
   const int64_t B = n < POTRF_PANEL ? n : POTRF_PANEL;
   double* Wk = work;           // B x B inverse of the diagonal block
   double* scr = Wk + B * B;    // scratch of the factor-and-inverse step (at least B x B)
-  const int64_t wscr = potrf_inverse_work_doubles(B);
   double* Pbuf[2];
-  Pbuf[0] = scr + (wscr > B * B ? wscr : B * B);   // (n - k0 - nb) x nb panel column, two of them
+  Pbuf[0] = scr + panel_scratch_doubles(n, B);     // (n - k0 - nb) x nb panel column, two of them
   Pbuf[1] = Pbuf[0] + n * B;
   static const bool la_on = [] {
     const char* e = std::getenv("GSS_POTRF_LOOKAHEAD");
@@ -1387,6 +1399,12 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
     // (Wk's strict upper triangle is zero on entry and nothing ever writes there: zeroed once, and again only for
     // the last panel, whose leading dimension differs)
     if (k0 == 0 || nb != B) rc = dev_zero_bytes(Wk, sizeof(double) * (size_t)(nb * nb), s);
+    // a ragged last panel works through padded copies in the scratch: it starts behind the helper's work of the
+    // panel before it (which reads the other panel column), whatever the sizes of the regions
+    if (rc == GSS_OK && nb != B && b_pending) {
+      if (hipStreamWaitEvent(s, ev_b, 0) != hipSuccess) rc = GSS_ERR_HIP;
+      b_pending = false;
+    }
     if (rc == GSS_OK) rc = potrf_inverse_rec(Akk, lda, Wk, nb, nb, k0, d_info, scr, true, s, false);
     if (rc != GSS_OK || m2 <= 0) continue;
     double* Ap = Akk + nb;                 // rows below the diagonal block
@@ -1431,8 +1449,7 @@ int32_t potrf_blocked_f64(double* A, int64_t n, int64_t lda, int* d_info, double
 // the bulk) go to the helper stream and run beside the next panel.  No inverse of L11 is formed.
 int64_t potrf_joint_work_doubles(int64_t nd, int64_t mb) {
   const int64_t B = nd < POTRF_PANEL ? nd : POTRF_PANEL;
-  const int64_t w = potrf_inverse_work_doubles(B);
-  return B * B + (w > B * B ? w : B * B) + 2 * (nd + mb) * B;
+  return B * B + panel_scratch_doubles(nd, B) + 2 * (nd + mb) * B;
 }
 
 int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_t ld21, double* C22, int64_t ns,
@@ -1441,10 +1458,9 @@ int32_t potrf_joint_f64(double* C11, int64_t nd, double* C21, int64_t mb, int64_
   const int64_t B = nd < POTRF_PANEL ? nd : POTRF_PANEL;
   double* Wk = work;
   double* scr = Wk + B * B;
-  const int64_t wscr = potrf_inverse_work_doubles(B);
   double* Pt[2];
   double* Pb[2];
-  Pt[0] = scr + (wscr > B * B ? wscr : B * B);
+  Pt[0] = scr + panel_scratch_doubles(nd, B);
   Pt[1] = Pt[0] + nd * B;
   Pb[0] = Pt[1] + nd * B;
   Pb[1] = Pb[0] + mb * B;

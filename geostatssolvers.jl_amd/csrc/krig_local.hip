@@ -302,7 +302,6 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
   __shared__ double G[LMAX_RHS][LMAX_RHS];
   __shared__ double Ssm[LMAX_NC][LMAX_NC + 1];
   __shared__ double rv[LMAX_NC], tv[LMAX_NC];
-  __shared__ int bad_flag;
   const int tid = threadIdx.x;
   const int nc = sp.nc;
   const int nrhs = 2 + nc;
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
     double c0[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
-    if (tid == 0) bad_flag = 0;
+    bool failed = false;
     // ---- assembly: covariance triangle (entries dealt round-robin), then the extra rows
     for (int64_t e = tid; e < ntri; e += BIG_NT) {
       int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
@@ -370,6 +369,7 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
     // ---- root-free Cholesky sweep by columns: row i of the array is owned by thread i mod 256
     for (int j = 0; j < K1; ++j) {
       const double* rowj = M + (int64_t)j * (j + 1) / 2;
+      int pivot_bad = 0;  // set by the one thread that owns the diagonal entry of this column
       for (int i = j + tid; i < RT; i += BIG_NT) {
         double* rowi = i < K1 ? M + (int64_t)i * (i + 1) / 2 : M + ntri + (int64_t)(i - K1) * K1;
         double a0 = rowi[j], a1 = 0.0;
@@ -382,14 +382,18 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
         const double acc = a0 + a1;
         rowi[j] = acc;
         if (i == j) {
-          if (!(acc > 0.0)) bad_flag = 1;
+          if (!(acc > 0.0)) pivot_bad = 1;
           invd[j] = 1.0 / acc;
         }
       }
-      __syncthreads();
-      if (bad_flag) break;
+      // the column's barrier carries the verdict on its pivot, so every wave decides on the SAME column (a flag in
+      // LDS read behind the barrier could already be the next column's)
+      if (__syncthreads_or(pivot_bad)) {
+        failed = true;
+        break;
+      }
     }
-    if (bad_flag) {
+    if (failed) {
       if (tid == 0) {
         mean_out[p] = NaN;
         var_out[p] = NaN;

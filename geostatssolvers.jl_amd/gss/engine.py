@@ -27,15 +27,17 @@ def _vg_struct(vg, dim, extent=None):
         a = 2.0 * (vg.range * max(float(extent), 1e-300) ** vg.nu) + vg.nugget + 1e-300
         return make_variogram("power", dim, a, vg.nugget, vg.range, vg.nu, None)
     if getattr(vg, "kind", None) == "nested":
-        # first structure carries the total nugget; every structure contributes c_i (sill_i - nugget_i)
-        terms = [(w, m) for w, m in vg.terms if w * (m.sill - m.nugget) > 0.0]
+        # first structure carries the total nugget; every structure contributes c_i (sill_i - nugget_i); a Gaussian
+        # structure's nugget is the regularised one (variograms.py: nugget + 1e-6 unless regularize=False)
+        terms = [(w, m) for w, m in vg.terms if w * (m.sill - m.effective_nugget) > 0.0]
         if not terms:
             raise ValueError("nested variogram without a structured (non-nugget) component")
         w0, m0 = terms[0]
-        nug = vg.nugget
-        extras = [(m.kind, w * (m.sill - m.nugget), m.range, m.nu, m.radii) for w, m in terms[1:]]
-        return make_variogram(m0.kind, dim, w0 * (m0.sill - m0.nugget) + nug, nug, m0.range, m0.nu, m0.radii, extras)
-    return make_variogram(vg.kind, dim, vg.sill, vg.nugget, vg.range, vg.nu, vg.radii)
+        nug = vg.effective_nugget
+        extras = [(m.kind, w * (m.sill - m.effective_nugget), m.range, m.nu, m.radii) for w, m in terms[1:]]
+        return make_variogram(m0.kind, dim, w0 * (m0.sill - m0.effective_nugget) + nug, nug, m0.range, m0.nu, m0.radii,
+                              extras)
+    return make_variogram(vg.kind, dim, vg.sill, getattr(vg, "effective_nugget", vg.nugget), vg.range, vg.nu, vg.radii)
 
 
 def _extent(x):

@@ -2,11 +2,19 @@
 (`GaussianVariogram(range=35., nugget=0.)`, `SphericalVariogram(range=10.)`,
 `GaussianVariogram(MetricBall((20., 5.)))` -- /root/reference/test/estimation/krig.jl:10,
 test/simulation/lu.jl:11,59-60, test/simulation/fft.jl:11).  They only carry parameters;
-evaluation happens on the device (csrc/gss_internal.h cov_from_d2)."""
+evaluation happens on the device (csrc/gss_internal.h cov_from_d2).
+
+Gaussian model: [RECALL] Variography evaluates `GaussianVariogram` with `nugget + 1e-6` ("small eps ... for numerical
+stability") -- which is why the reference's own suite can factor Gaussian covariances of 10^4 cells with
+the nugget left at 0 (test/simulation/lu.jl:29-64).  `effective_nugget` applies that rule where the parameters are
+handed to the device (`engine._vg_struct`); `GaussianVariogram(..., regularize=False)` opts out.  The kernels know
+nothing of it: it is a parameter change."""
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Optional, Tuple
+
+GAUSSIAN_NUGGET_EPS = 1e-6
 
 
 @dataclass(frozen=True)
@@ -31,9 +39,15 @@ class VariogramModel:
     range: float = 1.0
     nu: float = 1.0
     radii: Optional[Tuple[float, ...]] = None
+    regularize: bool = True      # Gaussian model only (module docstring)
 
     def isstationary(self):
         return self.kind != "power"
+
+    @property
+    def effective_nugget(self):
+        """The nugget the evaluation uses; `nugget` stays what the user gave (as Variography's `nugget(γ)`)."""
+        return self.nugget + (GAUSSIAN_NUGGET_EPS if self.kind == "gaussian" and self.regularize else 0.0)
 
     # gamma1 + gamma2 and c * gamma build a NestedVariogram ([DEP] Variography)
     def __add__(self, other):
@@ -68,11 +82,15 @@ class NestedVariogram:
     def nugget(self):
         return sum(w * m.nugget for w, m in self.terms)
 
+    @property
+    def effective_nugget(self):
+        return sum(w * m.effective_nugget for w, m in self.terms)
+
     def isstationary(self):
         return True
 
 
-def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=None):
+def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=None, regularize=True):
     radii = None
     if ball is not None:
         if not isinstance(ball, MetricBall):
@@ -82,7 +100,7 @@ def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=No
         else:
             radii, range = ball.radii, 1.0
     o = order if order is not None else (nu if nu is not None else 1.0)
-    return VariogramModel(kind, float(sill), float(nugget), float(range), float(o), radii)
+    return VariogramModel(kind, float(sill), float(nugget), float(range), float(o), radii, bool(regularize))
 
 
 def GaussianVariogram(ball=None, **kw):

@@ -147,6 +147,16 @@ vgkind(::CubicVariogram) = Int32(4)
 vgkind(::PentasphericalVariogram) = Int32(5)
 vgkind(::SineHoleVariogram) = Int32(6)
 
+# The nugget the loaded Variography evaluates with.  [RECALL] its `GaussianVariogram` functor adds a small constant
+# ("add small eps to nugget for numerical stability": `n = nugget + 1e-6`) that the `nugget(γ)` accessor does not
+# show -- the reason the reference's suite can factor Gaussian covariances of 10^4 cells with nugget 0
+# (test/simulation/lu.jl:29-64).  The parameters cross the C-ABI, not the functor, so the rule is applied here;
+# `GeoStatsSolversHIP.GAUSSIAN_NUGGET_EPS[] = 0.0` switches it off.
+const GAUSSIAN_NUGGET_EPS = Ref(1e-6)
+effnugget(γ) = Float64(ustrip(nugget(γ)))
+effnugget(γ::GaussianVariogram) = Float64(ustrip(nugget(γ))) + GAUSSIAN_NUGGET_EPS[]
+effnugget(γ::NestedVariogram) = sum(Float64(c) * effnugget(g) for (c, g) in zip(γ.cs, γ.γs))
+
 function structure(γ)            # (kind, aniso, range, nu, inv_radii) of one basic model
   rs = radii(metricball(γ))
   aniso = length(rs) > 1
@@ -167,21 +177,21 @@ function cvariogram(γ, dim; extent=nothing)
   isstationary(γ) || throw(ArgumentError("variogram model must be stationary"))   # fft.jl:91-93, lu.jl:110
   if γ isa NestedVariogram       # gamma = sum c_i gamma_i: first structure carries the total nugget
     cs, γs = γ.cs, γ.γs
-    keep = [i for i in eachindex(γs) if cs[i] * (sill(γs[i]) - nugget(γs[i])) > 0]
+    keep = [i for i in eachindex(γs) if cs[i] * (sill(γs[i]) - effnugget(γs[i])) > 0]
     length(keep) <= 4 || throw(ArgumentError("at most 4 nested structures are supported on the device"))
     k0, a0, r0, ν0, ir0 = structure(γs[keep[1]])
-    nug = Float64(nugget(γ))
+    nug = effnugget(γ)
     extras = ntuple(3) do j
       j + 1 > length(keep) && return NOEXTRA
       i = keep[j+1]
       k, a, r, ν, ir = structure(γs[i])
-      GssVgExtra(k, a, Float64(cs[i] * (sill(γs[i]) - nugget(γs[i]))), r, ν, ir)
+      GssVgExtra(k, a, Float64(cs[i] * (sill(γs[i]) - effnugget(γs[i]))), r, ν, ir)
     end
-    c0 = Float64(cs[keep[1]] * (sill(γs[keep[1]]) - nugget(γs[keep[1]])))
+    c0 = Float64(cs[keep[1]] * (sill(γs[keep[1]]) - effnugget(γs[keep[1]])))
     return GssVariogram(k0, Int32(dim), c0 + nug, nug, r0, ν0, a0, Int32(0), ir0, Int32(length(keep) - 1), Int32(0), extras)
   end
   k, a, r, ν, ir = structure(γ)
-  GssVariogram(k, Int32(dim), Float64(sill(γ)), Float64(nugget(γ)), r, ν, a, Int32(0), ir, Int32(0), Int32(0),
+  GssVariogram(k, Int32(dim), Float64(sill(γ)), effnugget(γ), r, ν, a, Int32(0), ir, Int32(0), Int32(0),
                (NOEXTRA, NOEXTRA, NOEXTRA))
 end
 

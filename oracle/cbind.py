@@ -5,6 +5,8 @@ import subprocess
 
 import numpy as np
 
+from .variogram import effective_nugget
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _KINDS = {"gaussian": 0, "exponential": 1, "spherical": 2, "matern": 3}
 
@@ -32,7 +34,7 @@ def krig_global(vg, variant, x, z, x0, mean=0.0, nthreads=1):
     z = np.ascontiguousarray(z, dtype=np.float64)
     mu = np.empty(x0.shape[0])
     var = np.empty(x0.shape[0])
-    rc = _lib().krig_oracle_global(_KINDS[vg.kind], x.shape[1], vg.sill, vg.nugget, vg.range, vg.nu, variant,
+    rc = _lib().krig_oracle_global(_KINDS[vg.kind], x.shape[1], vg.sill, effective_nugget(vg), vg.range, vg.nu, variant,
                                    float(mean), x.ctypes.data, z.ctypes.data, x.shape[0], x0.ctypes.data,
                                    x0.shape[0], mu.ctypes.data, var.ctypes.data, int(nthreads))
     if rc:

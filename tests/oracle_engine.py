@@ -12,7 +12,8 @@ def _ovg(vg):
     if getattr(vg, "kind", None) == "nested":
         from oracle.variogram import Nested
         return Nested([(w, _ovg(m)) for w, m in vg.terms])
-    return Variogram(vg.kind, sill=vg.sill, nugget=vg.nugget, range=vg.range, nu=vg.nu, radii=vg.radii)
+    return Variogram(vg.kind, sill=vg.sill, nugget=vg.nugget, range=vg.range, nu=vg.nu, radii=vg.radii,
+                     regularize=getattr(vg, "regularize", True))
 
 
 class _Krig:

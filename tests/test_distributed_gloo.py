@@ -35,6 +35,7 @@ def _problem_inputs():
 class _NotPosDef:
     """Variogram stand-in whose covariance is not positive definite: makes rank 0's LUGS preprocess raise."""
     kind, sill, nugget, range, nu, radii = "gaussian", 1.0, 0.0, 1e9, 1.0, None
+    regularize = False                 # without the Gaussian model's nugget epsilon (gss/variograms.py)
 
     def isstationary(self):
         return True

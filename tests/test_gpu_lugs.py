@@ -50,6 +50,21 @@ def test_factor_and_realisations_match_oracle(dims, ndata):
     h.close()
 
 
+def test_even_panel_count_with_a_ragged_last_panel():
+    """ns = 3 969 = 3 x 1 024 + 897: four panels, the last one ragged (not a multiple of 16) -- the case in which the
+    padded copies of the last panel's factor-and-inverse need more scratch than a full panel while the helper stream
+    still reads the panel column behind it (dense_la.hip, panel_scratch_doubles).  Against the oracle, 1e-9."""
+    from gss.engine import LUGSHandle
+    cent = offt.grid_centroids((63, 63))
+    kw = dict(range=9.0, nugget=0.02)
+    for _ in range(2):          # twice: the second run finds the pool's blocks in a different state
+        h = LUGSHandle(_mk("spherical", **kw), cent, [], [], 0.0)
+        L22, _ = h.factor()
+        h.close()
+        ref = np.linalg.cholesky(cov_pairwise(Variogram("spherical", **kw), cent))
+        assert np.max(np.abs(L22 - ref)) < 1e-9
+
+
 def test_cosimulation_matches_oracle():
     from gss.engine import LUGSHandle
     cent = offt.grid_centroids((500,))                                # test/simulation/lu.jl:33-45
@@ -95,18 +110,13 @@ def test_reference_cases_through_solve_api():
     sol = gss.solve(gss.SimulationProblem(D, ("z", float), 2),
                     gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))), rng=123))
     assert np.all(np.isfinite(sol["z"][0]))
-    # co-simulation (lu.jl:29-45)
+    # co-simulation, as written (lu.jl:29-39): the Gaussian model with its nugget left at 0
     D5 = gss.CartesianGrid(500)
     solver = gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))),
-                      ("y", dict(variogram=gss.GaussianVariogram(range=10.0, nugget=1e-4))),
+                      ("y", dict(variogram=gss.GaussianVariogram(range=10.0))),
                       (("z", "y"), dict(correlation=0.95)), rng=123)
     sol = gss.solve(gss.SimulationProblem(D5, (("z", float), ("y", float)), 1), solver)
-    assert sol[0].z.shape == (500,) and sol[0].y.shape == (500,)
-    # anisotropy (lu.jl:56-64), with a nugget so the Gaussian model is numerically positive definite
-    ball = gss.MetricBall((20.0, 5.0))
-    sol = gss.solve(gss.SimulationProblem(gss.CartesianGrid(40, 40), ("z", float), 3),
-                    gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(ball, nugget=1e-3))), rng=123))
-    assert len(sol["z"]) == 3 and np.all(np.isfinite(sol["z"][2]))
+    assert sol[0].z.shape == (500,) and sol[0].y.shape == (500,) and np.all(np.isfinite(sol[0].y))
     # custom factorization (test/simulation/lu.jl:66-76): both run, as in the reference
     for fact in ("lu", "cholesky"):
         sol = gss.solve(gss.SimulationProblem(S, D, "z", 1),
@@ -117,17 +127,41 @@ def test_reference_cases_through_solve_api():
                   gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), mean=1.0)), rng=1))
 
 
-def test_gaussian_without_nugget_reports_not_posdef_or_runs():
-    """test/simulation/lu.jl:47-54 runs a 100x100 Gaussian model with no nugget (10^4 x 10^4 Cholesky of a
-    numerically singular matrix); on the device this either factors or fails loudly, never silently."""
+@pytest.mark.parametrize("ball", [None, (20.0, 5.0)])
+def test_reference_gaussian_100x100_cases_run_as_written(ball):
+    """test/simulation/lu.jl:41-52 (`GaussianVariogram(range=10.0)`) and :54-64 (`GaussianVariogram(MetricBall((20.,5.)))`)
+    on `CartesianGrid(100, 100)`, three realisations, nugget left at 0 -- as written.  They run because the Gaussian model
+    is evaluated with `nugget + 1e-6` (gss/variograms.py) exactly as in the oracle.  cond(C) ~ 1e10, so the
+    factors are compared through what is backward stable: rows of L22 L22' against C to 1e-9, and the realisations
+    against the oracle's (same Philox normals, LAPACK factor) to 1e-4 absolute."""
+    import gss
+    from gss.engine import LUGSHandle
+    grid = gss.CartesianGrid(100, 100)
+    gvg = gss.GaussianVariogram(range=10.0) if ball is None else gss.GaussianVariogram(gss.MetricBall(ball))
+    ovg = Variogram("gaussian", range=10.0) if ball is None else Variogram("gaussian", radii=ball)
+    sol = gss.solve(gss.SimulationProblem(grid, ("z", float), 3), gss.LUGS(("z", dict(variogram=gvg)), rng=123))
+    zs = np.stack(sol["z"])
+    assert zs.shape == (3, 10000) and np.all(np.isfinite(zs)) and 0.3 < zs.var() < 2.5
+    cent = grid.centroids()
+    p = O.preprocess(ovg, cent)
+    ref, _ = O.realize(p, 123, 0, 3)
+    assert np.max(np.abs(zs - ref)) < 1e-4
+    h = LUGSHandle(gvg, cent, [], [], 0.0)
+    L22, _ = h.factor()
+    h.close()
+    for i in np.random.default_rng(1).integers(0, 10000, 6):
+        assert np.max(np.abs(L22[i] @ L22.T - cov_pairwise(ovg, cent[i:i + 1], cent)[0])) < 1e-9
+
+
+def test_gaussian_without_the_regularisation_is_reported_not_silently_wrong():
+    """`regularize=False` restores the bare model: the same 100 x 100 lattice is then numerically singular and the
+    device says so (GSS_ERR_NOT_POSDEF), as LAPACK does in the oracle."""
     import gss
     from gss import _lib
-    try:
-        sol = gss.solve(gss.SimulationProblem(gss.CartesianGrid(30, 30), ("z", float), 1),
-                        gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(range=10.0))), rng=123))
-        assert np.all(np.isfinite(sol["z"][0]))
-    except _lib.GSSError as e:
-        assert e.code == _lib.ERR_NOT_POSDEF
+    with pytest.raises(_lib.GSSError) as e:
+        gss.solve(gss.SimulationProblem(gss.CartesianGrid(100, 100), ("z", float), 1),
+                  gss.LUGS(("z", dict(variogram=gss.GaussianVariogram(range=10.0, regularize=False))), rng=123))
+    assert e.value.code == _lib.ERR_NOT_POSDEF
 
 
 def test_2d_100x100_runs_with_properties():

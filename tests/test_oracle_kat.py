@@ -37,7 +37,12 @@ def test_variogram_shapes():
         assert np.allclose(cov_h(vg, h), 2.0 - g)
     # practical range: ~95% of the sill at h = range
     for kind in ("gaussian", "exponential"):
-        assert abs(gamma_h(Variogram(kind, range=10.0), 10.0) - (1 - np.exp(-3))) < 1e-15
+        assert abs(gamma_h(Variogram(kind, range=10.0, regularize=False), 10.0) - (1 - np.exp(-3))) < 1e-15
+    # the Gaussian model is evaluated with nugget + 1e-6 ([RECALL] Variography); nothing else is
+    g = Variogram("gaussian", range=10.0, sill=2.0, nugget=0.25)
+    assert g.nugget == 0.25 and abs(gamma_h(g, 1e-12) - (0.25 + 1e-6)) < 1e-15 and gamma_h(g, 0.0) == 0.0
+    assert abs(gamma_h(g, 10.0) - ((2.0 - 0.25 - 1e-6) * (1 - np.exp(-3)) + 0.25 + 1e-6)) < 1e-15
+    assert gamma_h(Variogram("exponential", range=10.0), 1e-12) < 1e-11
     assert gamma_h(Variogram("spherical", range=10.0), 10.0) == 1.0
 
 
@@ -50,7 +55,7 @@ def test_matern_closed_forms_match_bessel_form():
 
 
 def test_anisotropic_ball_distance():
-    vg = Variogram("gaussian", radii=(20.0, 5.0))
+    vg = Variogram("gaussian", radii=(20.0, 5.0), regularize=False)
     c = cov_pairwise(vg, np.array([[0.0, 0.0]]), np.array([[20.0, 0.0], [0.0, 5.0], [0.0, 0.0]]))
     assert abs(c[0, 0] - np.exp(-3)) < 1e-15 and abs(c[0, 1] - np.exp(-3)) < 1e-15 and c[0, 2] == 1.0
 
