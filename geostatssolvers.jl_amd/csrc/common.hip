@@ -1,6 +1,7 @@
 // Library context, error reporting, memory staging, variogram validation.
 #include "gss_internal.h"
 
+#include <atomic>
 #include <mutex>
 
 #include <cmath>
@@ -11,9 +12,15 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace gss {
+
+std::recursive_mutex& api_mutex() {
+  static std::recursive_mutex mu;
+  return mu;
+}
 
 // ---- profiling registry --------------------------------------------------------------------
 struct ProfEntry {
@@ -23,10 +30,12 @@ struct ProfEntry {
 };
 static bool g_prof_on = false;
 static std::map<std::string, ProfEntry> g_prof;
+static std::mutex g_prof_mu;   // the registry, the block cache and the stream chain below are shared by every host thread
 
 bool prof_enabled() { return g_prof_on; }
 
 void prof_begin(const char* name, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   ProfEntry& e = g_prof[name];
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess) return;
@@ -40,6 +49,7 @@ void prof_begin(const char* name, hipStream_t s) {
 }
 
 void prof_end(const char* name, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   ProfEntry& e = g_prof[name];
   if (e.stop.size() == e.start.size() && !e.stop.empty()) (void)hipEventRecord(e.stop.back(), s);
 }
@@ -63,8 +73,11 @@ static hipStream_t g_last_stream = nullptr;
 static bool g_have_last_stream = false;
 static hipEvent_t g_chain_event = nullptr;
 
+static std::mutex g_chain_mu;
+
 hipStream_t to_stream(void* sv) {
   hipStream_t s = reinterpret_cast<hipStream_t>(sv);
+  std::lock_guard<std::mutex> lock(g_chain_mu);
   if (g_have_last_stream && s != g_last_stream) {
     bool chained = false;
     if (!g_chain_event && hipEventCreateWithFlags(&g_chain_event, hipEventDisableTiming) != hipSuccess)
@@ -103,6 +116,7 @@ struct PoolBlock {
 };
 static std::vector<PoolBlock> g_pool;
 static size_t g_pool_bytes = 0;
+static std::mutex g_pool_mu;
 // Sized for 288 GB of HBM: up to 16 GiB of released blocks stay cached (GSS_POOL_MAX_MB overrides; a failing
 // hipMalloc gives them all back first), single blocks up to a quarter of that -- the 1.2 GB state of a configs[3]
 // LUGS handle and the 2 GiB FFTGS buffers are re-used instead of being freed (a device synchronisation) and
@@ -110,8 +124,16 @@ static size_t g_pool_bytes = 0;
 static size_t pool_max_bytes() {
   static const size_t v = [] {
     const char* e = std::getenv("GSS_POOL_MAX_MB");
-    const long long mb = e ? atoll(e) : 16384;
-    return (size_t)(mb < 0 ? 0 : mb) << 20;
+    if (e) {
+      const long long mb = atoll(e);
+      return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }
+    // default: a quarter of what is free when the library first allocates, at most 16 GiB -- a second rank on the same
+    // device, or another allocator in this process, must not find the memory gone (they cannot make us give it back)
+    size_t fr = 0, tot = 0;
+    size_t cap = (size_t)16 << 30;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 4 < cap) cap = fr / 4;
+    return cap;
   }();
   return v;
 }
@@ -120,6 +142,7 @@ constexpr size_t POOL_MAX_COUNT = 96;
 int32_t DevBuf::alloc(size_t nbytes) {
   release();
   if (nbytes == 0) nbytes = 8;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
   // best fit among the cached blocks: the smallest one that holds the request and is at most a quarter larger
   // (sizes follow the problem: a point or a datum more must not cost a hipMalloc)
   size_t best = (size_t)-1;
@@ -154,6 +177,7 @@ int32_t DevBuf::alloc(size_t nbytes) {
 
 void DevBuf::release() {
   if (p) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
     if (cap <= pool_max_bytes() / 4) {
       // a full cache gives up its oldest blocks: sizes change from solve to solve, and the sizes of the latest
       // solves are the ones most likely to come back
@@ -315,6 +339,186 @@ int32_t HostPipe::finish(hipStream_t s) {
   return GSS_OK;
 }
 
+// ---- OutStream (gss_internal.h) ------------------------------------------------------------------------------
+constexpr size_t BOUNCE_BYTES = (size_t)32 << 20;
+static void* g_bounce[2] = {nullptr, nullptr};   // pinned, process-wide, freed by gss_shutdown
+static std::mutex g_bounce_mu;
+
+static void* bounce_buffer(int i) {
+  std::lock_guard<std::mutex> lock(g_bounce_mu);
+  if (!g_bounce[i] && hipHostMalloc(&g_bounce[i], BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g_bounce[i] = nullptr;
+  }
+  return g_bounce[i];
+}
+
+static void free_bounce_buffers() {
+  std::lock_guard<std::mutex> lock(g_bounce_mu);
+  for (int i = 0; i < 2; ++i) {
+    if (g_bounce[i]) (void)hipHostFree(g_bounce[i]);
+    g_bounce[i] = nullptr;
+  }
+}
+
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();   // an ordinary (pageable) host pointer is "invalid value" to the runtime
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+struct BounceCopy {
+  char* dst;
+  const char* src;
+  size_t bytes;
+};
+
+// runs on a runtime thread in stream order behind the transfer of the piece; no HIP calls in here
+static void bounce_copy_fn(void* pv) {
+  BounceCopy* c = static_cast<BounceCopy*>(pv);
+  constexpr int NT = 4;
+  const size_t part = (c->bytes / NT + 4095) & ~(size_t)4095;
+  std::thread th[NT - 1];
+  int started = 0;
+  for (int t = 1; t < NT; ++t) {
+    const size_t lo = (size_t)t * part;
+    if (lo >= c->bytes) break;
+    const size_t n = c->bytes - lo < part ? c->bytes - lo : part;
+    th[started++] = std::thread([=] { std::memcpy(c->dst + lo, c->src + lo, n); });
+  }
+  std::memcpy(c->dst, c->src, c->bytes < part ? c->bytes : part);
+  for (int t = 0; t < started; ++t) th[t].join();
+  delete c;
+}
+
+static size_t out_chunk_bytes() {   // read per call: the tests shrink it to push small problems through many chunks
+  const char* e = std::getenv("GSS_OUT_CHUNK_MB");
+  const long long mb = e ? atoll(e) : 256;
+  return (size_t)(mb < 1 ? 1 : mb) << 20;
+}
+
+static std::atomic<int64_t> g_stat_ring_bytes{0}, g_stat_chunks{0};
+
+OutStream::~OutStream() {
+  if (issued) {  // an early exit: nothing may still write into the ring or read it when its blocks return to the pool
+    for (int i = 0; i < 2; ++i)
+      if (cs[i]) (void)hipStreamSynchronize(cs[i]);
+  }
+  for (int i = 0; i < DEPTH; ++i) {
+    if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+    if (ev_free[i]) (void)hipEventDestroy(ev_free[i]);
+  }
+  if (ev_join) (void)hipEventDestroy(ev_join);
+}
+
+size_t OutStream::staged_bytes() const {
+  size_t b = 0;
+  for (int i = 0; i < DEPTH; ++i) b += ring[i].bytes;
+  return b;
+}
+
+int64_t OutStream::default_chunk(size_t real_bytes_, int64_t nreals_) {
+  int64_t c = real_bytes_ ? (int64_t)(out_chunk_bytes() / real_bytes_) : nreals_;
+  if (c < 1) c = 1;
+  return c > nreals_ ? nreals_ : c;
+}
+
+int32_t OutStream::begin(void* dst_, size_t real_bytes_, int64_t nreals_, int32_t mem, hipStream_t s,
+                         int64_t chunk_reals) {
+  dst = static_cast<char*>(dst_);
+  real_bytes = real_bytes_;
+  nreals = nreals_;
+  on = false;
+  if (mem != GSS_MEM_HOST || dst == nullptr || nreals <= 0 || real_bytes == 0) return GSS_OK;
+  chunk = chunk_reals > 0 ? (chunk_reals > nreals ? nreals : chunk_reals) : default_chunk(real_bytes, nreals);
+  const int64_t nchunks = (nreals + chunk - 1) / chunk;
+  const int depth = nchunks < DEPTH ? (int)nchunks : DEPTH;
+  // not the streams the FFTGS slabs run on (GEN0, GEN1): a transfer queued there would hold the slab kernels behind it
+  cs[0] = helper_stream(HELPER_GEN2);
+  cs[1] = helper_stream(HELPER_LOOKAHEAD);
+  GSS_REQUIRE(cs[0] != nullptr && cs[1] != nullptr, "no copy streams for the host outputs");
+  for (int i = 0; i < depth; ++i) {
+    GSS_TRY(ring[i].alloc(real_bytes * (size_t)chunk));
+    GSS_HIP(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+    GSS_HIP(hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
+  }
+  GSS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  g_stat_ring_bytes.store((int64_t)staged_bytes());
+  g_stat_chunks.store(0);
+  pinned_dst = host_pointer_is_pinned(dst) && host_pointer_is_pinned(dst + real_bytes * (size_t)nreals - 1);
+  if (!pinned_dst) GSS_REQUIRE(bounce_buffer(0) && bounce_buffer(1), "no pinned memory for the bounce buffers");
+  // the blocks of the ring may still be in use by work queued earlier (the pool re-uses in submission order)
+  GSS_HIP(hipEventRecord(ev_join, s));
+  GSS_HIP(hipStreamWaitEvent(cs[0], ev_join, 0));
+  GSS_HIP(hipStreamWaitEvent(cs[1], ev_join, 0));
+  on = true;
+  return GSS_OK;
+}
+
+int32_t OutStream::slot(int64_t r, hipStream_t s, double** out) {
+  if (!on) {
+    *out = reinterpret_cast<double*>(dst + (size_t)r * real_bytes);
+    return GSS_OK;
+  }
+  const int64_t c = r / chunk;
+  const int sl = (int)(c % DEPTH);
+  if (r % chunk == 0 && c >= DEPTH) GSS_HIP(hipStreamWaitEvent(s, ev_free[sl], 0));   // chunk c - DEPTH has left
+  *out = reinterpret_cast<double*>(static_cast<char*>(ring[sl].p) + (size_t)(r % chunk) * real_bytes);
+  return GSS_OK;
+}
+
+int32_t OutStream::done(int64_t r, hipStream_t s) {
+  if (!on) return GSS_OK;
+  if ((r + 1) % chunk != 0 && r + 1 != nreals) return GSS_OK;
+  const int64_t c = r / chunk;
+  const int sl = (int)(c % DEPTH);
+  const int64_t r0 = c * chunk;
+  const size_t bytes = (size_t)(r + 1 - r0) * real_bytes;
+  char* to = dst + (size_t)r0 * real_bytes;
+  const char* from = static_cast<const char*>(ring[sl].p);
+  GSS_HIP(hipEventRecord(ev_done[sl], s));
+  issued = true;
+  g_stat_chunks.fetch_add(1);
+  if (pinned_dst) {
+    hipStream_t q = cs[c & 1];
+    GSS_HIP(hipStreamWaitEvent(q, ev_done[sl], 0));
+    GSS_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToHost, q));
+    GSS_HIP(hipEventRecord(ev_free[sl], q));
+    return GSS_OK;
+  }
+  GSS_HIP(hipStreamWaitEvent(cs[0], ev_done[sl], 0));
+  GSS_HIP(hipStreamWaitEvent(cs[1], ev_done[sl], 0));
+  for (size_t off = 0; off < bytes; off += BOUNCE_BYTES, ++piece_no) {
+    const int b = (int)(piece_no & 1);
+    const size_t n = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+    GSS_HIP(hipMemcpyAsync(g_bounce[b], from + off, n, hipMemcpyDeviceToHost, cs[b]));
+    BounceCopy* job = new BounceCopy{to + off, static_cast<const char*>(g_bounce[b]), n};
+    const hipError_t e = hipLaunchHostFunc(cs[b], bounce_copy_fn, job);
+    if (e != hipSuccess) {
+      delete job;
+      set_error("hipLaunchHostFunc failed: %s", hipGetErrorString(e));
+      return GSS_ERR_HIP;
+    }
+  }
+  // the slot is free once both copy streams have passed this chunk
+  GSS_HIP(hipEventRecord(ev_join, cs[0]));
+  GSS_HIP(hipStreamWaitEvent(cs[1], ev_join, 0));
+  GSS_HIP(hipEventRecord(ev_free[sl], cs[1]));
+  return GSS_OK;
+}
+
+int32_t OutStream::finish(hipStream_t s) {
+  if (!on) return GSS_OK;
+  GSS_HIP(hipStreamSynchronize(cs[0]));
+  GSS_HIP(hipStreamSynchronize(cs[1]));
+  GSS_HIP(hipStreamSynchronize(s));
+  issued = false;
+  return GSS_OK;
+}
+
 static int32_t device_kind(int kind, double nu, int* out_kind, double* mscale) {
   *mscale = 0.0;
   switch (kind) {
@@ -444,9 +648,11 @@ using namespace gss;
 
 extern "C" {
 
-int32_t gss_version(void) { return GSS_VERSION; }
+int32_t gss_version(void) {
+  GSS_ENTRY(); return GSS_VERSION; }
 
 int32_t gss_device_count(int32_t* count) {
+  GSS_ENTRY();
   GSS_REQUIRE(count != nullptr, "count is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -456,6 +662,7 @@ int32_t gss_device_count(int32_t* count) {
 }
 
 int32_t gss_init(int32_t device) {
+  GSS_ENTRY();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) {
@@ -474,9 +681,38 @@ int32_t gss_init(int32_t device) {
 }
 
 int32_t gss_shutdown(void) {
+  GSS_ENTRY();
+  free_bounce_buffers();
+  std::lock_guard<std::mutex> lock(g_pool_mu);
   for (auto& b : g_pool) (void)hipFree(b.p);
   g_pool.clear();
   g_pool_bytes = 0;
+  return GSS_OK;
+}
+
+int32_t gss_trim_pool(void) {
+  GSS_ENTRY();
+  GSS_HIP(hipDeviceSynchronize());   // a cached block may still be read by work queued before its release
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (auto& b : g_pool) (void)hipFree(b.p);
+  g_pool.clear();
+  g_pool_bytes = 0;
+  return GSS_OK;
+}
+
+int32_t gss_stat(const char* name, int64_t* value) {
+  GSS_REQUIRE(name != nullptr && value != nullptr, "gss_stat: NULL argument");
+  if (!std::strcmp(name, "pool_bytes")) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    *value = (int64_t)g_pool_bytes;
+  } else if (!std::strcmp(name, "out_ring_bytes")) {
+    *value = g_stat_ring_bytes.load();
+  } else if (!std::strcmp(name, "out_chunks")) {
+    *value = g_stat_chunks.load();
+  } else {
+    set_error("gss_stat: unknown counter '%s'", name);
+    return GSS_ERR_INVALID;
+  }
   return GSS_OK;
 }
 
@@ -488,18 +724,23 @@ int32_t gss_last_error(char* buf, int32_t len) {
 }
 
 int32_t gss_profile_enable(int32_t on) {
+  GSS_ENTRY();
   g_prof_on = on != 0;
   return GSS_OK;
 }
 
 int32_t gss_profile_reset(void) {
+  GSS_ENTRY();
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   for (auto& kv : g_prof) prof_collect(kv.second);
   g_prof.clear();
   return GSS_OK;
 }
 
 int32_t gss_profile_read(const char* name, double* total_ms, int64_t* launches) {
+  GSS_ENTRY();
   GSS_REQUIRE(name != nullptr && total_ms != nullptr && launches != nullptr, "gss_profile_read: NULL argument");
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   auto it = g_prof.find(name);
   if (it == g_prof.end()) {
     *total_ms = 0.0;
@@ -513,6 +754,7 @@ int32_t gss_profile_read(const char* name, double* total_ms, int64_t* launches) 
 }
 
 int32_t gss_synchronize(void* stream) {
+  GSS_ENTRY();
   GSS_HIP(hipStreamSynchronize(to_stream(stream)));
   return GSS_OK;
 }

@@ -49,6 +49,7 @@ using namespace gss;
 
 extern "C" int32_t gss_cov_pairwise(const gss_variogram_t* vg, const double* a, int64_t na, const double* b,
                                     int64_t nb, double* out, int64_t ldo, int32_t mem, void* stream) {
+  GSS_ENTRY();
   VgDev v;
   GSS_TRY(make_vgdev(vg, &v));
   GSS_REQUIRE(a != nullptr && out != nullptr && na >= 0, "gss_cov_pairwise: bad arguments");

@@ -1517,6 +1517,7 @@ using namespace gss;
 extern "C" {
 
 int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(a != nullptr && n >= 0 && lda >= n, "gss_dev_potrf: bad arguments");
   hipStream_t s = to_stream(stream);
   DevBuf info, dinv;
@@ -1534,6 +1535,7 @@ int32_t gss_dev_potrf(double* a, int64_t n, int64_t lda, void* stream) {
 }
 
 int32_t gss_dev_potrf_inverse(double* a, int64_t n, int64_t lda, double* w, int64_t ldw, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(a != nullptr && w != nullptr && n >= 0 && lda >= n && ldw >= n, "gss_dev_potrf_inverse: bad arguments");
   if (n == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
@@ -1558,6 +1560,7 @@ int32_t gss_dev_potrf_inverse(double* a, int64_t n, int64_t lda, double* w, int6
 }
 
 int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_t ldw, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(l != nullptr && w != nullptr && n >= 0 && ldl >= n && ldw >= n, "gss_dev_trtri: bad arguments");
   hipStream_t s = to_stream(stream);
   DevBuf T;
@@ -1572,6 +1575,7 @@ int32_t gss_dev_trtri(const double* l, int64_t n, int64_t ldl, double* w, int64_
 int32_t gss_dev_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sa_i, int64_t sa_k,
                      const double* B, int64_t sb_k, int64_t sb_j, double beta, double* D, int64_t sd_i,
                      int64_t sd_j, int32_t lower_only, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(A && B && D && M >= 0 && N >= 0 && K >= 0, "gss_dev_gemm: bad arguments");
   // bit 0: lower tiles only; bits 1..3: zero structure of an operand (GEMM_TRI_* << 1), test support
   return gemm_f64(M, N, K, alpha, A, sa_i, sa_k, B, sb_k, sb_j, beta, D, sd_i, sd_j, (lower_only & 1) != 0,

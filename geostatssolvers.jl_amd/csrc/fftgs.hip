@@ -658,6 +658,7 @@ extern "C" {
 
 int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t ndim, const int64_t* dims,
                          const double* spacing, double mean, int32_t flags, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(out != nullptr, "gss_fftgs_create: out is NULL");
   *out = nullptr;
   GSS_REQUIRE(ndim >= 1 && ndim <= 3 && dims != nullptr, "FFTGS needs a 1-D, 2-D or 3-D Cartesian grid");
@@ -728,11 +729,13 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
 }
 
 int32_t gss_fftgs_destroy(gss_fftgs_t* h) {
+  GSS_ENTRY();
   delete h;
   return GSS_OK;
 }
 
 int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr && f_out != nullptr, "gss_fftgs_spectrum: NULL argument");
   GSS_REQUIRE(h->ready, "handle has no spectrum");
   hipStream_t s = to_stream(stream);
@@ -745,6 +748,7 @@ int32_t gss_fftgs_spectrum(gss_fftgs_t* h, double* f_out, int32_t mem, void* str
 }
 
 int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
   *dev_ptr = h->state.p;
   *bytes = (int64_t)(sizeof(double) * (size_t)(h->NH + 2));
@@ -752,12 +756,14 @@ int32_t gss_fftgs_state_buffer(gss_fftgs_t* h, void** dev_ptr, int64_t* bytes) {
 }
 
 int32_t gss_fftgs_adopt_state(gss_fftgs_t* h, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   return fftgs_finish_state(h, to_stream(stream));
 }
 
 int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
                           const int64_t* inds, int64_t ninds, double* out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_fftgs_realize: bad arguments");
   GSS_REQUIRE(h->ready, "handle has no spectrum");
   if (nreals == 0) return GSS_OK;
@@ -765,23 +771,39 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
   if (!h->fused) GSS_TRY(ensure_rocfft(h));
   const int64_t N = h->N;
   const int64_t npts = inds ? ninds : N;
-  Staged sn, si, so;
-  GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(nreals * N), mem, s));
+  // Host arrays: the realisations leave chunk by chunk through a ring of at most three chunks (OutStream: the
+  // reference returns every realisation as a host vector, fft.jl:173,197 -- 256 realisations of 512^3 cells are 256 GiB
+  // and never sit in HBM together); supplied noise arrives one realisation at a time on the caller's stream.
+  Staged sn, si;
+  OutStream os;
+  const bool host = mem == GSS_MEM_HOST;
+  if (noise && host) {
+    GSS_TRY(sn.own.alloc(sizeof(double) * (size_t)N));
+    sn.p = sn.own.p;
+  } else {
+    sn.p = const_cast<double*>(noise);
+  }
   GSS_TRY(si.in(inds, sizeof(int64_t) * (size_t)(inds ? ninds : 0), mem, s));
-  GSS_TRY(so.out(out, sizeof(double) * (size_t)(nreals * npts), mem));
+  GSS_TRY(os.begin(out, sizeof(double) * (size_t)npts, nreals, mem, s));
   if (inds && h->Z.bytes < sizeof(double) * (size_t)N) GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N));
 
   // fused pipeline with more than one realisation: P1 of realisation r+1 on the helper stream beside P2..P5 of r
-  const bool piped = h->fused && h->overlap && nreals > 1;
+  const bool piped = h->fused && h->overlap && nreals > 1 && !(noise && host);
   if (piped) {
     GSS_TRY(fftgs_pipeline_setup(h, s));
     GSS_HIP(hipEventRecord(h->ev_in, s));               // everything queued so far (inputs, earlier calls) ...
     GSS_HIP(hipStreamWaitEvent(h->s2, h->ev_in, 0));    // ... precedes the helper stream's first kernel
   }
   for (int64_t r = 0; r < nreals; ++r) {
+    double* dst = nullptr;                              // realisation r's place (caller's HBM or a slot of the ring)
+    GSS_TRY(os.slot(r, s, &dst));
+    const double* nz = nullptr;
+    if (noise) {
+      nz = host ? sn.as<double>() : noise + r * N;
+      if (host) GSS_HIP(hipMemcpyAsync(sn.p, noise + r * N, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, s));
+    }
     if (h->fused) {
-      double* zf = inds ? h->Z.as<double>() : so.as<double>() + r * N;
-      const double* nz = noise ? sn.as<double>() + r * N : nullptr;
+      double* zf = inds ? h->Z.as<double>() : dst;
       if (piped) {
         const int b = (int)(r & 1);
         h->Xcur = b ? h->X2.as<double2>() : h->X.as<double2>();
@@ -798,14 +820,15 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
       }
       if (inds) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
-                           ninds, so.as<double>() + r * ninds);
+                           ninds, dst);
         GSS_HIP(hipGetLastError());
       }
+      GSS_TRY(os.done(r, s));
       continue;
     }
     double* u = h->U.as<double>();
     if (noise) {
-      u = sn.as<double>() + r * N;  // the forward transform does not overwrite its input
+      u = const_cast<double*>(nz);  // the forward transform does not overwrite its input
     } else {
       ProfScope ps("fftgs_noise", s);
       GSS_TRY(philox_uniform_dev(seed, first_real + r, N, u, N, N, s));
@@ -820,18 +843,19 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
                          h->NH, h->mean);
       GSS_HIP(hipGetLastError());
     }
-    double* z = inds ? h->Z.as<double>() : so.as<double>() + r * N;
+    double* z = inds ? h->Z.as<double>() : dst;
     {
       ProfScope ps("fftgs_inv", s);
       GSS_TRY(fft_exec(h, h->inv, h->Xn.p, z, s));
     }
     if (inds) {
       hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, z, si.as<int64_t>(),
-                         ninds, so.as<double>() + r * ninds);
+                         ninds, dst);
       GSS_HIP(hipGetLastError());
     }
+    GSS_TRY(os.done(r, s));
   }
-  return so.back(out, sizeof(double) * (size_t)(nreals * npts), mem, s);
+  return os.finish(s);
 }
 
 }  // extern "C"

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <mutex>
+
 #include "gss.h"
 
 namespace gss {
@@ -36,6 +38,12 @@ void set_error(const char* fmt, ...);
       return GSS_ERR_INVALID;           \
     }                                   \
   } while (0)
+
+// Every exported function takes the library's lock for its whole duration (GSS_ENTRY, first statement): calls from
+// several host threads are serialised, so the stream chain (to_stream), the block cache and the process-wide work
+// buffers see one call at a time whichever handles and streams the threads use.  Recursive: exports call each other.
+std::recursive_mutex& api_mutex();
+#define GSS_ENTRY() std::lock_guard<std::recursive_mutex> gss_entry_lock__(::gss::api_mutex())
 
 // ---------------------------------------------------------------------------------------------
 // optional per-kernel timing with HIP events (gss_profile_*)
@@ -115,6 +123,43 @@ struct HostPipe {
   int32_t fetch(int64_t off, int64_t n, hipStream_t s);
   int32_t deliver(int64_t off, int64_t n, hipStream_t s);
   int32_t finish(hipStream_t s);
+};
+
+// Per-realisation outputs of the simulation calls (gss_fftgs_realize, gss_lugs_realize, gss_sgs_realize).  The
+// reference hands every realisation back as a host vector (fft.jl:173,197; lu.jl:217-221); with a host destination the
+// device therefore stages at most DEPTH chunks of realisations (a chunk: as many realisations as fit ~256 MiB, at least
+// one -- GSS_OUT_CHUNK_MB) in a ring, and chunk c crosses the bus on a copy stream of the process while chunk c + 1 is
+// computed on the caller's stream.  A pinned destination (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor)
+// is written by the DMA engine directly; a pageable one goes through two pinned bounce buffers of the process (pieces of
+// 32 MiB alternating over two copy streams, each followed in stream order by a host function that copies the piece to
+// its destination with a few threads: the transfer of piece p + 1 overlaps the host copy of piece p).  With a device
+// destination every method is a no-op around `dst + r * real_bytes`.  Usage: begin(); per realisation r (ascending):
+// slot(r) -> kernels on s -> done(r); finish().  The destructor joins the copy streams (error paths).
+struct OutStream {
+  static constexpr int DEPTH = 3;
+  bool on = false, issued = false;
+  char* dst = nullptr;          // destination (host when on, device otherwise)
+  size_t real_bytes = 0;
+  int64_t nreals = 0, chunk = 1;
+  bool pinned_dst = false;
+  DevBuf ring[DEPTH];
+  hipEvent_t ev_done[DEPTH] = {nullptr, nullptr, nullptr}, ev_free[DEPTH] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_join = nullptr;
+  hipStream_t cs[2] = {nullptr, nullptr};
+  int64_t piece_no = 0;
+  OutStream() = default;
+  OutStream(const OutStream&) = delete;
+  OutStream& operator=(const OutStream&) = delete;
+  ~OutStream();
+  // chunk_reals > 0 fixes the realisations per chunk (callers that compute block-wise and feed several outputs)
+  int32_t begin(void* dst_, size_t real_bytes_, int64_t nreals_, int32_t mem, hipStream_t s, int64_t chunk_reals = 0);
+  static int64_t default_chunk(size_t real_bytes_, int64_t nreals_);
+  // device address of realisation r's output; the first realisation of a chunk makes s wait until the slot's previous
+  // contents have left
+  int32_t slot(int64_t r, hipStream_t s, double** out);
+  int32_t done(int64_t r, hipStream_t s);   // realisation r has been queued on s
+  int32_t finish(hipStream_t s);            // host destination: returns when every byte has arrived
+  size_t staged_bytes() const;              // HBM held by the ring
 };
 
 // Every C-ABI entry converts its `stream` argument here.  Scratch memory (the DevBuf pool, the kriging workspace) is

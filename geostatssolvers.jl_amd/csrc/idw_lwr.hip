@@ -828,6 +828,7 @@ int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t
                         int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
                         double metric_param, double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
                         void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(exponent > 0.0, "exponent must be positive");  // idw.jl:96
   EstSpec sp;
   std::memset(&sp, 0, sizeof(sp));
@@ -843,6 +844,7 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
                         int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
                         double metric_param, int32_t weight_kind, double weight_a, double weight_p, double* mean,
                         double* var, uint8_t* status, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(weight_kind == GSS_WEIGHT_EXP || weight_kind == GSS_WEIGHT_TRICUBE, "unknown weight function %d",
               weight_kind);
   GSS_REQUIRE(weight_kind != GSS_WEIGHT_EXP || weight_p > 0.0, "weight exponent must be positive");

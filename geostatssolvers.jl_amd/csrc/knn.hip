@@ -732,6 +732,7 @@ using namespace gss;
 extern "C" int32_t gss_knn_search(const double* xdata, int64_t n, int32_t dim, const double* centers, int64_t m,
                                   int32_t k, double radius, const double* inv_radii, int32_t metric,
                                   double metric_param, int32_t* idx, int32_t* count, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(xdata && centers && idx, "gss_knn_search: NULL array");
   GSS_REQUIRE(k >= 1 && k <= n, "gss_knn_search: k = %d outside 1..n = %lld", k, (long long)n);
   GSS_TRY(check_metric(metric, metric_param, dim, radius, inv_radii));

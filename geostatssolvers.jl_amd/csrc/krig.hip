@@ -879,6 +879,7 @@ extern "C" {
 int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t variant, double sk_mean,
                         int32_t degree, int32_t ndrift, const double* xdata, const double* z,
                         const double* drift_data, int64_t n, int32_t flags, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(out != nullptr, "gss_krig_create: out is NULL");
   *out = nullptr;
   GSS_REQUIRE(xdata != nullptr && z != nullptr, "gss_krig_create: NULL data");
@@ -973,11 +974,13 @@ int32_t gss_krig_create(gss_krig_t** out, const gss_variogram_t* vg, int32_t var
 }
 
 int32_t gss_krig_destroy(gss_krig_t* h) {
+  GSS_ENTRY();
   delete h;
   return GSS_OK;
 }
 
 int32_t gss_krig_info(const gss_krig_t* h, int64_t* n, int32_t* nc) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   if (n) *n = h->n;
   if (nc) *nc = h->nc;
@@ -985,6 +988,7 @@ int32_t gss_krig_info(const gss_krig_t* h, int64_t* n, int32_t* nc) {
 }
 
 int32_t gss_krig_factor_buffer(gss_krig_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
   GSS_TRY(krig_fit_wait(h));   // (an asynchronous fit: the buffer is handed out complete)
   *dev_ptr = h->factor.p;
@@ -993,6 +997,7 @@ int32_t gss_krig_factor_buffer(gss_krig_t* h, void** dev_ptr, int64_t* bytes) {
 }
 
 int32_t gss_krig_adopt_factor(gss_krig_t* h) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   h->factored = true;
   return GSS_OK;
@@ -1000,6 +1005,7 @@ int32_t gss_krig_adopt_factor(gss_krig_t* h) {
 
 int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
                                 double* mean, double* var, uint8_t* status, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   GSS_REQUIRE(h->factored, "handle has no factor (created with GSS_KRIG_NO_FACTOR and never adopted one)");
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_global: NULL array");
@@ -1135,6 +1141,7 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
                              int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
                              double metric_param, double* mean, double* var, uint8_t* status, int32_t* idx_out,
                              int32_t* count_out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   GSS_TRY(check_metric(metric, metric_param, h->dim, radius, inv_radii));
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_knn: NULL array");
@@ -1188,6 +1195,7 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
 // one GEMM for the dual weights and one GEMM per chunk of domain points.
 int32_t gss_krig_predict_global_batch(gss_krig_t* h, const double* xdom, int64_t m, const double* zbatch,
                                       int64_t nbatch, double* mean_out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   GSS_REQUIRE(h->factored, "handle has no factor");
   GSS_REQUIRE(m >= 0 && nbatch >= 0, "negative sizes");

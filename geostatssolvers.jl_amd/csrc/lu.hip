@@ -198,6 +198,7 @@ using namespace gss;
 extern "C" {
 
 int32_t gss_dev_getrf_l(double* a, int64_t n, int64_t lda, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(a != nullptr && n >= 1 && lda >= n, "gss_dev_getrf_l: bad arguments");
   hipStream_t s = to_stream(stream);
   DevBuf info, ipiv;

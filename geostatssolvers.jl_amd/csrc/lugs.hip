@@ -276,6 +276,7 @@ extern "C" {
 int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const double* centroids, int64_t N,
                         const int64_t* dlocs, const double* z1, int64_t nd, double mean, int32_t flags,
                         void* stream) {
+  GSS_ENTRY();
   int32_t rc = lugs_create_impl(out, vg, centroids, N, dlocs, z1, nd, mean, flags, stream);
   // once more on the launch-per-block path (check_info has switched the single-launch kernel off for the process)
   if (rc == LUGS_RETRY) rc = lugs_create_impl(out, vg, centroids, N, dlocs, z1, nd, mean, flags, stream);
@@ -287,11 +288,13 @@ int32_t gss_lugs_create(gss_lugs_t** out, const gss_variogram_t* vg, const doubl
 }
 
 int32_t gss_lugs_destroy(gss_lugs_t* h) {
+  GSS_ENTRY();
   delete h;
   return GSS_OK;
 }
 
 int32_t gss_lugs_info(const gss_lugs_t* h, int64_t* ns, int64_t* nd) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   if (ns) *ns = h->ns;
   if (nd) *nd = h->nd;
@@ -299,6 +302,7 @@ int32_t gss_lugs_info(const gss_lugs_t* h, int64_t* ns, int64_t* nd) {
 }
 
 int32_t gss_lugs_factor(gss_lugs_t* h, double* l22, double* d2, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   hipStream_t s = to_stream(stream);
   const hipMemcpyKind kind = mem == GSS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -309,6 +313,7 @@ int32_t gss_lugs_factor(gss_lugs_t* h, double* l22, double* d2, int32_t mem, voi
 }
 
 int32_t gss_lugs_state_buffer(gss_lugs_t* h, void** dev_ptr, int64_t* bytes) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr && dev_ptr != nullptr && bytes != nullptr, "NULL argument");
   *dev_ptr = h->state.p;
   *bytes = (int64_t)(sizeof(double) * (size_t)(h->ns * h->ns + h->ns));
@@ -316,28 +321,20 @@ int32_t gss_lugs_state_buffer(gss_lugs_t* h, void** dev_ptr, int64_t* bytes) {
 }
 
 int32_t gss_lugs_adopt_state(gss_lugs_t* h) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   h->ready = true;
   return GSS_OK;
 }
 
-int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
-                         double rho, const double* w1, double* out, double* w_out, int32_t mem, void* stream) {
-  GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_lugs_realize: bad arguments");
-  GSS_REQUIRE(h->ready, "handle has no factor");
-  GSS_REQUIRE(w1 == nullptr || (rho >= -1.0 && rho <= 1.0), "correlation %g outside [-1, 1]", rho);
-  if (nreals == 0) return GSS_OK;
-  hipStream_t s = to_stream(stream);
-  const int64_t ns = h->ns, nd = h->nd, N = h->N, R = nreals;
-  Staged sn, sw1, so, swo;
-  GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(R * ns), mem, s));
-  GSS_TRY(sw1.in(w1, sizeof(double) * (size_t)(R * ns), mem, s));
-  GSS_TRY(so.out(out, sizeof(double) * (size_t)(R * N), mem));
-  GSS_TRY(swo.out(w_out, sizeof(double) * (size_t)(R * ns), mem));
+// Realisations first_real .. first_real + R - 1 with every array in HBM (lu.jl:198-224); asynchronous on s.
+static int32_t lugs_realize_block(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t R, const double* noise,
+                                  double rho, const double* w1, double* out, double* w_out, hipStream_t s) {
+  const int64_t ns = h->ns, nd = h->nd, N = h->N;
   DevBuf w2buf, wmix, Y2;
-  const double* w2 = sn.as<double>();
+  const double* w2 = noise;
   if (!noise) {                                                                                 // lu.jl:209
-    double* dst = swo.p ? swo.as<double>() : nullptr;
+    double* dst = w_out;
     if (!dst) {
       GSS_TRY(w2buf.alloc(sizeof(double) * (size_t)(R * ns)));
       dst = w2buf.as<double>();
@@ -348,13 +345,13 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
       GSS_HIP(hipGetLastError());
     }
     w2 = dst;
-  } else if (swo.p) {
-    GSS_HIP(hipMemcpyAsync(swo.p, w2, sizeof(double) * (size_t)(R * ns), hipMemcpyDeviceToDevice, s));
+  } else if (w_out) {
+    GSS_HIP(hipMemcpyAsync(w_out, w2, sizeof(double) * (size_t)(R * ns), hipMemcpyDeviceToDevice, s));
   }
   const double* weff = w2;
   if (w1 && ns) {                                                                               // lu.jl:213
     GSS_TRY(wmix.alloc(sizeof(double) * (size_t)(R * ns)));
-    hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((R * ns + 255) / 256)), dim3(256), 0, s, sw1.as<double>(), w2, rho,
+    hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((R * ns + 255) / 256)), dim3(256), 0, s, w1, w2, rho,
                        std::sqrt(1.0 - rho * rho), R * ns, wmix.as<double>());
     GSS_HIP(hipGetLastError());
     weff = wmix.as<double>();
@@ -410,11 +407,50 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
   const double add = nd == 0 ? h->mean : 0.0;                                                   // lu.jl:221
   hipLaunchKernelGGL(lugs_scatter_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)R), dim3(256), 0, s,
                      Y2.as<double>(), h->d2(), h->slocs.as<int64_t>(), ns, h->z1.as<double>(),
-                     h->dlocs.as<int64_t>(), nd, add, N, so.as<double>());
+                     h->dlocs.as<int64_t>(), nd, add, N, out);
   GSS_HIP(hipGetLastError());
-  GSS_TRY(so.back(out, sizeof(double) * (size_t)(R * N), mem, s));
-  GSS_TRY(swo.back(w_out, sizeof(double) * (size_t)(R * ns), mem, s));
-  GSS_HIP(hipStreamSynchronize(s));  // scratch buffers are freed on return
+  return GSS_OK;
+}
+
+int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                         double rho, const double* w1, double* out, double* w_out, int32_t mem, void* stream) {
+  GSS_ENTRY();
+  GSS_REQUIRE(h != nullptr && out != nullptr && nreals >= 0 && first_real >= 0, "gss_lugs_realize: bad arguments");
+  GSS_REQUIRE(h->ready, "handle has no factor");
+  GSS_REQUIRE(w1 == nullptr || (rho >= -1.0 && rho <= 1.0), "correlation %g outside [-1, 1]", rho);
+  if (nreals == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  const int64_t ns = h->ns, N = h->N;
+  if (mem == GSS_MEM_DEVICE) {
+    GSS_TRY(lugs_realize_block(h, seed, first_real, nreals, noise, rho, w1, out, w_out, s));
+    GSS_HIP(hipStreamSynchronize(s));  // scratch buffers are freed on return
+    return GSS_OK;
+  }
+  // Host arrays (lu.jl:217-221 returns host vectors): blocks of realisations that fit one chunk of the output ring;
+  // block b's results (and normals) cross the bus while block b + 1 is computed, and HBM holds at most three blocks.
+  const int64_t rb = OutStream::default_chunk(sizeof(double) * (size_t)N, nreals);
+  OutStream os, osw;
+  GSS_TRY(os.begin(out, sizeof(double) * (size_t)N, nreals, mem, s, rb));
+  GSS_TRY(osw.begin(w_out, sizeof(double) * (size_t)ns, nreals, mem, s, rb));
+  DevBuf nbuf, w1buf;
+  if (noise) GSS_TRY(nbuf.alloc(sizeof(double) * (size_t)(rb * ns)));
+  if (w1) GSS_TRY(w1buf.alloc(sizeof(double) * (size_t)(rb * ns)));
+  for (int64_t r0 = 0; r0 < nreals; r0 += rb) {
+    const int64_t n = nreals - r0 < rb ? nreals - r0 : rb;
+    if (noise && ns)
+      GSS_HIP(hipMemcpyAsync(nbuf.p, noise + r0 * ns, sizeof(double) * (size_t)(n * ns), hipMemcpyHostToDevice, s));
+    if (w1 && ns)
+      GSS_HIP(hipMemcpyAsync(w1buf.p, w1 + r0 * ns, sizeof(double) * (size_t)(n * ns), hipMemcpyHostToDevice, s));
+    double *dout = nullptr, *dw = nullptr;
+    GSS_TRY(os.slot(r0, s, &dout));
+    if (w_out) GSS_TRY(osw.slot(r0, s, &dw));
+    GSS_TRY(lugs_realize_block(h, seed, first_real + r0, n, noise ? nbuf.as<double>() : nullptr, rho,
+                               w1 ? w1buf.as<double>() : nullptr, dout, dw, s));
+    GSS_TRY(os.done(r0 + n - 1, s));
+    GSS_TRY(osw.done(r0 + n - 1, s));
+  }
+  GSS_TRY(os.finish(s));
+  GSS_TRY(osw.finish(s));
   return GSS_OK;
 }
 

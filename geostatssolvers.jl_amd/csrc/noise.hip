@@ -49,6 +49,7 @@ using namespace gss;
 extern "C" {
 
 int32_t gss_philox_uniform(uint64_t seed, int64_t real, int64_t n, double* out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(out != nullptr && n >= 0, "gss_philox_uniform: bad arguments");
   hipStream_t s = to_stream(stream);
   Staged so;
@@ -58,6 +59,7 @@ int32_t gss_philox_uniform(uint64_t seed, int64_t real, int64_t n, double* out, 
 }
 
 int32_t gss_philox_normal(uint64_t seed, int64_t real, int64_t n, double* out, int32_t mem, void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(out != nullptr && n >= 0, "gss_philox_normal: bad arguments");
   hipStream_t s = to_stream(stream);
   Staged so;

@@ -745,6 +745,7 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
                              const int64_t* dlocs, const double* zdata, int64_t nd, int32_t maxneighbors,
                              int32_t minneighbors, double radius, const double* inv_radii, int32_t flags,
                              void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(out != nullptr, "gss_sgs_create: out is NULL");
   GSS_REQUIRE(npaths >= 1 && path_base >= 0 && (npaths == 1 || path != nullptr), "gss_sgs_create_paths: bad path set");
   *out = nullptr;
@@ -911,17 +912,20 @@ int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, 
                        int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,
                        int32_t maxneighbors, int32_t minneighbors, double radius, const double* inv_radii,
                        int32_t flags, void* stream) {
+  GSS_ENTRY();
   return gss_sgs_create_paths(out, vg, mean, centroids, N, dim, path, 1, 0, dlocs, zdata, nd, maxneighbors, minneighbors,
                               radius, inv_radii, flags, stream);
 }
 
 int32_t gss_sgs_destroy(gss_sgs_t* h) {
+  GSS_ENTRY();
   delete h;
   return GSS_OK;
 }
 
 int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, double* sigma, int32_t mem,
                         void* stream) {
+  GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
   hipStream_t s = to_stream(stream);
   const hipMemcpyKind kind = mem == GSS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -935,29 +939,22 @@ int32_t gss_sgs_weights(gss_sgs_t* h, int32_t* idx, int32_t* ncond, double* w, d
   return GSS_OK;
 }
 
-int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
-                        double* out, int32_t mem, void* stream) {
-  GSS_REQUIRE(h != nullptr, "NULL handle");
-  GSS_REQUIRE(nreals >= 0 && first_real >= 0 && nreals < INT_MAX, "bad realisation range");
-  if (nreals == 0) return GSS_OK;
-  GSS_REQUIRE(out != nullptr, "gss_sgs_realize: out is NULL");
-  hipStream_t s = to_stream(stream);
+// Realisations first_real .. first_real + nreals - 1 with every array in HBM; asynchronous on s.
+static int32_t sgs_realize_block(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                                 double* out, hipStream_t s) {
   const int64_t N = h->N;
   const int R = (int)nreals;
-  Staged sn, so;
-  if (noise) GSS_TRY(sn.in(noise, sizeof(double) * (size_t)(N * R), mem, s));
-  GSS_TRY(so.out(out, sizeof(double) * (size_t)(N * R), mem));
   if (h->npaths > 1) {
     // one visiting order per realisation: realisation first_real + i walks path first_real + i - path_base
     const int64_t p0 = first_real - h->path_base;
     GSS_REQUIRE(p0 >= 0 && p0 + nreals <= h->npaths, "realisations %lld..%lld have no visiting order in this handle "
                 "(paths cover %lld..%lld)", (long long)first_real, (long long)(first_real + nreals - 1),
                 (long long)h->path_base, (long long)(h->path_base + h->npaths - 1));
-    double* zr = so.as<double>();   // realisation-major working field = the output itself
+    double* zr = out;   // realisation-major working field = the output itself
     {
       ProfScope ps("sgs_noise", s);
       hipLaunchKernelGGL(sgs_noise_rows_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real,
-                         N, R, noise ? sn.as<double>() : nullptr, zr);
+                         N, R, noise ? noise : nullptr, zr);
       GSS_HIP(hipGetLastError());
     }
     if (h->nd > 0) {
@@ -983,8 +980,6 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
                          h->sigma.as<double>(), h->k, N, R, p0, h->mean, zr);
       GSS_HIP(hipGetLastError());
     }
-    GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
-    GSS_HIP(hipStreamSynchronize(s));
     return GSS_OK;
   }
   // the working field is GBs (8 N R bytes): allocating and freeing it on every call costs more than a short sweep
@@ -996,7 +991,7 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
   {
     ProfScope ps("sgs_noise", s);
     hipLaunchKernelGGL(sgs_noise_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real, N, R,
-                       noise ? sn.as<double>() : nullptr, zt.as<double>());
+                       noise ? noise : nullptr, zt.as<double>());
     GSS_HIP(hipGetLastError());
   }
   if (h->nd > 0) {
@@ -1030,11 +1025,50 @@ int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t
     GSS_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(sgs_transpose_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, s,
-                     zt.as<double>(), N, R, so.as<double>());
+                     zt.as<double>(), N, R, out);
   GSS_HIP(hipGetLastError());
-  GSS_TRY(so.back(out, sizeof(double) * (size_t)(N * R), mem, s));
-  GSS_HIP(hipStreamSynchronize(s));
   return GSS_OK;
+}
+
+int32_t gss_sgs_realize(gss_sgs_t* h, uint64_t seed, int64_t first_real, int64_t nreals, const double* noise,
+                        double* out, int32_t mem, void* stream) {
+  GSS_ENTRY();
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  GSS_REQUIRE(nreals >= 0 && first_real >= 0 && nreals < INT_MAX, "bad realisation range");
+  if (nreals == 0) return GSS_OK;
+  GSS_REQUIRE(out != nullptr, "gss_sgs_realize: out is NULL");
+  hipStream_t s = to_stream(stream);
+  const int64_t N = h->N;
+  if (h->npaths > 1) {
+    const int64_t p0 = first_real - h->path_base;
+    GSS_REQUIRE(p0 >= 0 && p0 + nreals <= h->npaths, "realisations %lld..%lld have no visiting order in this handle "
+                "(paths cover %lld..%lld)", (long long)first_real, (long long)(first_real + nreals - 1),
+                (long long)h->path_base, (long long)(h->path_base + h->npaths - 1));
+  }
+  if (mem == GSS_MEM_DEVICE) {
+    GSS_TRY(sgs_realize_block(h, seed, first_real, nreals, noise, out, s));
+    GSS_HIP(hipStreamSynchronize(s));
+    return GSS_OK;
+  }
+  // Host arrays (seq.jl:137-141 returns host vectors): blocks of realisations -- whole groups of 64 lanes for a shared
+  // visiting order -- through the output ring; block b crosses the bus while block b + 1 is swept.
+  int64_t rb = OutStream::default_chunk(sizeof(double) * (size_t)N, nreals);
+  if (h->npaths <= 1 && rb < nreals) rb = rb < 64 ? 64 : rb / 64 * 64;
+  if (rb > nreals) rb = nreals;
+  OutStream os;
+  GSS_TRY(os.begin(out, sizeof(double) * (size_t)N, nreals, mem, s, rb));
+  DevBuf nbuf;
+  if (noise) GSS_TRY(nbuf.alloc(sizeof(double) * (size_t)(rb * N)));
+  for (int64_t r0 = 0; r0 < nreals; r0 += rb) {
+    const int64_t n = nreals - r0 < rb ? nreals - r0 : rb;
+    if (noise)
+      GSS_HIP(hipMemcpyAsync(nbuf.p, noise + r0 * N, sizeof(double) * (size_t)(n * N), hipMemcpyHostToDevice, s));
+    double* dout = nullptr;
+    GSS_TRY(os.slot(r0, s, &dout));
+    GSS_TRY(sgs_realize_block(h, seed, first_real + r0, n, noise ? nbuf.as<double>() : nullptr, dout, s));
+    GSS_TRY(os.done(r0 + n - 1, s));
+  }
+  return os.finish(s);
 }
 
 }  // extern "C"

@@ -61,6 +61,8 @@ SIGNATURES = {
     "gss_shutdown": [],
     "gss_last_error": [C.c_char_p, _i32],
     "gss_synchronize": [_p],
+    "gss_trim_pool": [],
+    "gss_stat": [C.c_char_p, C.POINTER(_i64)],
     "gss_profile_enable": [_i32],
     "gss_profile_reset": [],
     "gss_profile_read": [C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)],
@@ -229,6 +231,18 @@ def metric_spec(distance):
     if name == "haversine" and not par > 0.0:
         raise ValueError("('haversine', radius) needs a positive radius")
     return METRICS[name], par
+
+
+def stat(name: str) -> int:
+    """A library counter: "pool_bytes", "out_ring_bytes", "out_chunks" (gss.h, gss_stat)."""
+    v = C.c_int64()
+    check(load().gss_stat(name.encode(), C.byref(v)))
+    return v.value
+
+
+def trim_pool():
+    """Give the library's cached device blocks back to the driver (gss.h, gss_trim_pool)."""
+    check(load().gss_trim_pool())
 
 
 def profile_enable(on: bool = True):

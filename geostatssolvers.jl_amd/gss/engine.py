@@ -49,7 +49,8 @@ def _extent(x):
 
 
 def _space(x):
-    return MEM_DEVICE if is_torch(x) else MEM_HOST
+    """MEM_DEVICE for CUDA tensors; numpy arrays and CPU tensors (pinned ones included) are host memory."""
+    return MEM_DEVICE if is_torch(x) and x.is_cuda else MEM_HOST
 
 
 def _empty_like_space(ref, shape, dtype):
@@ -212,14 +213,21 @@ class FFTGSHandle:
         check(self._l.gss_fftgs_spectrum(self._h, ptr(out), MEM_HOST, current_stream()))
         return out
 
-    def realize(self, seed, first_real, nreals, noise=None, inds=None, out=None, device=False):
-        """nreals x npts realisations; `device=True` (or a CUDA `out`/`noise`) keeps them in HBM."""
+    def realize(self, seed, first_real, nreals, noise=None, inds=None, out=None, device=False, pinned=False):
+        """nreals x npts realisations; `device=True` (or a CUDA `out`/`noise`) keeps them in HBM.  Host results leave
+        the device chunk by chunk while the next realisations are computed (at most three chunks of ~256 MiB staged in
+        HBM, csrc OutStream); `pinned=True` returns a numpy view of page-locked memory, which the DMA engine writes
+        directly (a pageable array goes through the library's pinned bounce buffers); `out` may be a numpy array or a
+        CPU / pinned / CUDA tensor of shape (nreals, npts)."""
         noise = _prep_in(noise)
         npts = self.N if inds is None else len(inds)
         if out is None:
-            if device or is_torch(noise):
+            if device or (is_torch(noise) and noise.is_cuda):
                 import torch
                 out = torch.empty((nreals, npts), dtype=torch.float64, device="cuda")
+            elif pinned:
+                import torch
+                out = torch.empty((nreals, npts), dtype=torch.float64, pin_memory=True)
             else:
                 out = np.empty((nreals, npts))
         mem = _space(out)
@@ -234,7 +242,7 @@ class FFTGSHandle:
                 ii = np.ascontiguousarray(inds, dtype=np.int64)
         check(self._l.gss_fftgs_realize(self._h, int(seed), int(first_real), int(nreals), ptr(noise), ptr(ii),
                                         0 if inds is None else npts, ptr(out), mem, current_stream()))
-        return out
+        return out.numpy() if pinned and is_torch(out) and not out.is_cuda else out
 
 
 class LUGSHandle:

@@ -27,8 +27,18 @@
  *     with GSS_KRIG_ASYNC_FIT: the fit).  The process has five such streams, created together at the first use.
  *     Those streams are fenced by events on both sides: everything such a call does starts
  *     after what `stream` held at the call and is complete, in stream order, before whatever is put on `stream` next.
- *   - handles are opaque, owned by the library, not thread-safe; the caller owns every buffer it
- *     passes and the library never returns memory it allocated.
+ *   - host threads: every export takes one process-wide lock for its whole duration, so calls from several host
+ *     threads (Julia `Threads.@threads` over variables, finalizers on the GC thread) are SAFE and run one after
+ *     another -- whichever handles and streams they use; the stream chain above then orders their device work.  What
+ *     is NOT provided is concurrency: a call with host arrays holds the lock until its last byte has arrived.  A
+ *     handle may be used from any thread, by one call at a time (which the lock guarantees).  `gss_last_error` is
+ *     per thread.
+ *   - host results of the simulation calls (gss_fftgs_realize, gss_lugs_realize, gss_sgs_realize with GSS_MEM_HOST)
+ *     leave the device in chunks of ~256 MiB while the following realisations are computed; at most three chunks are
+ *     staged in HBM whatever `nreals` is.  A page-locked destination (hipHostMalloc / hipHostRegister) is written by
+ *     the DMA engine directly; a pageable one goes through pinned bounce buffers of the library.
+ *   - handles are opaque and owned by the library; the caller owns every buffer it passes and the library never
+ *     returns memory it allocated.
  */
 #ifndef GSS_H
 #define GSS_H
@@ -114,6 +124,13 @@ int32_t gss_init(int32_t device);          /* bind the calling process to `devic
 int32_t gss_shutdown(void);
 int32_t gss_last_error(char* buf, int32_t len);
 int32_t gss_synchronize(void* stream);
+/* Released device blocks are cached for re-use (up to GSS_POOL_MAX_MB, default a quarter of the device memory that
+ * was free at the first allocation, at most 16 GiB); gss_trim_pool gives them all back to the driver -- for a host
+ * program whose own allocator (torch, RCCL, rocFFT) has just failed.  Synchronises the device. */
+int32_t gss_trim_pool(void);
+/* Counters for tests and diagnostics: "pool_bytes" (device bytes in the block cache), "out_ring_bytes" (HBM staged for
+ * the host outputs of the last simulation call), "out_chunks" (chunks that call moved). */
+int32_t gss_stat(const char* name, int64_t* value);
 
 /* ---- kernel timing (bench.py's roofline leg): when enabled every launch of a named hot kernel is
  *      bracketed by HIP events on the stream it is launched on; gss_profile_read synchronises

@@ -91,7 +91,30 @@ def test_product_library_host_side_under_asan_ubsan():
             assert lib.gss_lugs_create(C.byref(h), C.byref(v), P(cent), 30, P(d), P(z1), 2, 0.0, 0, None) != 0
             x = np.random.default_rng(0).uniform(size=(50, 2)); z = np.zeros(50)
             assert lib.gss_krig_create(C.byref(h), C.byref(v), 1, 0.0, 0, 0, P(x), P(z), None, 50, 0, None) != 0
-        lib.gss_profile_reset(); lib.gss_shutdown()
+        # two host threads at once (ctypes releases the GIL inside the calls): every export serialises on the library's
+        # lock (gss.h, host threads), the error text is per thread, the counters and the profile registry stay coherent
+        import threading
+        bad = []
+        def hammer(tid):
+            hh = C.c_void_p(); val = C.c_int64(); ms = C.c_double(); nl = C.c_int64()
+            vb = _lib.make_variogram("matern", 2, nu=80.0 + tid)
+            xx = np.zeros((4, 2)); zz = np.zeros(4)
+            for it in range(300):
+                if lib.gss_krig_create(C.byref(hh), C.byref(vb), 1, 0.0, 0, 0, P(xx), P(zz), None, 4, 0, None) != 1:
+                    bad.append("status")
+                if f"nu={80 + tid}" not in err():
+                    bad.append(err())
+                if lib.gss_stat(b"pool_bytes", C.byref(val)) != 0 or val.value != 0:
+                    bad.append("stat")
+                lib.gss_profile_enable(it & 1); lib.gss_profile_read(b"krig_rhs", C.byref(ms), C.byref(nl))
+                if it % 50 == 0:
+                    lib.gss_profile_reset()
+                if not have_gpu and lib.gss_trim_pool() == 0:
+                    bad.append("trim without a device")
+        ts = [threading.Thread(target=hammer, args=(t,)) for t in range(2)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not bad, bad[:3]
+        lib.gss_profile_enable(0); lib.gss_profile_reset(); lib.gss_shutdown()
         print("asan-ok")
     """
     try:
