@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 1h,2,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
+    python bench_configs.py [--configs 1h,2,2h,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
 """
 import argparse
 import json
@@ -330,6 +330,47 @@ def cfg1_host(a, gss, _lib):
             "bytes_over_pcie_per_point": 24 + 17, "finite": bool(np.isfinite(mu).all())}
 
 
+def cfg2_host(a, gss, _lib):
+    """configs[2] with the realisations delivered to host memory (the second number; the reference returns
+    host vectors, fft.jl:173,197): one gss_fftgs_realize call for `--host-reals` realisations of 512^3 cells into a
+    page-locked and into a pageable destination.  The library stages three chunks (3 GiB) whatever the count."""
+    from gss.engine import FFTGSHandle
+    e = 256 if a.quick else 512
+    R = a.host_reals
+    N = e ** 3
+    f = FFTGSHandle(gss.ExponentialVariogram(range=50.0 * e / 512), (e, e, e))
+    dev = torch.empty((2, N), dtype=torch.float64, device="cuda")
+    f.realize(4, 0, 2, out=dev)
+    sync()
+    host = torch.empty((R, N), dtype=torch.float64, pin_memory=True)
+    host.zero_()
+    t0 = time.perf_counter()
+    host[:2].copy_(dev, non_blocking=True)
+    sync()
+    copy_gbs = 2 * N * 8 / (time.perf_counter() - t0) / 1e9
+    f.realize(4, 0, 1, out=host[:1])
+    t0 = time.perf_counter()
+    f.realize(4, 0, R, out=host)
+    dt = time.perf_counter() - t0
+    ring, chunks = _lib.stat("out_ring_bytes"), _lib.stat("out_chunks")
+    same = bool(torch.equal(host[1].cuda(), dev[1])) and bool(torch.equal(host[R - 1].cuda(), f.realize(4, R - 1, 1, out=dev[:1])[0]))
+    Rp = min(R, 4)
+    pg = np.empty((Rp, N))
+    pg.fill(0.0)
+    t0 = time.perf_counter()
+    f.realize(4, 0, Rp, out=pg)
+    dtp = time.perf_counter() - t0
+    samep = bool(np.array_equal(pg[1], host[1].numpy()))
+    f.close()
+    return {"config": "configs[2] FFTGS %d^3, %d realisations in ONE call, results in host memory" % (e, R),
+            "metric": "FFTGS realisations/s including D2H", "value": round(R / dt, 2), "unit": "realisations/s",
+            "achieved_GBs": round(R * N * 8 / dt / 1e9, 2), "pcie_copy_rate_GBs": round(copy_gbs, 2),
+            "frac_of_copy_rate": round(R * N * 8 / dt / 1e9 / copy_gbs, 3), "hbm_staged_bytes": ring, "chunks": chunks,
+            "bit_identical_to_device_path": same,
+            "pageable": {"realisations": Rp, "value": round(Rp / dtp, 2), "GBs": round(Rp * N * 8 / dtp / 1e9, 2),
+                         "bit_identical": samep}}
+
+
 def cfg_cond_fftgs(a, gss, _lib):
     """Section 8f.1 row: conditional FFTGS through the solver API (fft.jl:106-135,176-192): e^3 grid, exponential
     range 20, 1 000 conditioning points, global kriging of the data and of every unconditional realisation."""
@@ -361,11 +402,12 @@ def main():
     ap.add_argument("--configs", default="2,3,4")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--sgs-reals", type=int, default=1024, help="realisations of the SGS row (multiple of 64)")
+    ap.add_argument("--host-reals", type=int, default=24, help="realisations of the 2h row (1 GiB of host memory each)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -488,7 +488,7 @@ function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
         dinds = unique(found)                                            # fft.jl:132
       end
     end
-    preproc[var] = (γ=γ, μ=μ, handle=handle, z̄=z̄, krig=krig, dinds=dinds)
+    preproc[var] = (γ=γ, μ=μ, handle=handle, z̄=z̄, krig=krig, dinds=dinds, maxneighbors=p.maxneighbors)
   end
   preproc[:_run] = RunState(problem, solver)
   preproc
@@ -508,6 +508,35 @@ function fftgs_block(problem, preproc, var, first::Int, count::Int)
     C_NULL))
   isnothing(par.krig) && return out
   # conditioning, fft.jl:176-192: krige the unconditional values at the data cells, add the residual field
+  if isnothing(par.maxneighbors)
+    # global neighbourhood: the kriging system of fft.jl:187 has the same locations (the data cells' centroids) for
+    # every realisation -- ONE factorisation, the realisations' values at the data cells as a batch of right-hand
+    # sides (means only: gss_krig_predict_global_batch), instead of a solve(EstimationProblem...) per realisation
+    X0 = coordmatrix(pdomain)
+    d, m = size(X0)
+    Xd = X0[:, par.dinds]
+    nd = length(par.dinds)
+    Zb = out[par.dinds, :]                                              # nd x count == count x nd row-major
+    Z̄ᵤ = Matrix{Float64}(undef, m, count)
+    vg = Ref(cvariogram(par.γ, d))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    z0 = Zb[:, 1]
+    GC.@preserve X0 Xd Zb Z̄ᵤ z0 begin
+      check(ccall((:gss_krig_create, libgss), Int32,
+                  (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Int32, Float64, Int32, Int32, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Int64, Int32, Ptr{Cvoid}),
+                  h, vg, Int32(0), Float64(par.μ), Int32(0), Int32(0), Xd, z0, C_NULL, nd, Int32(0), C_NULL))
+      try
+        check(ccall((:gss_krig_predict_global_batch, libgss), Int32,
+                    (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}),
+                    h[], X0, m, Zb, count, Z̄ᵤ, GSS_MEM_HOST, C_NULL))
+      finally
+        ccall((:gss_krig_destroy, libgss), Int32, (Ptr{Cvoid},), h[])
+      end
+    end
+    out .= par.z̄ .+ (out .- Z̄ᵤ)                                         # fft.jl:191
+    return out
+  end
   kdom = PointSet(centroid.(pdomain))
   ddomain = view(pdomain, par.dinds)
   for r in 1:count
