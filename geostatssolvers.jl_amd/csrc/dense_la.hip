@@ -367,62 +367,12 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// In-place Cholesky of the lower triangle of A (n <= 64) and, when dinv != nullptr, inv(L) into dinv
-// (64 x 64 column-major, ld = 64, zero padded).  One wave, everything in registers: lane i owns row i of the
-// block (64 doubles), other rows' entries arrive by v_readlane broadcasts, the loops are fully unrolled so all
-// register indices are static.  A block with n < 64 is embedded in diag(A, I), whose factor and inverse are
-// diag(L, I) and diag(inv(L), I).
-__global__ __launch_bounds__(64) void potrf_inv_leaf_kernel(double* __restrict__ A, int n, int64_t lda,
-                                                            int row_offset, int* __restrict__ info,
-                                                            double* __restrict__ dinv) {
-  const int lane = threadIdx.x;
-  double row[LEAF];
-#pragma unroll
-  for (int c = 0; c < LEAF; ++c) {
-    double v = (c == lane) ? 1.0 : 0.0;
-    if (lane < n && c <= lane) v = A[lane + (int64_t)c * lda];
-    row[c] = v;
-  }
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < LEAF; ++j) {
-    double acc = row[j];
-#pragma unroll
-    for (int c = 0; c < j; ++c) acc = fma(-row[c], bcast_lane(row[c], j), acc);
-    double d = bcast_lane(acc, j);
-    if (!(d > 0.0)) {
-      if (bad == 0) bad = row_offset + j + 1;
-      d = 1.0;
-    }
-    const double sq = sqrt(d);
-    row[j] = (lane == j) ? sq : acc / sq;  // lanes < j hold don't-care values in the upper triangle
-    __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later columns from being hoisted (SGPR pressure)
-  }
-  if (bad != 0 && lane == 0 && *info == 0) *info = bad;
-#pragma unroll
-  for (int c = 0; c < LEAF; ++c)
-    if (lane < n && c <= lane) A[lane + (int64_t)c * lda] = row[c];
-  if (!dinv) return;
-  // inverse: lane c owns column c of W = inv(L); x[i] = W(i, c)
-  double x[LEAF];
-#pragma unroll
-  for (int i = 0; i < LEAF; ++i) {
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) acc = fma(bcast_lane(row[k], i), x[k], acc);  // x[k] = 0 for k < lane
-    const double dii = bcast_lane(row[i], i);
-    x[i] = (i == lane) ? 1.0 / dii : (i > lane ? -acc / dii : 0.0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int i = 0; i < LEAF; ++i) dinv[i + lane * LEAF] = (i < n && lane < n) ? x[i] : 0.0;
-}
 
 // The same leaf on MFMA tiles (default).  The block, embedded in diag(A, I) when n < 64, is held by one wave as the
 // upper block triangle of 16 x 16 tiles and factorised as A = U'U exactly like the moving-neighbourhood systems
 // (tile16.h): diagonal tiles through potrf16_full, U_kj = V_k' A_kj, A_ij -= U_ki' U_kj.  L = U' goes back to A;
 // W = inv(L) follows from  W_II = V_I',  W_JI = -V_J' sum_{K=I..J-1} U_KJ' W_KI  (J > I) -- again only X'Y products.
-// 22 us instead of 51 us for the register/readlane leaf above (kept for A/B: GSS_LEAF_VARIANT=0).
+// 22 us instead of 51 us for the register/readlane leaf of round 1.
 __global__ __launch_bounds__(64) void potrf_inv_leaf_tile_kernel(double* __restrict__ A, int n, int64_t lda,
                                                                  int row_offset, int* __restrict__ info,
                                                                  double* __restrict__ dinv, int64_t ldd, int full64) {
@@ -1127,16 +1077,8 @@ static int32_t potrf_rec(double* A, int64_t n, int64_t lda, int64_t row_offset, 
                          hipStream_t s) {
   if (n <= 0) return GSS_OK;
   if (n <= LEAF) {
-    static int leaf_variant = -1;
-    if (leaf_variant < 0) {
-      const char* e = std::getenv("GSS_LEAF_VARIANT");
-      leaf_variant = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (leaf_variant == 1)
-      hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info,
-                         dinv, (int64_t)LEAF, 1);
-    else
-      hipLaunchKernelGGL(potrf_inv_leaf_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info, dinv);
+    hipLaunchKernelGGL(potrf_inv_leaf_tile_kernel, dim3(1), dim3(64), 0, s, A, (int)n, lda, (int)row_offset, d_info,
+                       dinv, (int64_t)LEAF, 1);
     GSS_HIP(hipGetLastError());
     return GSS_OK;
   }
@@ -1312,11 +1254,7 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
     GSS_HIP(hipGetLastError());
     return GSS_OK;
   }
-  static const bool leaf128 = [] {
-    const char* e = std::getenv("GSS_LEAF128");
-    return !(e && e[0] == '0');
-  }();
-  if (n <= 2 * LEAF && leaf128) {
+  if (n <= 2 * LEAF) {
     static bool attr = false;
     if (!attr) {
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_leaf128_kernel<8>),

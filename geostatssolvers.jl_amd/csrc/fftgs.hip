@@ -182,11 +182,8 @@ struct gss_fftgs {
   hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p5[2] = {nullptr, nullptr}, ev_in = nullptr;
   int overlap = 1;
   DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
-  int x_gen = 2;                // x passes: 2 = Stockham kernels (ff_x_fwd2 / ff_x_inv2), 1 = first generation
-  int x_rows = 8;               // x lines per workgroup of generation 2 (rows * M / 8 <= 256)
-  int axis_fast = 1;            // 512-point lines: the pass-by-pass kernel with all loads issued up front
-  int axis_gen = 2;             // strided passes: 2 = ff_axis2_kernel (register-direct first / last pass), 1 = ff_axis_kernel
-  int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes of generation 2
+  int x_rows = 8;               // x lines per workgroup of the Stockham x passes (rows * M / 8 <= 256)
+  int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes
   // slab order of the strided passes: slab i runs on stream i mod ns (0 = the caller's, the others are helper streams
   // of the process, slab_stream()); the events that fence them belong to the handle
   static constexpr int SLAB_MAX_STREAMS = 4;
@@ -292,7 +289,6 @@ static int32_t upload_twiddles(DevBuf& buf, int L, hipStream_t s) {
   return GSS_OK;
 }
 
-static size_t ff_axis_lds(int L) { return sizeof(double2) * (size_t)(L / 2 + FF_TX * lds_line_pitch(L)); }
 static size_t ff_xfwd2_lds(int M, int logM, int rows) { return sizeof(double2) * (size_t)(M + x_table_len(logM) + rows * M); }
 static size_t ff_xinv2_lds(int M, int logM, int rows) { return sizeof(double2) * (size_t)(x_table_len(logM) + rows * M); }
 
@@ -346,32 +342,22 @@ static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s, int slab_
   double2* X = h->Xcur;
   const double* fh = MODE == 2 ? h->Fh_tiled.as<double>() : nullptr;
   const double mean = MODE == 2 ? h->mean : 0.0;
-  if (h->axis_gen == 1) {
-    hipLaunchKernelGGL(ff_axis_kernel<MODE>, dim3((unsigned)(nouter * f.ntx)), dim3(FF_THREADS), ff_axis_lds(L), s, f, logL,
-                       tw, ostride, lstride, X, fh, mean);
-  } else {
-    const int txlog = axis == 1 ? h->txy_log : h->txz_log;
-    const unsigned blocks = (unsigned)(nouter * (slab_nt > 0 ? slab_nt : (f.nhp >> txlog)));
-    const size_t lds = ff_axis2_lds(L, txlog);
-    if (slab_nt > 0 && !(txlog == 3 && logL == 9 && h->axis_fast)) return GSS_ERR_UNSUPPORTED;
-    if (txlog == 3 && logL == 9 && h->axis_fast)
-      hipLaunchKernelGGL((ff_axis2_fast_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, tw, ostride, lstride,
-                         X, fh, mean);
-    else if (txlog == 3 && logL == 9)
-      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride,
-                         X, fh, mean);
-    else if (txlog == 3)
-      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512, -1>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride,
-                         X, fh, mean);
-    else
-      hipLaunchKernelGGL((ff_axis2_kernel<MODE, 2, 256, -1>), dim3(blocks), dim3(256), lds, s, f, logL, tw, ostride, lstride,
-                         X, fh, mean);
-  }
+  const int txlog = axis == 1 ? h->txy_log : h->txz_log;
+  const unsigned blocks = (unsigned)(nouter * (slab_nt > 0 ? slab_nt : (f.nhp >> txlog)));
+  const size_t lds = ff_axis2_lds(L, txlog);
+  if (slab_nt > 0 && !(txlog == 3 && logL == 9)) return GSS_ERR_UNSUPPORTED;
+  if (txlog == 3 && logL == 9)      // 512-point lines: the pass-by-pass kernel with every load issued up front
+    hipLaunchKernelGGL((ff_axis2_fast_kernel<MODE, 3, 512, 9>), dim3(blocks), dim3(512), lds, s, f, tw, ostride, lstride,
+                       X, fh, mean);
+  else if (txlog == 3)
+    hipLaunchKernelGGL((ff_axis2_kernel<MODE, 3, 512, -1>), dim3(blocks), dim3(512), lds, s, f, logL, tw, ostride, lstride,
+                       X, fh, mean);
+  else
+    hipLaunchKernelGGL((ff_axis2_kernel<MODE, 2, 256, -1>), dim3(blocks), dim3(256), lds, s, f, logL, tw, ostride, lstride,
+                       X, fh, mean);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
-static size_t ff_xfwd_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * lds_line_pitch(M)); }
-static size_t ff_xinv_lds(int M) { return sizeof(double2) * (size_t)(M + FF_ROWS * (M + 1) + FF_ROWS * lds_line_pitch(M)); }
 
 // The fused five-pass pipeline serves 3-D grids whose sizes are powers of two (32..1024 along x, 16..1024 along
 // y and z); everything else, and GSS_FFTGS_PATH=rocfft, stays on the rocFFT pipeline.
@@ -396,16 +382,7 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)nt));
   const int M = f.n1 / 2;
   const int lmax = f.n2 > f.n3 ? f.n2 : f.n3;
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_PHILOX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_ARRAY>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_fwd_kernel<FF_SRC_COV>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_xfwd_lds(M)));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ff_xinv_lds(M)));
-  // generation 2 of the x passes (Stockham): as many lines per workgroup as give every thread one radix-8 item
-  h->x_gen = env_int("GSS_FFTGS_X", 2) == 1 ? 1 : 2;
+  // Stockham x passes: as many lines per workgroup as give every thread one radix-8 item
   h->x_rows = M <= 256 ? 8 : 4;
   GSS_TRY(upload_x_tables(h->xtw, f.l1 - 1, s));
 #define GSS_X2_ATTR(ROWS, LOGM)                                                                                       \
@@ -431,25 +408,15 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   // measured (profiles/r02_fftgs_overlap.txt): the two-stream pipeline changes nothing at 512^3 (2.378 against
   // 2.367 ms per realisation) -- the passes fill the chip and the queues take turns; kept as an A/B switch, off
   h->overlap = env_int("GSS_FFTGS_OVERLAP", 0) != 0;
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ff_axis_lds(lmax)));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ff_axis_lds(lmax)));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ff_axis_lds(lmax)));
-  // generation 2 of the strided passes: 8-column tiles (4 when a 1024-point line would not leave room in LDS);
-  // GSS_FFTGS_AXIS=1 / GSS_FFTGS_TXY / GSS_FFTGS_TXZ (log2 of the tile width) are A/B switches
-  h->axis_gen = env_int("GSS_FFTGS_AXIS", 2) == 1 ? 1 : 2;
-  h->axis_fast = env_int("GSS_FFTGS_AXIS_FAST", 1) != 0;
-  h->txy_log = env_int("GSS_FFTGS_TXY", f.n2 > 512 ? 2 : 3) == 2 ? 2 : 3;
-  h->txz_log = env_int("GSS_FFTGS_TXZ", f.n3 > 512 ? 2 : 3) == 2 ? 2 : 3;
+  // strided passes: 8-column tiles (4 when a 1024-point line would not leave room in LDS)
+  h->txy_log = f.n2 > 512 ? 2 : 3;
+  h->txz_log = f.n3 > 512 ? 2 : 3;
 #define GSS_A2_ATTR(MODE, TXL, NT, LOGL)                                                                            \
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_kernel<MODE, TXL, NT, LOGL>),                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(lmax, TXL)))
   if (h->txy_log == 3 || h->txz_log == 3) {
     GSS_A2_ATTR(0, 3, 512, -1); GSS_A2_ATTR(1, 3, 512, -1); GSS_A2_ATTR(2, 3, 512, -1);
-    if (lmax >= 512) {  // 512-point lines have their own instantiation (length fixed at compile time)
-      GSS_A2_ATTR(0, 3, 512, 9); GSS_A2_ATTR(1, 3, 512, 9); GSS_A2_ATTR(2, 3, 512, 9);
+    if (lmax >= 512) {  // 512-point lines have their own kernel (length fixed at compile time)
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_fast_kernel<0, 3, 512, 9>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_axis2_lds(512, 3)));
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ff_axis2_fast_kernel<1, 3, 512, 9>),
@@ -472,12 +439,6 @@ static void launch_p1_src(gss_fftgs* h, uint64_t seed, uint32_t real, const doub
   const int64_t nrows = (int64_t)f.n2 * f.n3;
   double2* X = h->Xcur;
   const CovSrc* cs = h->covsrc.as<CovSrc>();
-  if (h->x_gen == 1) {
-    const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
-    hipLaunchKernelGGL(ff_x_fwd_kernel<SRC>, dim3(gx), dim3(FF_XTHREADS), ff_xfwd_lds(M), s, f, h->tw1.as<double2>(), seed,
-                       real, noise, X, cs);
-    return;
-  }
   const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
   const size_t lds = ff_xfwd2_lds(M, f.l1 - 1, h->x_rows);
   if (f.l1 == 9)
@@ -503,11 +464,6 @@ static void launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
   const int M = f.n1 / 2;
   const int64_t nrows = (int64_t)f.n2 * f.n3;
   const double2* X = h->Xcur;
-  if (h->x_gen == 1) {
-    const unsigned gx = (unsigned)((nrows + FF_ROWS - 1) / FF_ROWS);
-    hipLaunchKernelGGL(ff_x_inv_kernel, dim3(gx), dim3(FF_XTHREADS), ff_xinv_lds(M), s, f, h->tw1.as<double2>(), X, z);
-    return;
-  }
   const unsigned gx = (unsigned)((nrows + h->x_rows - 1) / h->x_rows);
   const size_t lds = ff_xinv2_lds(M, f.l1 - 1, h->x_rows);
   if (f.l1 == 9)
@@ -551,9 +507,7 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
   if (h->fused) {
     const FusedGrid& f = h->fg;
     const int64_t nt = (int64_t)f.n2 * f.ntx * f.n3 * FF_TX;
-    if (h->axis_gen == 1)
-      hipLaunchKernelGGL(ff_tile_fh_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
-    else if (h->txz_log == 3)
+    if (h->txz_log == 3)
       hipLaunchKernelGGL(ff_tile_fh2_kernel<3>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
     else
       hipLaunchKernelGGL(ff_tile_fh2_kernel<2>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
@@ -587,7 +541,7 @@ static int32_t fftgs_fused_rest(gss_fftgs* h, double* z, hipStream_t s) {
   static const int slab = env_int("GSS_FFTGS_SLAB", 2);
   static const int slab_streams = env_int("GSS_FFTGS_SLAB_STREAMS", 3);
   const FusedGrid& f = h->fg;
-  const bool can_slab = slab > 0 && h->axis_gen != 1 && h->txy_log == 3 && h->txz_log == 3 && f.l2 == 9 && f.l3 == 9 && h->axis_fast;
+  const bool can_slab = slab > 0 && h->txy_log == 3 && h->txz_log == 3 && f.l2 == 9 && f.l3 == 9;
   if (can_slab) {
     ProfScope ps("fftgs_p234", s);
     const int ntx = f.nhp >> 3;

@@ -57,214 +57,6 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 }
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ int brev_bits(int k, int bits) { return (int)(__brev((unsigned)k) >> (32 - bits)); }
-// LDS address of logical line element i: one pad element after every 8 keeps the stride-8 accesses of the last
-// forward / first inverse radix-8 pass (lane stride 128 B -> 144 B) off the same banks
-__device__ __forceinline__ int lphys(int i) { return i + (i >> 3); }
-__host__ __device__ constexpr int lds_line_pitch(int L) { return L + (L >> 3) + 2; }
-
-// The LDS transforms are radix-2 decimation-in-frequency (forward, output bit-reversed) and decimation-in-time
-// (inverse, input bit-reversed, unnormalised), executed NS = 3 stages at a time on 8 elements held in registers
-// (a radix-8 pass: one LDS round trip and one barrier per three stages; a radix-4 or radix-2 pass finishes
-// lengths whose log2 is not a multiple of 3).  Line l of a tile sits at buf + l * pitch.  One twiddle table
-// tw[k] = exp(-2 pi i k / Lt) serves every length L that divides Lt: w_L^k = tw[k * tws], tws = Lt / L.
-
-// NS consecutive DIF stages s0 .. s0+NS-1 of a length-2^logL transform
-template <int NS, int NT>
-__device__ __forceinline__ void dif_pass(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
-                                         int s0, int tid) {
-  constexpr int R = 1 << NS;
-  const int logd = logL - s0 - NS;  // spacing of the R elements: d = (L >> s0) / R
-  const int d = 1 << logd;
-  const int items_per_line = 1 << (logL - NS);
-  for (int it = tid; it < nlines * items_per_line; it += NT) {
-    const int line = it >> (logL - NS);
-    const int r = it & (items_per_line - 1);
-    const int p = r & (d - 1);
-    const int blk = r >> logd;
-    double2* lb = buf + line * pitch;
-    const int e0 = (blk << (logd + NS)) + p;
-    int addr[R];
-    double2 x[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      addr[q] = lphys(e0 + (q << logd));
-      x[q] = lb[addr[q]];
-    }
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int span = R >> (u + 1);  // partner distance in q
-      const int s = s0 + u;
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if ((q & span) == 0) {
-          const int pos = p + ((q & (span - 1)) << logd);
-          const double2 w = tw[(pos << s) * tws];
-          const double2 a = x[q], c = x[q + span];
-          x[q] = make_double2(a.x + c.x, a.y + c.y);
-          x[q + span] = cmul(make_double2(a.x - c.x, a.y - c.y), w);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) lb[addr[q]] = x[q];
-  }
-  __syncthreads();
-}
-
-// NS consecutive inverse DIT stages s0 .. s0+NS-1 (half = 1 << s)
-template <int NS, int NT>
-__device__ __forceinline__ void dit_pass(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
-                                         int s0, int tid) {
-  constexpr int R = 1 << NS;
-  const int logd = s0;  // spacing d = 1 << s0
-  const int d = 1 << logd;
-  const int items_per_line = 1 << (logL - NS);
-  for (int it = tid; it < nlines * items_per_line; it += NT) {
-    const int line = it >> (logL - NS);
-    const int r = it & (items_per_line - 1);
-    const int p = r & (d - 1);
-    const int blk = r >> logd;
-    double2* lb = buf + line * pitch;
-    const int e0 = (blk << (logd + NS)) + p;
-    int addr[R];
-    double2 x[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      addr[q] = lphys(e0 + (q << logd));
-      x[q] = lb[addr[q]];
-    }
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int span = 1 << u;
-      const int s = s0 + u;
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if ((q & span) == 0) {
-          const int pos = p + ((q & (span - 1)) << logd);
-          const double2 w = cconj(tw[(pos << (logL - 1 - s)) * tws]);
-          const double2 a = x[q], c = cmul(x[q + span], w);
-          x[q] = make_double2(a.x + c.x, a.y + c.y);
-          x[q + span] = make_double2(a.x - c.x, a.y - c.y);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) lb[addr[q]] = x[q];
-  }
-  __syncthreads();
-}
-
-template <int NT>
-__device__ __forceinline__ void lds_fft_dif(double2* buf, int logL, int pitch, int nlines, const double2* tw, int tws,
-                                            int tid) {
-  int s = 0;
-  for (; s + 3 <= logL; s += 3) dif_pass<3, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  if (logL - s == 2) dif_pass<2, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  else if (logL - s == 1) dif_pass<1, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-}
-
-template <int NT>
-__device__ __forceinline__ void lds_fft_dit_inv(double2* buf, int logL, int pitch, int nlines, const double2* tw,
-                                                int tws, int tid) {
-  int s = 0;
-  for (; s + 3 <= logL; s += 3) dit_pass<3, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  if (logL - s == 2) dit_pass<2, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-  else if (logL - s == 1) dit_pass<1, NT>(buf, logL, pitch, nlines, tw, tws, s, tid);
-}
-
-// ---- P1: noise -> half spectrum along x -------------------------------------------------------------
-// LDS: tw[n1/2] | Z[FF_ROWS][lds_line_pitch(n1/2)]
-template <int SRC>
-__global__ __launch_bounds__(FF_XTHREADS) void ff_x_fwd_kernel(FusedGrid g, const double2* __restrict__ tw1,
-                                                              uint64_t seed, uint32_t real,
-                                                              const double* __restrict__ noise,
-                                                              double2* __restrict__ X, const CovSrc* __restrict__ cs) {
-  extern __shared__ __attribute__((aligned(16))) double2 sm[];
-  const int M = g.n1 >> 1, logM = g.l1 - 1;
-  const int MP = lds_line_pitch(M);
-  double2* tw = sm;
-  double2* Z = sm + M;
-  const int tid = threadIdx.x;
-  const int64_t nrows = (int64_t)g.n2 * g.n3;
-  const int64_t row0 = (int64_t)blockIdx.x * FF_ROWS;
-  for (int k = tid; k < M; k += FF_XTHREADS) tw[k] = tw1[k];
-  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
-    const int r = e / M, nidx = e - r * M;
-    const int64_t row = row0 + r;
-    double2 v = make_double2(0.0, 0.0);
-    if (row < nrows) {
-      const int64_t blk = row * M + nidx;  // elements 2 blk, 2 blk + 1 of the realisation
-      if (SRC == FF_SRC_ARRAY) {
-        v = reinterpret_cast<const double2*>(noise)[blk];
-      } else if (SRC == FF_SRC_COV) {
-        const int i2 = (int)(row % g.n2), i3 = (int)(row / g.n2);
-        const double zero[3] = {0.0, 0.0, 0.0};
-        double a[3] = {(double)(2 * nidx - cs->c1) * cs->s1, (double)(i2 - cs->c2) * cs->s2, (double)(i3 - cs->c3) * cs->s3};
-        v.x = cov_pair<3>(cs->vg, a, zero);
-        a[0] = (double)(2 * nidx + 1 - cs->c1) * cs->s1;
-        v.y = cov_pair<3>(cs->vg, a, zero);
-      } else {
-        philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)blk, v.x, v.y);
-      }
-    }
-    Z[r * MP + lphys(nidx)] = v;
-  }
-  __syncthreads();
-  lds_fft_dif<FF_XTHREADS>(Z, logM, MP, FF_ROWS, tw, 2, tid);  // w_M^k = w_{n1}^{2k}
-  // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2, k = 0 .. M
-  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_XTHREADS) {
-    const int r = e / (M + 1), k = e - r * (M + 1);
-    const int64_t row = row0 + r;
-    if (row >= nrows) continue;
-    const double2* z = Z + r * MP;
-    const double2 a = z[lphys(brev_bits(k & (M - 1), logM))];
-    const double2 b = cconj(z[lphys(brev_bits((M - k) & (M - 1), logM))]);
-    const double2 w = (k < M) ? tw[k] : make_double2(-1.0, 0.0);
-    const double2 d = cmul(make_double2(a.x - b.x, a.y - b.y), w);  // w^k (a - b)
-    // -i * d = (d.y, -d.x)
-    X[row * g.nhp + k] = make_double2(0.5 * (a.x + b.x + d.y), 0.5 * (a.y + b.y - d.x));
-  }
-}
-
-// ---- P5: half spectrum -> realisation along x ------------------------------------------------------------
-// LDS: tw[n1/2] | Xs[FF_ROWS][M+1] | Z[FF_ROWS][lds_line_pitch(M)]
-__global__ __launch_bounds__(FF_XTHREADS) void ff_x_inv_kernel(FusedGrid g, const double2* __restrict__ tw1,
-                                                              const double2* __restrict__ X,
-                                                              double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double2 sm[];
-  const int M = g.n1 >> 1, logM = g.l1 - 1;
-  const int MP = lds_line_pitch(M);
-  double2* tw = sm;
-  double2* Xs = sm + M;
-  double2* Z = Xs + FF_ROWS * (M + 1);
-  const int tid = threadIdx.x;
-  const int64_t nrows = (int64_t)g.n2 * g.n3;
-  const int64_t row0 = (int64_t)blockIdx.x * FF_ROWS;
-  for (int k = tid; k < M; k += FF_XTHREADS) tw[k] = tw1[k];
-  for (int e = tid; e < FF_ROWS * (M + 1); e += FF_XTHREADS) {
-    const int r = e / (M + 1), k = e - r * (M + 1);
-    const int64_t row = row0 + r;
-    Xs[e] = row < nrows ? X[row * g.nhp + k] : make_double2(0.0, 0.0);
-  }
-  __syncthreads();
-  // Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})), stored at the bit-reversed position
-  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
-    const int r = e / M, k = e - r * M;
-    const double2* xs = Xs + r * (M + 1);
-    const double2 a = xs[k], b = cconj(xs[M - k]);
-    const double2 d = cmul(make_double2(a.x - b.x, a.y - b.y), cconj(tw[k]));
-    // i * d = (-d.y, d.x)
-    Z[r * MP + lphys(brev_bits(k, logM))] = make_double2(a.x + b.x - d.y, a.y + b.y + d.x);
-  }
-  __syncthreads();
-  lds_fft_dit_inv<FF_XTHREADS>(Z, logM, MP, FF_ROWS, tw, 2, tid);
-  for (int e = tid; e < FF_ROWS * M; e += FF_XTHREADS) {
-    const int r = e / M, nidx = e - r * M;
-    const int64_t row = row0 + r;
-    if (row < nrows) reinterpret_cast<double2*>(out)[row * M + nidx] = Z[r * MP + lphys(nidx)];  // (u[2n], u[2n+1])
-  }
-}
-
 // =====================================================================================================
 // x passes, second generation (ff_x_fwd2_kernel / ff_x_inv2_kernel): Stockham autosort passes.
 // Every pass reads its R inputs at stride M / R and writes its outputs at stride Ns (the product of the radices
@@ -612,64 +404,6 @@ __global__ __launch_bounds__(NT) void ff_x_inv2_kernel(FusedGrid g, const double
         }
       }
     }
-  }
-}
-
-// ---- P2 / P4 / P3: strided lines, tiles of FF_TX consecutive kx -----------------------------------------
-// A tile is (outer index o, kx tile t): line element j of lane-column c sits at X[base(o) + j * lstride + t*TX + c].
-// MODE 0: forward DIF in place.  MODE 1: inverse DIT in place.  MODE 2: forward, phase with Fh, inverse.
-// LDS: tw[L/2] | buf[FF_TX][lds_line_pitch(L)]
-template <int MODE>
-__global__ __launch_bounds__(FF_THREADS) void ff_axis_kernel(FusedGrid g, int logL, const double2* __restrict__ twL,
-                                                             int64_t ostride, int64_t lstride,
-                                                             double2* __restrict__ X,
-                                                             const double* __restrict__ Fh_tiled, double mean) {
-  extern __shared__ __attribute__((aligned(16))) double2 sm[];
-  const int L = 1 << logL;
-  const int LP = lds_line_pitch(L);
-  double2* tw = sm;
-  double2* buf = sm + (L >> 1);
-  const int tid = threadIdx.x;
-  // block b -> tile: within every group of 16 blocks, blocks x and x + 8 (same XCD) take tiles 2x and 2x + 1
-  const int bb = blockIdx.x;
-  constexpr int GL = 3 - FF_TX_LOG;  // log2 of the tiles that share one 128-B line
-  const int tile = (bb & ~((8 << GL) - 1)) + ((bb & 7) << GL) + ((bb >> 3) & ((1 << GL) - 1));
-  const int t = tile % g.ntx;
-  const int o = tile / g.ntx;
-  const int kx0 = t * FF_TX;
-  double2* base = X + (int64_t)o * ostride + kx0;
-  for (int k = tid; k < (L >> 1); k += FF_THREADS) tw[k] = twL[k];
-  for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-    const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
-    buf[c * LP + lphys(j)] = base[(int64_t)j * lstride + c];  // columns kx >= nh of the padded pitch hold zeros
-  }
-  __syncthreads();
-  if (MODE == 0 || MODE == 2) lds_fft_dif<FF_THREADS>(buf, logL, LP, FF_TX, tw, 1, tid);
-  if (MODE == 2) {
-    // element j of the bit-reversed line is frequency brev(j); Fh_tiled is stored in exactly this order:
-    // Fh_tiled[((o * ntx + t) * L + j) * TX + c]
-    const double* fh = Fh_tiled + ((int64_t)o * g.ntx + t) * L * FF_TX;
-    for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-      const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
-      const double2 x = buf[c * LP + lphys(j)];
-      const double f = fh[e];
-      const double mag2 = x.x * x.x + x.y * x.y;
-      double2 p;
-      if (mag2 > 0.0) {
-        const double inv = f / sqrt(mag2);
-        p = make_double2(x.x * inv, x.y * inv);
-      } else {
-        p = make_double2(f, 0.0);  // angle(0) = 0
-      }
-      if (o == 0 && t == 0 && c == 0 && j == 0) p = make_double2(mean, 0.0);  // DC <- mean
-      buf[c * LP + lphys(j)] = p;
-    }
-    __syncthreads();
-  }
-  if (MODE == 1 || MODE == 2) lds_fft_dit_inv<FF_THREADS>(buf, logL, LP, FF_TX, tw, 1, tid);
-  for (int e = tid; e < L * FF_TX; e += FF_THREADS) {
-    const int c = e & (FF_TX - 1), j = e >> FF_TX_LOG;
-    base[(int64_t)j * lstride + c] = buf[c * LP + lphys(j)];
   }
 }
 
@@ -1047,24 +781,6 @@ __global__ __launch_bounds__(256) void ff_tile_fh2_kernel(FusedGrid g, const dou
     const int zp = (r << last_ns) + q;
     const int t = (int)(tile % ntx), yp = (int)(tile / ntx);
     const int kx = t * TX + c;
-    const int kz = brev_bits(zp, g.l3), ky = brev_bits(yp, g.l2);
-    dst[e] = kx < g.nh ? Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx] : 0.0;
-  }
-}
-
-// Fh (natural half spectrum [kz][ky][kx], nh fastest) -> tiled, bit-reversed order used by P3:
-// dst[((y' * ntx + t) * n3 + z') * TX + c] = Fh[brev(z')][brev(y')][t * TX + c]   (0 beyond nh)
-__global__ __launch_bounds__(256) void ff_tile_fh_kernel(FusedGrid g, const double* __restrict__ Fh,
-                                                         double* __restrict__ dst) {
-  const int64_t total = (int64_t)g.n2 * g.ntx * g.n3 * FF_TX;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e & (FF_TX - 1));
-    int64_t r = e >> FF_TX_LOG;
-    const int zp = (int)(r % g.n3);
-    r /= g.n3;
-    const int t = (int)(r % g.ntx);
-    const int yp = (int)(r / g.ntx);
-    const int kx = t * FF_TX + c;
     const int kz = brev_bits(zp, g.l3), ky = brev_bits(yp, g.l2);
     dst[e] = kx < g.nh ? Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx] : 0.0;
   }

@@ -165,11 +165,7 @@ __global__ __launch_bounds__(256) void krig_rhs2_kernel(VgDev vg, const double* 
 template <int DIM>
 static void launch_krig_rhs(dim3 grid, hipStream_t s, const VgDev& vg, const double* xd, int n, const double* x0,
                             int64_t m_valid, double* R, int64_t ldr, int seg_len, int nblk) {
-  static const bool wide = [] {
-    const char* e = std::getenv("GSS_K1_WIDE");
-    return !(e && e[0] == '0');
-  }();
-  if (wide && (ldr & 1) == 0) {
+  if ((ldr & 1) == 0) {   // two adjacent points per thread, 16-B stores (every workspace the library makes is even)
     const int64_t ncols = (int64_t)nblk * 256;
     const int nblk2 = (int)((ncols + 511) / 512);
     const dim3 g2((unsigned)(nblk2 * NSEG));
@@ -295,7 +291,7 @@ constexpr size_t QUADFORM_LDS_BYTES = sizeof(double) * 4 * TILE_LDS;
 // SPLIT: one workgroup per (strip, row block I) instead of one per strip.  The row block is the slow block index,
 // heaviest first, so that the workgroups in flight at any time cost the same (see the kernel); a strip's units keep
 // one XCD.  Partial column sums go to qpart[I][p]; krig_finish_kernel adds them in fixed order.
-template <bool W14, bool SPLIT>
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     const double* __restrict__ W, int64_t ldw, int N1pad, int n, int N1, const double* __restrict__ R,
     int64_t ldr, double sill, double mean0, int64_t m_valid,
@@ -308,7 +304,6 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
   const int nI = (N1 + BM) / BM;  // rows 0..N1: the system plus the dual-weight row N1 (the mean)
   int64_t strip = blockIdx.x;  // strips strip0 .. strip0 + nstrips - 1 belong to this launch
@@ -330,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   const int i2 = (tid & 63) * 2;
   const int kq = tid >> 6;
 
-  double qacc[4] = {0.0, 0.0, 0.0, 0.0};
-  double macc[4] = {0.0, 0.0, 0.0, 0.0};  // row N1 of the product: wd . rhs
+  double qacc[2] = {0.0, 0.0};
+  double macc[2] = {0.0, 0.0};  // row N1 of the product: wd . rhs
 
   int buf = 0;  // LDS stage holding the operands of the stage about to be multiplied; runs on across row blocks
   for (int I = Ibeg; I < Iend; ++I) {
@@ -341,14 +336,9 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
     // rows i0 .. N1 of this block carry data (row N1 = dual weights); 16-row tiles beyond them are zero padding
     const int tm_max = (N1 + 1 - i0 + 15) / 16 < 8 ? (N1 + 1 - i0 + 15) / 16 : 8;
 
-    d4 acc[4][4];
-    d4 accw[8][2];
-    if (W14) {
+    d4 accw[8][2];   // 1 x 4 wave layout: every wave sees all 128 rows (8 tiles) of 32 columns (2 tiles)
 #pragma unroll
-      for (int tm = 0; tm < 8; ++tm) accw[tm][0] = accw[tm][1] = d4{0.0, 0.0, 0.0, 0.0};
-    } else {
-      zero_acc(acc);
-    }
+    for (int tm = 0; tm < 8; ++tm) accw[tm][0] = accw[tm][1] = d4{0.0, 0.0, 0.0, 0.0};
 
     d2v ra[4], rb[4];
     const double* wp = W + (int64_t)kq * ldw + i0 + i2;
@@ -382,12 +372,10 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
           rb[r] = *reinterpret_cast<const d2v*>(rq + (int64_t)(4 * r) * ldr);
         }
       }
-      if (W14) {
+      {
         // stages inside the diagonal block (k > i0) only touch row tiles tm >= (k - i0) / 16
         const int tmn = (t * BK - i0) >> 4;
         mma_stage_w14<GUARD>(As + cur * TILE_LDS, Bs + cur * TILE_LDS, accw, wave, lane, tmn > 0 ? tmn : 0, tm_max);
-      } else {
-        mma_stage(As + cur * TILE_LDS, Bs + cur * TILE_LDS, acc, wm, wn, lane);
       }
       if (more) {
         double* an = As + (cur ^ 1) * TILE_LDS;
@@ -401,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
       __syncthreads();
       buf ^= 1;
     };
-    if (W14) {
+    {
       const int tdiag = (i0 / BK + 1) < ntile ? (i0 / BK + 1) : ntile;
       if (tm_max < 8) {  // last row block: its bottom row tiles are padding, every stage is guarded
         for (int t = 0; t < ntile; ++t) stage(t, std::true_type{});
@@ -409,49 +397,29 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
         for (int t = 0; t < tdiag; ++t) stage(t, std::false_type{});
         for (int t = tdiag; t < ntile; ++t) stage(t, std::true_type{});
       }
-    } else {
-      for (int t = 0; t < ntile; ++t) stage(t, std::false_type{});
     }
 
     // signed squares: rows < n count +, constraint rows n..N1-1 count -, padding rows are zero
-    if (W14) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        double s = 0.0;
+    for (int tn = 0; tn < 2; ++tn) {
+      double s = 0.0;
 #pragma unroll
-        for (int tm = 0; tm < 8; ++tm)
+      for (int tm = 0; tm < 8; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = i0 + tm * 16 + lk + 4 * r;
-            const double v = accw[tm][tn][r];
-            const double vv = v * v;
-            s += (row < n) ? vv : (row < N1 ? -vv : 0.0);
-            if (row == N1) macc[tn] += v;
-          }
-        qacc[tn] += s;
-      }
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        double s = 0.0;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = i0 + wm * 64 + tm * 16 + lk + 4 * r;
-            const double v = acc[tm][tn][r];
-            const double vv = v * v;
-            s += (row < n) ? vv : (row < N1 ? -vv : 0.0);
-            if (row == N1) macc[tn] += v;
-          }
-        qacc[tn] += s;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + tm * 16 + lk + 4 * r;
+          const double v = accw[tm][tn][r];
+          const double vv = v * v;
+          s += (row < n) ? vv : (row < N1 ? -vv : 0.0);
+          if (row == N1) macc[tn] += v;
+        }
+      qacc[tn] += s;
     }
   }
 
-  // reduce over the 4 lane groups (rows) of the wave, then (2 x 2 layout) over the two wave rows
+  // reduce over the 4 lane groups (rows) of the wave
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
+  for (int tn = 0; tn < 2; ++tn) {
     qacc[tn] += __shfl_xor(qacc[tn], 16);
     qacc[tn] += __shfl_xor(qacc[tn], 32);
     macc[tn] += __shfl_xor(macc[tn], 16);
@@ -461,22 +429,14 @@ __global__ __launch_bounds__(256, 2) void krig_quadform_kernel(
   double* red = smem;            // [2][BN] signed squares
   double* redm = smem + 2 * BN;  // [2][BN] mean row
   if (lk == 0) {
-    if (W14) {
-      red[wave * 32 + lr] = qacc[0];
-      red[wave * 32 + 16 + lr] = qacc[1];
-      red[BN + wave * 32 + lr] = 0.0;
-      red[BN + wave * 32 + 16 + lr] = 0.0;
-      redm[wave * 32 + lr] = macc[0];
-      redm[wave * 32 + 16 + lr] = macc[1];
-      redm[BN + wave * 32 + lr] = 0.0;
-      redm[BN + wave * 32 + 16 + lr] = 0.0;
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        red[wm * BN + wn * 64 + tn * 16 + lr] = qacc[tn];
-        redm[wm * BN + wn * 64 + tn * 16 + lr] = macc[tn];
-      }
-    }
+    red[wave * 32 + lr] = qacc[0];
+    red[wave * 32 + 16 + lr] = qacc[1];
+    red[BN + wave * 32 + lr] = 0.0;
+    red[BN + wave * 32 + 16 + lr] = 0.0;
+    redm[wave * 32 + lr] = macc[0];
+    redm[wave * 32 + 16 + lr] = macc[1];
+    redm[BN + wave * 32 + lr] = 0.0;
+    redm[BN + wave * 32 + 16 + lr] = 0.0;
   }
   __syncthreads();
   if (SPLIT) {
@@ -1015,19 +975,11 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   const int dim = h->dim;
 
   static bool attr_set = false;
-  static int split = 0;    // 0: one workgroup per strip (default); 1: per (strip, row block) for every strip -- 2 % slower than the hybrid (24 % before the row block became the slow block index)
-  static int variant = 1;  // 1: 1 x 4 waves with zero-tile skipping in the diagonal block (default); 0: 2 x 2 waves
   if (!attr_set) {
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, false>),
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true, false>),
+    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    if (const char* e = std::getenv("GSS_K3_VARIANT")) variant = std::atoi(e);
-    if (const char* e = std::getenv("GSS_K3_SPLIT")) split = std::atoi(e);
     attr_set = true;
   }
 
@@ -1037,7 +989,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   HostPipe pipe;
   GSS_TRY(pipe.begin(mem, m, s));
   const bool piped = pipe.on;
-  static const int64_t piece = std::getenv("GSS_KRIG_HOST_PIECE") ? atoll(std::getenv("GSS_KRIG_HOST_PIECE")) : HostPipe::PIECE;   // A/B switch
+  const int64_t piece = HostPipe::PIECE;
   if (piped && piece >= 256 && mc > piece) mc = piece;
   double *Rws = nullptr, *mpart = nullptr;
   GSS_TRY(krig_workspace(h->N1pad, mc, s, &Rws, &mpart));
@@ -1098,24 +1050,15 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
                             smean.as<double>() + off, svar.as<double>() + off, stp, qpart, (S0), (NS)
       // Whole rounds of 512 resident workgroups (2 per CU) run one workgroup per strip; the remainder strips
       // would occupy a full extra round, so they run as (strip, row block) units, which pack ~3x tighter.
-      const int nmain = split ? 0 : (nstrips / 512) * 512;
+      const int nmain = (nstrips / 512) * 512;
       const int nrem = nstrips - nmain;
-      if (nmain > 0) {
-        if (variant == 1)
-          hipLaunchKernelGGL((krig_quadform_kernel<true, false>), dim3((unsigned)nmain), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS(0, nmain));
-        else
-          hipLaunchKernelGGL((krig_quadform_kernel<false, false>), dim3((unsigned)nmain), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS(0, nmain));
-      }
+      if (nmain > 0)
+        hipLaunchKernelGGL((krig_quadform_kernel<false>), dim3((unsigned)nmain), dim3(256), QUADFORM_LDS_BYTES, s,
+                           GSS_K3_ARGS(0, nmain));
       if (nrem > 0) {
         const unsigned grid = (unsigned)(8 * ((nrem + 7) / 8) * nI);
-        if (variant == 1)
-          hipLaunchKernelGGL((krig_quadform_kernel<true, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS(nmain, nrem));
-        else
-          hipLaunchKernelGGL((krig_quadform_kernel<false, true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s,
-                             GSS_K3_ARGS(nmain, nrem));
+        hipLaunchKernelGGL((krig_quadform_kernel<true>), dim3(grid), dim3(256), QUADFORM_LDS_BYTES, s,
+                           GSS_K3_ARGS(nmain, nrem));
         const int64_t pbeg = (int64_t)nmain * BN;
         if (mv > pbeg)
           hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv - pbeg + 255) / 256)), dim3(256), 0, s, qpart + pbeg,

@@ -43,236 +43,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int DIM>
-__global__ __launch_bounds__(64) void krig_local_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
-                                                        const double* __restrict__ z,
-                                                        const double* __restrict__ drift_data,
-                                                        const double* __restrict__ x0,
-                                                        const double* __restrict__ drift_dom, int64_t m, int k,
-                                                        int minneighbors, const int* __restrict__ idx,
-                                                        const int* __restrict__ count, double* __restrict__ mean_out,
-                                                        double* __restrict__ var_out,
-                                                        uint8_t* __restrict__ status_out) {
-  __shared__ double Lp[LMAX_K * (LMAX_K + 1) / 2];  // packed lower triangle, row major
-  __shared__ double nx[LMAX_K][3];
-  __shared__ double Ssm[LMAX_NC][LMAX_NC + 1];
-  __shared__ double rv[LMAX_NC], tv[LMAX_NC];
-  __shared__ double res[3];
-
-  const int64_t p = blockIdx.x;
-  const int lane = threadIdx.x;
-  const int cnt = count[p];
-  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
-  if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
-    if (lane == 0) {
-      mean_out[p] = NaN;
-      var_out[p] = NaN;
-      status_out[p] = GSS_PT_MISSING;
-    }
-    return;
-  }
-  const int nc = sp.nc;
-  const int nrhs = 2 + nc;
-  double c0[DIM];
-#pragma unroll
-  for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
-
-  // neighbour j on lane j
-  const bool act = lane < cnt;
-  const int nj = act ? idx[p * k + lane] : 0;
-  double xj[DIM];
-#pragma unroll
-  for (int a = 0; a < DIM; ++a) {
-    xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
-    nx[lane][a] = xj[a];
-  }
-  // right-hand sides per lane: [0] = c0 column, [1] = data values, [2 + c] = drift column c
-  double b[LMAX_RHS];
-#pragma unroll
-  for (int r = 0; r < LMAX_RHS; ++r) b[r] = 0.0;
-  if (act) {
-    b[0] = cov_pair<DIM>(vg, xj, c0);
-    double zz = z[nj];
-    if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-    b[1] = zz;
-#pragma unroll
-    for (int c = 0; c < LMAX_NC; ++c) {
-      if (c < nc) {
-        double f = 1.0;
-        if (sp.variant == GSS_KRIG_UNIVERSAL) {
-#pragma unroll
-          for (int a = 0; a < DIM; ++a) {
-            const double u = (xj[a] - c0[a]) * sp.inv_scale;
-            for (int q = 0; q < sp.e[c][a]; ++q) f *= u;
-          }
-        } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
-          f = drift_data[(int64_t)nj * nc + c];
-        }
-        b[2 + c] = f;
-      }
-    }
-  }
-  __syncthreads();
-
-  // covariance matrix, packed lower triangle, entries dealt round-robin to the lanes
-  const int nent = tri(cnt);
-  for (int e = lane; e < nent; e += 64) {
-    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-    while (tri(i + 1) <= e) ++i;
-    while (tri(i) > e) --i;
-    const int c = e - tri(i);
-    double xi[DIM], xc[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) {
-      xi[a] = nx[i][a];
-      xc[a] = nx[c][a];
-    }
-    Lp[e] = cov_pair<DIM>(vg, xi, xc);
-  }
-  __syncthreads();
-
-  // Cholesky, left-looking by columns: lane i owns row i
-  bool bad = false;
-  const double* rowi = Lp + tri(lane < cnt ? lane : 0);
-  for (int j = 0; j < cnt; ++j) {
-    double acc = 0.0;
-    const bool mine = lane >= j && lane < cnt;
-    if (mine) {
-      const double* rowj = Lp + tri(j);
-      // four partial sums: shorter dependency chains and a quarter of the loop overhead
-      double a0 = rowi[j], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int c = 0;
-      for (; c + 4 <= j; c += 4) {
-        a0 = fma(-rowi[c], rowj[c], a0);
-        a1 = fma(-rowi[c + 1], rowj[c + 1], a1);
-        a2 = fma(-rowi[c + 2], rowj[c + 2], a2);
-        a3 = fma(-rowi[c + 3], rowj[c + 3], a3);
-      }
-      for (; c < j; ++c) a0 = fma(-rowi[c], rowj[c], a0);
-      acc = (a0 + a1) + (a2 + a3);
-    }
-    const double d = __shfl(acc, j);
-    if (!(d > 0.0)) {
-      bad = true;
-      break;
-    }
-    const double sq = sqrt(d);
-    if (mine) Lp[tri(lane) + j] = (lane == j) ? sq : acc / sq;
-    __syncthreads();
-  }
-  if (bad) {
-    if (lane == 0) {
-      mean_out[p] = NaN;
-      var_out[p] = NaN;
-      status_out[p] = GSS_PT_SINGULAR;
-    }
-    return;
-  }
-
-  // forward substitution Y = L^-1 B for all right-hand sides in one column sweep
-  for (int j = 0; j < cnt; ++j) {
-    const double ljj = Lp[tri(j) + j];
-    const double lij = (lane > j && lane < cnt) ? rowi[j] : 0.0;
-    const double inv = 1.0 / ljj;
-#pragma unroll
-    for (int r = 0; r < LMAX_RHS; ++r) {
-      if (r < nrhs) {
-        const double yj = __shfl(b[r], j) * inv;
-        if (lane == j) b[r] = yj;
-        else b[r] = fma(-lij, yj, b[r]);
-      }
-    }
-  }
-
-  const double qf = wave_sum(b[0] * b[0]);
-  const double af = wave_sum(b[1] * b[0]);
-  double rsr = 0.0, tsr = 0.0;
-  if (nc > 0) {
-#pragma unroll
-    for (int c = 0; c < LMAX_NC; ++c) {
-      if (c < nc) {
-        double f0 = 1.0;
-        if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (sp.e[c][0] + sp.e[c][1] + sp.e[c][2]) == 0 ? 1.0 : 0.0;
-        else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + c];
-        const double rc = wave_sum(b[2 + c] * b[0]) - f0;
-        const double tc = wave_sum(b[2 + c] * b[1]);
-        if (lane == 0) {
-          rv[c] = rc;
-          tv[c] = tc;
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < LMAX_NC; ++c2) {
-          if (c2 <= c) {
-            const double sv = wave_sum(b[2 + c] * b[2 + c2]);
-            if (lane == 0) Ssm[c][c2] = sv;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (lane == 0) {
-      // Cholesky of S and the two triangular solves, serial (nc <= 10)
-      int okS = 1;
-      for (int j = 0; j < nc && okS; ++j) {
-        double d = Ssm[j][j];
-        for (int c = 0; c < j; ++c) d -= Ssm[j][c] * Ssm[j][c];
-        if (!(d > 0.0)) {
-          okS = 0;
-          break;
-        }
-        const double sq = sqrt(d);
-        Ssm[j][j] = sq;
-        for (int i = j + 1; i < nc; ++i) {
-          double v = Ssm[i][j];
-          for (int c = 0; c < j; ++c) v -= Ssm[i][c] * Ssm[j][c];
-          Ssm[i][j] = v / sq;
-        }
-      }
-      double s1 = 0.0, s2 = 0.0;
-      if (okS) {
-        for (int i = 0; i < nc; ++i) {
-          double u = rv[i], v = tv[i];
-          for (int c = 0; c < i; ++c) {
-            u -= Ssm[i][c] * rv[c];
-            v -= Ssm[i][c] * tv[c];
-          }
-          u /= Ssm[i][i];
-          v /= Ssm[i][i];
-          rv[i] = u;
-          tv[i] = v;
-          s1 += u * u;
-          s2 += u * v;
-        }
-      }
-      res[0] = s1;
-      res[1] = s2;
-      res[2] = okS ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    rsr = res[0];
-    tsr = res[1];
-    if (res[2] == 0.0) {
-      if (lane == 0) {
-        mean_out[p] = NaN;
-        var_out[p] = NaN;
-        status_out[p] = GSS_PT_SINGULAR;
-      }
-      return;
-    }
-  }
-  if (lane == 0) {
-    const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
-    const double v = vg.sill - qf + rsr;
-    mean_out[p] = mu;
-    var_out[p] = v > 0.0 ? v : 0.0;
-    status_out[p] = GSS_PT_OK;
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // More than 64 neighbours (maxneighbors in 65 .. n - 1; krig.jl:201-210 and ui.jl:16-23 accept any count).
-// One workgroup of 256 threads per estimation point, same mathematics as krig_local_kernel above with the
+// One workgroup of 256 threads per estimation point, same mathematics as the MFMA-tile kernel below with the
 // right-hand sides [c0 | z | F] appended to the covariance block as extra ROWS: a root-free Cholesky sweep over the
 // (k' + nrhs) x k' array leaves A(i, c) = L(i, c) sqrt(d_c) in the triangle and, in the extra rows, the forward-
 // substituted right-hand sides in the same scaling, so that every dot product of the block elimination is
@@ -481,7 +254,7 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5, MFMA-tiled variant (default).  Same mathematics as krig_local_kernel above, but the k x k system is held in
+// K5, MFMA-tiled variant (default).  The k x k system is held in
 // registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r <-> element
 // (row (l >> 4) + 4 r, column l & 15)) and factorised as A = U'U by tiles:
 //   diagonal tile   : through LDS into "lane = row" form, 16 x 16 Cholesky with the inverse V = U_kk^-1 built in the
@@ -784,8 +557,6 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
   const char* brute = std::getenv("GSS_KNN_BRUTE");
   // (the haversine distance always searches exhaustively, in passes of 64 beyond 64 neighbours)
   const bool use_index = metric != GSS_METRIC_HAVERSINE && (big || !(brute && brute[0] == '1'));
-  const char* k5 = std::getenv("GSS_K5_VARIANT");  // 0 = LDS left-looking kernel (kept for A/B), default MFMA tiles
-  const bool use_mfma = !(k5 && k5[0] == '0');
   if (use_index) GSS_TRY(knn_index_build_from_device(xdata, n, dim, &ix, s));
   DevBuf idx_s, cnt_s, st_s;
   if (!idx_out) GSS_TRY(idx_s.alloc(sizeof(int) * (size_t)((m < chunk ? m : chunk) * k)));
@@ -838,7 +609,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
       GSS_HIP(hipStreamSynchronize(s));   // the slab is released at the end of this iteration
       continue;
     }
-    if (use_mfma) {
+    {
 #define GSS_K5_ARGS vg, sp, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, \
                     var + off, st
 #define GSS_K5_LAUNCH(D, K) \
@@ -873,22 +644,6 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
       if (piped) GSS_TRY(pipe->deliver(off, mv, s));
       continue;
     }
-    switch (dim) {
-      case 1:
-        hipLaunchKernelGGL((krig_local_kernel<1>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
-                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
-        break;
-      case 2:
-        hipLaunchKernelGGL((krig_local_kernel<2>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
-                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
-        break;
-      default:
-        hipLaunchKernelGGL((krig_local_kernel<3>), dim3((unsigned)mv), dim3(64), 0, s, vg, sp, xdata, z, drift_data,
-                           x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, var + off, st);
-        break;
-    }
-    GSS_HIP(hipGetLastError());
-    if (piped) GSS_TRY(pipe->deliver(off, mv, s));
   }
   if (piped) GSS_TRY(pipe->finish(s));
   GSS_HIP(hipStreamSynchronize(s));  // scratch and the search index are released on return

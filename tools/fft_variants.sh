@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/fft_variants.sh ["ENV=.. ENV=.." ...]  -- FFTGS leg of bench.py under A/B switches of the fused passes
-if [ $# -eq 0 ]; then set -- "GSS_FFTGS_X=1 GSS_FFTGS_AXIS=1 GSS_FFTGS_OVERLAP=0" "GSS_FFTGS_OVERLAP=0" "GSS_FFTGS_OVERLAP=1"; fi
+if [ $# -eq 0 ]; then set -- "GSS_FFTGS_SLAB=0" "GSS_FFTGS_OVERLAP=0" "GSS_FFTGS_OVERLAP=1"; fi
 for v in "$@"; do
   echo "== $v"
   env $v python bench.py --steps 1 --warmup 0 --no-cpu-baseline --lugs 0 --npoints 100000 2>/dev/null | python -c "
