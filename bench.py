@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--ndata", type=int, default=1000)
     ap.add_argument("--npoints", type=int, default=1_000_000, help="domain points per GPU per step")
     ap.add_argument("--factor-broadcast", action="store_true")
+    ap.add_argument("--native-bcast", action="store_true",
+                    help="replicate the preprocess states with the library's own RCCL broadcast (gss_comm_init + "
+                         "gss_state_bcast) instead of torch.distributed.broadcast")
     ap.add_argument("--sync-fit", action="store_true", help="gss_krig_create waits for the fit (default: "
                     "GSS_KRIG_ASYNC_FIT, the fit beside the first assembly, as the solver front-end runs it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,8 +142,12 @@ def main():
     def step():
         if a.factor_broadcast and use_dist:
             h = KrigHandle(vg, OK, x, z, factor=(rank == 0))
-            parallel.broadcast_(h.factor_tensor(), 0)
-            h.adopt_factor()
+            if a.native_bcast:
+                parallel.native_comm()
+                h.bcast_state(0)
+            else:
+                parallel.broadcast_(h.factor_tensor(), 0)
+                h.adopt_factor()
         else:
             h = KrigHandle(vg, OK, x, z, async_fit=not a.sync_fit)   # as solve() does: the fit beside the assembly
         out = h.predict_global(x0_dev)
@@ -276,6 +283,7 @@ def fftgs_leg(c):
     rank, world = c["rank"], c["world"]
     from gss.engine import FFTGSHandle
     e, R = a.fftgs, a.fftgs_reals
+    share = "native" if a.native_bcast else "broadcast"
     vg = gss.ExponentialVariogram(range=50.0 * e / 512.0)
     N = e ** 3
     try:
@@ -286,7 +294,7 @@ def fftgs_leg(c):
         f.close()
         c["barrier"]()
         t0 = time.perf_counter()
-        f = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute))
+        f = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute), share)
         c["barrier"]()
         pre_warm = c["max_over_ranks"](time.perf_counter() - t0)   # rank 0 computes, peers adopt the broadcast
     except _lib.GSSError as err:
@@ -326,7 +334,7 @@ def fftgs_leg(c):
     # the per-GPU share of configs[2] end to end: preprocess (warm) + 32 realisations
     c["barrier"]()
     t0 = time.perf_counter()
-    f2 = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute))
+    f2 = parallel.replicate_state(lambda compute: FFTGSHandle(vg, (e, e, e), spectrum=compute), share)
     for r0 in range(0, 32, B):
         f2.realize(4, rank * 32 + r0, min(B, 32 - r0), out=obuf[:min(B, 32 - r0)])
     c["barrier"]()
@@ -420,9 +428,13 @@ def lugs_leg(c):
         t_pre = time.perf_counter() - t0
         c["barrier"]()
         t0 = time.perf_counter()
-        parallel.broadcast_(h.state_tensor(), 0)
-        if rank != 0:
-            h.adopt_state()
+        if c["a"].native_bcast and world > 1:
+            parallel.native_comm()
+            h.bcast_state(0)
+        else:
+            parallel.broadcast_(h.state_tensor(), 0)
+            if rank != 0:
+                h.adopt_state()
         c["barrier"]()
         t_bc = c["max_over_ranks"](time.perf_counter() - t0)
     except _lib.GSSError as err:

@@ -63,6 +63,13 @@ SIGNATURES = {
     "gss_synchronize": [_p],
     "gss_trim_pool": [],
     "gss_stat": [C.c_char_p, C.POINTER(_i64)],
+    "gss_comm_unique_id": [_p],
+    "gss_comm_init": [_p, _i32, _i32],
+    "gss_comm_info": [C.POINTER(_i32), C.POINTER(_i32)],
+    "gss_comm_destroy": [],
+    "gss_state_bcast": [_i32, _p, _i32, _p],
+    "gss_state_ipc_export": [_i32, _p, _p],
+    "gss_state_ipc_import": [_i32, _p, _p, _p],
     "gss_profile_enable": [_i32],
     "gss_profile_reset": [],
     "gss_profile_read": [C.c_char_p, C.POINTER(_f64), C.POINTER(_i64)],
@@ -231,6 +238,51 @@ def metric_spec(distance):
     if name == "haversine" and not par > 0.0:
         raise ValueError("('haversine', radius) needs a positive radius")
     return METRICS[name], par
+
+
+STATE_KRIG, STATE_FFTGS, STATE_LUGS = 0, 1, 2
+COMM_ID_BYTES, IPC_TOKEN_BYTES = 128, 80
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128 bytes every rank passes to `comm_init` (gss.h, gss_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().gss_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
+def comm_init(uid: bytes, rank: int, nranks: int):
+    if len(uid) != COMM_ID_BYTES:
+        raise ValueError("unique id must have 128 bytes")
+    buf = C.create_string_buffer(uid, COMM_ID_BYTES)
+    check(lib().gss_comm_init(C.cast(buf, C.c_void_p), int(rank), int(nranks)))
+
+
+def comm_info():
+    r, n = C.c_int32(), C.c_int32()
+    check(load().gss_comm_info(C.byref(r), C.byref(n)))
+    return r.value, n.value
+
+
+def comm_destroy():
+    check(load().gss_comm_destroy())
+
+
+def state_bcast(kind: int, handle, root: int = 0):
+    check(lib().gss_state_bcast(int(kind), handle, int(root), current_stream()))
+
+
+def state_ipc_export(kind: int, handle) -> bytes:
+    buf = C.create_string_buffer(IPC_TOKEN_BYTES)
+    check(lib().gss_state_ipc_export(int(kind), handle, C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
+def state_ipc_import(kind: int, handle, token: bytes):
+    if len(token) != IPC_TOKEN_BYTES:
+        raise ValueError("IPC token must have 80 bytes")
+    buf = C.create_string_buffer(token, IPC_TOKEN_BYTES)
+    check(lib().gss_state_ipc_import(int(kind), handle, C.cast(buf, C.c_void_p), current_stream()))
 
 
 def stat(name: str) -> int:

@@ -87,7 +87,26 @@ def _alias_tensor(owner, dev_ptr, nbytes):
     return t
 
 
-class KrigHandle:
+class _NativeState:
+    """The library's own replication routes (gss.h "multi-GPU"): RCCL broadcast inside the library and HIP IPC."""
+    _STATE_KIND = None
+
+    def bcast_state(self, root=0):
+        """ncclBroadcast of the state on the communicator of `parallel.native_comm()`; the peers adopt."""
+        _lib.state_bcast(self._STATE_KIND, self._h, root)
+
+    def export_state(self) -> bytes:
+        """80-byte token another process passes to `import_state` (keep this handle alive until it has)."""
+        return _lib.state_ipc_export(self._STATE_KIND, self._h)
+
+    def import_state(self, token: bytes):
+        """Pull the owner's state into this handle (created without factor / spectrum) and adopt it."""
+        _lib.state_ipc_import(self._STATE_KIND, self._h, token)
+
+
+class KrigHandle(_NativeState):
+    _STATE_KIND = _lib.STATE_KRIG
+
     """gss_krig_t*: fitted kriging system living in HBM."""
 
     def __init__(self, vg, variant, xdata, z, mean=0.0, degree=0, drift_data=None, factor=True, async_fit=False):
@@ -175,7 +194,9 @@ class KrigHandle:
         return out
 
 
-class FFTGSHandle:
+class FFTGSHandle(_NativeState):
+    _STATE_KIND = _lib.STATE_FFTGS
+
     """gss_fftgs_t*: spectral amplitude + rocFFT plans for one variable."""
 
     def __init__(self, vg, dims, spacing=None, mean=0.0, spectrum=True):
@@ -245,7 +266,9 @@ class FFTGSHandle:
         return out.numpy() if pinned and is_torch(out) and not out.is_cuda else out
 
 
-class LUGSHandle:
+class LUGSHandle(_NativeState):
+    _STATE_KIND = _lib.STATE_LUGS
+
     """gss_lugs_t*: d2 and L22 in HBM for one variable."""
 
     def __init__(self, vg, centroids, dlocs, z1, mean=0.0, factor=True, factorization="cholesky"):

@@ -4,8 +4,10 @@ Domain points (kriging) and realisations (FFTGS, LUGS, SGS) are independent give
 takes a contiguous block and the data path has no collective.  The reference makes the same cut: `preprocess` runs
 once and `solvesingle` is mapped over realisations (/root/reference/src/simulation/fft.jl:62,145, lu.jl:76,171).
 The one collective is the broadcast of the preprocess state from rank 0 (`replicate_state`): RCCL over xGMI when the
-process group backend is `nccl`, `gloo` in the CPU tests.  `all_gather_concat` (opt-in, `solve(..., gather=True)`)
-reassembles the full result on every rank for callers that want it.
+process group backend is `nccl`, `gloo` in the CPU tests; `share="native"` does the same broadcast inside libgss_hip.so
+(gss_comm_init + gss_state_bcast: RCCL without torch, the route a Julia host takes).  `all_gather_concat`
+(`solve(..., gather=True)`, the default: the reference's `solve` returns the whole solution) reassembles the full
+result on every rank; `gather=False` leaves every rank with its block.
 
 Collectives run on whichever device the process group serves: under an `nccl`-only group host arrays are staged
 through HBM, under `gloo` device tensors are staged through host memory."""
@@ -80,8 +82,8 @@ def replicate_state(make: Callable[[bool], object], share: str = "broadcast"):
     rank, ws = world()
     if ws == 1 or share == "recompute":
         return make(True)
-    if share != "broadcast":
-        raise ValueError(f"share={share!r}: 'broadcast' or 'recompute'")
+    if share not in ("broadcast", "native"):
+        raise ValueError(f"share={share!r}: 'broadcast', 'native' or 'recompute'")
     flag = torch.zeros(1, dtype=torch.int32)
     handle, err = None, None
     if rank == 0:
@@ -100,12 +102,58 @@ def replicate_state(make: Callable[[bool], object], share: str = "broadcast"):
         raise RuntimeError("preprocess failed on rank 0")
     if code == 2:
         return handle if rank == 0 else make(True)
+    # the peers allocate; a peer that cannot (out of memory, a different grid) must not leave rank 0 alone in the
+    # broadcast: a second flag is exchanged first (max over ranks) and the failure is raised everywhere
+    perr = None
     if rank != 0:
-        handle = make(False)
+        try:
+            handle = make(False)
+        except Exception as e:                  # noqa: BLE001
+            perr = e
+    if _any_rank(perr is not None):
+        raise perr if perr is not None else RuntimeError("a peer rank could not allocate the state")
+    if share == "native" and hasattr(handle, "bcast_state"):
+        native_comm()
+        handle.bcast_state(0)                   # ncclBroadcast inside the library; the peers adopt there
+        return handle
     broadcast_(handle.state_tensor(), 0)
     if rank != 0:
-        handle.adopt_state()
+        try:
+            handle.adopt_state()
+        except Exception as e:                  # noqa: BLE001
+            perr = e
+    if _any_rank(perr is not None):
+        raise perr if perr is not None else RuntimeError("a peer rank could not adopt the state")
     return handle
+
+
+def _any_rank(flag: bool) -> bool:
+    """True on every rank if `flag` is true on any (one small all-reduce on the group's device)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dev = _collective_device(t)
+    t = t.to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+_native_ready = False
+
+
+def native_comm():
+    """The library's own RCCL communicator over the ranks of the default process group (gss.h: gss_comm_init): rank 0
+    draws the unique id, torch.distributed only carries its 128 bytes.  Idempotent."""
+    global _native_ready
+    if _native_ready:
+        return
+    import torch.distributed as dist
+    from . import _lib
+    rank, ws = world()
+    box = [_lib.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    _lib.comm_init(box[0], rank, ws)
+    _native_ready = True
 
 
 def all_gather_concat(local, total: int):

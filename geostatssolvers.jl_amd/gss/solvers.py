@@ -314,10 +314,11 @@ class KrigingSolver(_Solver):
                             maxneighbors=p["maxneighbors"], nmax=nmax, searcher=kind, params=p)
         return pre
 
-    def solve(self, problem: EstimationProblem, gather: bool = False):
+    def solve(self, problem: EstimationProblem, gather: bool = True):
         """krig.jl:130-164 with the domain points sharded over ranks (parallel.shard_range).  With several ranks each
         one returns the estimates of its own block of domain points (no collective on the data path);
-        `gather=True` reassembles the full table on every rank."""
+        `gather=True` (default: the reference's `solve` returns the whole solution) reassembles the full table on every
+        rank; `gather=False` leaves every rank with its own block of points, in domain order."""
         pre = self.preprocess(problem)
         pdom = problem.domain
         xdom_all = pdom.centroids()
@@ -400,7 +401,7 @@ class _NeighborEstimator(_Solver):
     def _estimate(self, p, x, z, xdom, nmax, radius, radii):
         raise NotImplementedError
 
-    def solve(self, problem: EstimationProblem, gather: bool = False):
+    def solve(self, problem: EstimationProblem, gather: bool = True):
         pdom = problem.domain
         coords = problem.data.domain.centroids()
         xdom_all = pdom.centroids()
@@ -569,10 +570,11 @@ class FFTGS(_Solver):
         r = _next_real(preproc, covars)
         return {var: self._block(problem, preproc, var, r, 1)[0] for var in covars}
 
-    def solve(self, problem: SimulationProblem, gather: bool = False):
+    def solve(self, problem: SimulationProblem, gather: bool = True):
         """GeoStatsBase's realisation loop ([DEP]) batched: realisations are sharded
         over ranks, each rank produces its block in one device call (fft.jl:145-198) and returns an Ensemble of its
-        own realisations (`gather=True`: of all of them, on every rank)."""
+        realisations -- all of them on every rank by default, as the reference's `solve` returns them; `gather=False`
+        keeps the rank's own block (no collective on the data path)."""
         pre = self.preprocess(problem)
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
@@ -689,7 +691,7 @@ class LUGS(_Solver):
         r = _next_real(preproc, covars)
         return {v: y[0] for v, y in self._block(preproc, tuple(covars), r, 1).items()}
 
-    def solve(self, problem: SimulationProblem, gather: bool = False):
+    def solve(self, problem: SimulationProblem, gather: bool = True):
         pre = self.preprocess(problem)
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(problem.nreals, rank, ws)
@@ -804,7 +806,7 @@ class SGS(_Solver):
         run = preproc["_run"]
         return {var: preproc[var].realize(run["seed"] + run["vindex"][var], r, 1)[0] for var in covars}
 
-    def solve(self, problem: SimulationProblem, gather: bool = False):
+    def solve(self, problem: SimulationProblem, gather: bool = True):
         pre = self.preprocess(problem)
         run = pre["_run"]
         rank, ws = parallel.world()

@@ -132,6 +132,32 @@ int32_t gss_trim_pool(void);
  * the host outputs of the last simulation call), "out_chunks" (chunks that call moved). */
 int32_t gss_stat(const char* name, int64_t* value);
 
+/* ---- multi-GPU: one process per GPU, the preprocess state of rank 0 replicated to the peers -----------------
+ *      The reference runs `preprocess` once and maps `solvesingle` over realisations, on worker processes if asked
+ *      (fft.jl:62,145; lu.jl:76,171); kriging shards domain points over a replicated factor (krig.jl:180).  Realisation
+ *      r depends on (seed, r) only, so the shards need nothing else from each other.  Two routes, both behind this ABI:
+ *
+ *      RCCL ("ncclBroadcast of the factor over xGMI"): rank 0 calls gss_comm_unique_id, the HOST carries
+ *      the GSS_COMM_ID_BYTES bytes to the peers (Julia `remotecall`, an MPI / torch.distributed broadcast, a file ...),
+ *      every rank calls gss_comm_init after gss_init(device); then gss_state_bcast(kind, handle, root, stream) on every
+ *      rank -- the root with the handle it computed, the peers with one created GSS_*_NO_FACTOR / _NO_SPECTRUM from the
+ *      same inputs -- is one ncclBroadcast of the state buffer followed by the peers' adopt.  RCCL is loaded at run time.
+ *
+ *      HIP IPC (no communicator, works between processes that share one device as well): the owner writes a token with
+ *      gss_state_ipc_export, the host carries its GSS_IPC_TOKEN_BYTES bytes, a peer calls gss_state_ipc_import: it maps
+ *      the owner's buffer, pulls it with one device-to-device copy over its own xGMI link and adopts.  The owner keeps
+ *      its handle alive until the peers have imported.                                                              */
+enum { GSS_STATE_KRIG = 0, GSS_STATE_FFTGS = 1, GSS_STATE_LUGS = 2 };   /* which create call `handle` came from */
+#define GSS_COMM_ID_BYTES 128
+#define GSS_IPC_TOKEN_BYTES 80
+int32_t gss_comm_unique_id(uint8_t* id);                               /* id[GSS_COMM_ID_BYTES], root only */
+int32_t gss_comm_init(const uint8_t* id, int32_t rank, int32_t nranks);
+int32_t gss_comm_info(int32_t* rank, int32_t* nranks);                 /* -1, 0 without a communicator */
+int32_t gss_comm_destroy(void);
+int32_t gss_state_bcast(int32_t kind, void* handle, int32_t root, void* stream);
+int32_t gss_state_ipc_export(int32_t kind, void* handle, uint8_t* token);          /* token[GSS_IPC_TOKEN_BYTES] */
+int32_t gss_state_ipc_import(int32_t kind, void* handle, const uint8_t* token, void* stream);
+
 /* ---- kernel timing (bench.py's roofline leg): when enabled every launch of a named hot kernel is
  *      bracketed by HIP events on the stream it is launched on; gss_profile_read synchronises
  *      those events and returns the summed duration and the launch count for `name`

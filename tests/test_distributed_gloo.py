@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
                                    engine=OracleEngine)
         sol = gss.solve(prob, solver, gather=True)
         out["krig_mu"], out["krig_var"] = sol["z"], sol["z_variance"]
-        local = gss.solve(prob, solver)                   # default: every rank keeps its own block
+        local = gss.solve(prob, solver, gather=False)     # every rank keeps its own block
         lo, hi = parallel.shard_range(101, rank, world)
         out["local_len"] = (len(local["z"]), hi - lo)
         # FFTGS / LUGS: realisations sharded; realisation r depends only on (seed, r)
@@ -80,7 +80,7 @@ def _worker(rank, world, port, q):
         out["lu_factorisations"] = _LUGS.ncomputed - before
         s2r = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
                         gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0))), rng=9, engine=OracleEngine,
-                                 share="recompute"))
+                                 share="recompute"), gather=False)
         lo_r, hi_r = parallel.shard_range(3, rank, world)
         out["lu_local"] = (np.stack(s2r["z"]) if hi_r > lo_r else np.empty((0, 24)), lo_r, hi_r)
         # a failure of rank 0's preprocess reaches every rank as an exception, not as a hung broadcast
