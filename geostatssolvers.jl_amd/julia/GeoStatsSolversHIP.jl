@@ -18,7 +18,12 @@
 # covariable group; the k-th `solvesingle` call of a group produces realisation k - 1.  `solve` is also
 # specialised for the three simulation solvers: it produces all realisations of a variable in ONE device call
 # (same indices, same fields) and frees the device state before returning.
-# Device handles live in this process: worker processes (`procs` other than `[myid()]`) are refused.
+# Several GPUs: `solve(problem, solver; procs=workers())` with ONE worker process per GPU (Distributed), each bound to its
+# device by `GeoStatsSolversHIP.bind_device(dev)`.  The first worker runs the preprocess (fft.jl:62, lu.jl:76 -- once, as
+# the reference), exports an 80-byte HIP-IPC token per device state, the other workers create their handles without state
+# and pull it over their own xGMI link (gss_state_ipc_import); every worker then realises a contiguous block of
+# realisations -- realisation r depends on (seed, r) only, so the ensemble equals the single-process one.  Kriging shards
+# the domain the same way (the factor is recomputed per worker: cheaper than moving it below a few thousand data).
 module GeoStatsSolversHIP
 
 using Meshes
@@ -29,15 +34,22 @@ using Tables
 using Random
 using Unitful
 using LinearAlgebra: cholesky, lu      # values of LUGS' `factorization` parameter (lu.jl:70)
-using Distributed: myid
+using Distributed: myid, remotecall_fetch
 
 import GeoStatsBase: solve, preprocess, solvesingle
 
 export KrigingSolverHIP, IDWSolverHIP, LWRSolverHIP, ExpWeight, TricubeWeight, FFTGSHIP, LUGSHIP, SGSHIP
+export krig_fit, krig_predict_device!, fftgs_realize_device!, bind_device
 
 const libgss = get(ENV, "LIBGSS_HIP", "libgss_hip.so")
 
 const GSS_MEM_HOST = Int32(0)
+const GSS_MEM_DEVICE = Int32(1)
+const GSS_FFTGS_NO_SPECTRUM = Int32(1)
+const GSS_LUGS_NO_FACTOR = Int32(1)
+const GSS_STATE_FFTGS = Int32(1)
+const GSS_STATE_LUGS = Int32(2)
+const GSS_IPC_TOKEN_BYTES = 80
 const GSS_KRIG_NO_FACTOR = Int32(1)
 const GSS_KRIG_ASYNC_FIT = Int32(2)     # fit beside the first assembly; status at the first global prediction
 const GSS_LUGS_FACT_LU = Int32(2)
@@ -91,9 +103,9 @@ struct RunState
   vindex::Dict{Symbol,Int}                # variable => 0-based position among variables(problem)
   owner::Int                              # process that owns the device handles
 end
-function RunState(problem, solver)
+function RunState(problem, solver; seed=nothing)
   allcovars = covariables(problem, solver)
-  RunState(rand(solver.rng, UInt64), Dict{Any,Threads.Atomic{Int}}(c.names => Threads.Atomic{Int}(0) for c in allcovars),
+  RunState(isnothing(seed) ? rand(solver.rng, UInt64) : UInt64(seed), Dict{Any,Threads.Atomic{Int}}(c.names => Threads.Atomic{Int}(0) for c in allcovars),
            Dict{Symbol,Int}(v => i - 1 for (i, v) in enumerate(keys(variables(problem)))), myid())
 end
 function nextreal!(run::RunState, conames)
@@ -220,7 +232,10 @@ coordmatrix(dom) = reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(d
   @param path = LinearPath()
 end
 
-function solve(problem::EstimationProblem, solver::KrigingSolverHIP)
+# `procs`: one worker per GPU, each estimates a contiguous block of the domain (krig.jl:180,205: the points are
+# independent given the data; the factor is recomputed per worker) -- see solve_points_on_workers below
+function solve(problem::EstimationProblem, solver::KrigingSolverHIP; procs=[myid()])
+  procs == [myid()] || return solve_points_on_workers(problem, solver, collect(procs))
   pdata = data(problem)
   pdomain = domain(problem)
   dtable = values(pdata)
@@ -453,7 +468,11 @@ end
   @global rng = Random.GLOBAL_RNG      # fft.jl:59: the Philox seed of a solve is `rand(rng, UInt64)`
 end
 
-function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
+preprocess(problem::SimulationProblem, solver::FFTGSHIP) = fftgs_preprocess(problem, solver)
+
+# `compute=false`: the spectrum arrives from another process (import_token!); `seed`: the run's Philox seed when the
+# caller has drawn it already (every worker of a distributed solve must use the same one)
+function fftgs_preprocess(problem::SimulationProblem, solver::FFTGSHIP; compute=true, seed=nothing)
   pdata = data(problem)
   pdomain = domain(problem)
   pgrid = parent(pdomain)
@@ -467,7 +486,8 @@ function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gss_fftgs_create, libgss), Int32,
                 (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Int32, Ptr{Int64}, Ptr{Float64}, Float64, Int32, Ptr{Cvoid}),
-                h, vg, Int32(length(dims)), dims, sp, Float64(μ), Int32(0), C_NULL))   # fft.jl:96-103
+                h, vg, Int32(length(dims)), dims, sp, Float64(μ), compute ? Int32(0) : GSS_FFTGS_NO_SPECTRUM,
+                C_NULL))                                                   # fft.jl:96-103
     handle = Handle(h[], :fftgs)
     # conditional simulation, fft.jl:105-135: krige the data, locate the data cells
     z̄, krig, dinds = nothing, nothing, nothing
@@ -490,7 +510,7 @@ function preprocess(problem::SimulationProblem, solver::FFTGSHIP)
     end
     preproc[var] = (γ=γ, μ=μ, handle=handle, z̄=z̄, krig=krig, dinds=dinds, maxneighbors=p.maxneighbors)
   end
-  preproc[:_run] = RunState(problem, solver)
+  preproc[:_run] = RunState(problem, solver; seed)
   preproc
 end
 
@@ -554,7 +574,7 @@ function solvesingle(problem::SimulationProblem, covars::NamedTuple, solver::FFT
 end
 
 function solve(problem::SimulationProblem, solver::FFTGSHIP; procs=[myid()])
-  procs == [myid()] || error("FFTGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  procs == [myid()] || return solve_on_workers(problem, solver, collect(procs))
   preproc = preprocess(problem, solver)
   reals = Dict{Symbol,Vector{Vector{Float64}}}()
   for covars in covariables(problem, solver), var in covars.names
@@ -575,7 +595,9 @@ end
   @global rng = Random.GLOBAL_RNG      # lu.jl:73
 end
 
-function preprocess(problem::SimulationProblem, solver::LUGSHIP)
+preprocess(problem::SimulationProblem, solver::LUGSHIP) = lugs_preprocess(problem, solver)
+
+function lugs_preprocess(problem::SimulationProblem, solver::LUGSHIP; compute=true, seed=nothing)
   pdomain = domain(problem)
   buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # lu.jl:86
   C = coordmatrix(pdomain)
@@ -591,7 +613,8 @@ function preprocess(problem::SimulationProblem, solver::LUGSHIP)
       z₁ = Float64.(buff[var][findall(mask[var])])
       !isnothing(p.mean) && !isempty(dlocs) && @warn "mean can only be specified in unconditional simulation"
       μ = isnothing(p.mean) ? 0.0 : Float64(p.mean)
-      flags = p.factorization === cholesky ? Int32(0) : GSS_LUGS_FACT_LU                # lu.jl:70,107
+      flags = (p.factorization === cholesky ? Int32(0) : GSS_LUGS_FACT_LU) |           # lu.jl:70,107
+              (compute ? Int32(0) : GSS_LUGS_NO_FACTOR)
       vg = Ref(cvariogram(p.variogram, d))
       h = Ref{Ptr{Cvoid}}(C_NULL)
       GC.@preserve C dlocs z₁ check(ccall((:gss_lugs_create, libgss), Int32,
@@ -602,7 +625,7 @@ function preprocess(problem::SimulationProblem, solver::LUGSHIP)
     length(conames) == 2 && (coparams[conames] = covars.params[conames].correlation)    # lu.jl:154-163
     push!(preproc, conames => coparams)
   end
-  preproc[:_run] = RunState(problem, solver)
+  preproc[:_run] = RunState(problem, solver; seed)
   preproc
 end
 
@@ -639,7 +662,7 @@ function solvesingle(::SimulationProblem, covars::NamedTuple, solver::LUGSHIP, p
 end
 
 function solve(problem::SimulationProblem, solver::LUGSHIP; procs=[myid()])
-  procs == [myid()] || error("LUGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  procs == [myid()] || return solve_on_workers(problem, solver, collect(procs))
   preproc = preprocess(problem, solver)
   reals = Dict{Symbol,Vector{Vector{Float64}}}()
   for covars in covariables(problem, solver)
@@ -649,6 +672,201 @@ function solve(problem::SimulationProblem, solver::LUGSHIP; procs=[myid()])
     end
   end
   ensemble(problem, reals)
+end
+
+# ---- device-resident arrays (GSS_MEM_DEVICE) -------------------------------------------------------------------------
+# The solver methods above take and return host arrays, like the reference.  A caller that keeps its arrays in HBM
+# (AMDGPU.jl: `pointer(A)` of a `ROCArray{Float64}` on the device this process is bound to) uses these entry points:
+# nothing crosses PCIe and the calls are asynchronous on `stream` (a hipStream_t as Ptr{Cvoid}; C_NULL = default stream).
+struct KrigingFit
+  handle::Handle
+  n::Int
+  d::Int
+end
+
+"""
+    krig_fit(γ, X, z; mean=nothing, degree=nothing) -> KrigingFit
+
+Factorise the kriging system of the data `X` (d x n, host) / `z` once on the device (krig.jl:176); `mean` selects simple
+kriging, `degree` universal kriging, neither ordinary kriging (ui.jl:40-50).
+"""
+function krig_fit(γ, X::Matrix{Float64}, z::Vector{Float64}; mean=nothing, degree=nothing)
+  d, n = size(X)
+  variant, deg, skmean = Int32(1), Int32(0), 0.0
+  if !isnothing(degree)
+    variant, deg = Int32(2), Int32(degree)
+  elseif !isnothing(mean)
+    variant, skmean = Int32(0), Float64(mean)
+  end
+  extent = sqrt(sum(abs2, maximum(X, dims=2) .- minimum(X, dims=2)))
+  vg = Ref(cvariogram(γ, d; extent))
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve X z check(ccall((:gss_krig_create, libgss), Int32,
+    (Ptr{Ptr{Cvoid}}, Ptr{GssVariogram}, Int32, Float64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64,
+     Int32, Ptr{Cvoid}), h, vg, variant, skmean, deg, Int32(0), X, z, C_NULL, n, Int32(0), C_NULL))
+  KrigingFit(Handle(h[], :krig), n, d)
+end
+
+"""
+    krig_predict_device!(μ, σ², status, fit, X0, m; stream=C_NULL)
+
+Global-neighbourhood estimates (krig.jl:180-183) at the `m` points whose coordinates (d x m, column-major) sit in HBM at
+`X0`; means, variances and status bytes are written to HBM at `μ`, `σ²`, `status`.
+"""
+function krig_predict_device!(μ::Ptr{Float64}, σ²::Ptr{Float64}, status::Ptr{UInt8}, fit::KrigingFit, X0::Ptr{Float64},
+                              m::Integer; stream::Ptr{Cvoid}=C_NULL)
+  check(ccall((:gss_krig_predict_global, libgss), Int32,
+              (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+              fit.handle, X0, C_NULL, Int64(m), μ, σ², status, GSS_MEM_DEVICE, stream))
+end
+
+"""
+    fftgs_realize_device!(dst, preproc, var, first, count; stream=C_NULL)
+
+Unconditional realisations `first .. first+count-1` of `var` on the whole grid of `preproc = preprocess(problem,
+solver::FFTGSHIP)`, written to HBM at `dst` (count x N doubles, realisation-major) -- the 500+ realisations/s path;
+`solve` / `solvesingle` deliver host vectors like the reference and are bounded by PCIe (~50 realisations/s at 512^3).
+"""
+function fftgs_realize_device!(dst::Ptr{Float64}, preproc, var::Symbol, first::Integer, count::Integer;
+                               stream::Ptr{Cvoid}=C_NULL)
+  check(ccall((:gss_fftgs_realize, libgss), Int32,
+              (Ptr{Cvoid}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}),
+              preproc[var].handle, varseed(preproc[:_run], var), Int64(first), Int64(count), C_NULL, C_NULL, Int64(0),
+              dst, GSS_MEM_DEVICE, stream))
+end
+
+# ---- several GPUs: one worker process per GPU ---------------------------------------------------------------------
+# Everything below runs through remotecall_fetch on workers that have loaded this module and called bind_device.
+"""
+    bind_device(dev)
+
+Bind this process to GPU `dev` (gss_init): call it once on every worker before a `solve(...; procs=workers())`,
+e.g. `@everywhere workers() GeoStatsSolversHIP.bind_device(myid() - 2)`.
+"""
+bind_device(dev::Integer) = check(ccall((:gss_init, libgss), Int32, (Int32,), Int32(dev)))
+
+const WORKER_STATE = Dict{UInt64,Any}()     # run id => preproc: the device handles stay alive between remote calls
+
+function export_token(kind::Int32, handle::Handle)
+  tok = Vector{UInt8}(undef, GSS_IPC_TOKEN_BYTES)
+  GC.@preserve tok check(ccall((:gss_state_ipc_export, libgss), Int32, (Int32, Ptr{Cvoid}, Ptr{UInt8}), kind, handle, tok))
+  tok
+end
+function import_token!(kind::Int32, handle::Handle, tok::Vector{UInt8})
+  GC.@preserve tok check(ccall((:gss_state_ipc_import, libgss), Int32, (Int32, Ptr{Cvoid}, Ptr{UInt8}, Ptr{Cvoid}),
+                               kind, handle, tok, C_NULL))
+end
+
+# (key, state kind, handle) of every device state a preprocess holds
+statehandles(pre, ::FFTGSHIP) = [(var, GSS_STATE_FFTGS, par.handle) for (var, par) in pre if var !== :_run]
+function statehandles(pre, ::LUGSHIP)
+  out = Any[]
+  for (conames, coparams) in pre
+    conames === :_run && continue
+    for (key, par) in coparams
+      key isa Set && length(key) == 1 && push!(out, ((conames, key), GSS_STATE_LUGS, par.handle))
+    end
+  end
+  out
+end
+worker_preprocess_impl(problem, solver::FFTGSHIP; kw...) = fftgs_preprocess(problem, solver; kw...)
+worker_preprocess_impl(problem, solver::LUGSHIP; kw...) = lugs_preprocess(problem, solver; kw...)
+worker_preprocess_impl(problem, solver::SGSHIP; kw...) = sgs_preprocess(problem, solver; kw...)
+statehandles(pre, ::SGSHIP) = Any[]          # nothing to move (see sgs_preprocess)
+
+# owner (tokens === nothing): preprocess, return one token per state; peer: create without state, import
+function worker_preprocess(id::UInt64, problem, solver, seed::UInt64, tokens)
+  pre = worker_preprocess_impl(problem, solver; compute=isnothing(tokens), seed=seed)
+  WORKER_STATE[id] = pre
+  isnothing(tokens) && return Dict(key => export_token(kind, h) for (key, kind, h) in statehandles(pre, solver))
+  for (key, kind, h) in statehandles(pre, solver)
+    import_token!(kind, h, tokens[key])
+  end
+  nothing
+end
+
+# realisations first .. first+count-1 of every variable: Dict(var => npts x count)
+function worker_block(id::UInt64, problem, solver::FFTGSHIP, first::Int, count::Int)
+  pre = WORKER_STATE[id]
+  Dict(var => fftgs_block(problem, pre, var, first, count) for covars in covariables(problem, solver) for var in covars.names)
+end
+function worker_block(id::UInt64, problem, solver::LUGSHIP, first::Int, count::Int)
+  pre = WORKER_STATE[id]
+  out = Dict{Symbol,Matrix{Float64}}()
+  for covars in covariables(problem, solver)
+    merge!(out, lugs_block(pre, covars.names, first, count))
+  end
+  out
+end
+function worker_block(id::UInt64, problem, solver::SGSHIP, first::Int, count::Int)
+  pre = WORKER_STATE[id]
+  Dict(var => sgs_block(pre, var, first, count) for covars in covariables(problem, solver) for var in covars.names)
+end
+function worker_release(id::UInt64, solver)
+  pre = pop!(WORKER_STATE, id, nothing)
+  isnothing(pre) && return nothing
+  if solver isa SGSHIP
+    for (var, par) in pre
+      var !== :_run && !isnothing(par.shared[]) && destroy!(par.shared[])
+    end
+  end
+  for (_, _, h) in statehandles(pre, solver)
+    destroy!(h)
+  end
+  nothing
+end
+
+blockrange(n::Int, i::Int, P::Int) = (q = divrem(n, P); lo = (i - 1) * q[1] + min(i - 1, q[2]); (lo, q[1] + (i <= q[2] ? 1 : 0)))
+
+# estimation: blocks of domain elements; every worker returns its columns in domain order, the visiting order of the
+# solver's `path` (krig.jl:179-183) is applied once at the end
+linearpath(solver::KrigingSolverHIP, problem) =
+  KrigingSolverHIP((Tuple(covars.names) => merge(covars.params[Set(covars.names)], (path=LinearPath(),))
+                    for covars in covariables(problem, solver))...)
+function worker_points(problem, solver, lo::Int, cnt::Int)
+  sub = EstimationProblem(data(problem), view(domain(problem), (lo + 1):(lo + cnt)), Tuple(keys(variables(problem))))
+  cols = Tables.columns(values(solve(sub, solver)))
+  Dict(name => collect(Tables.getcolumn(cols, name)) for name in Tables.columnnames(cols))
+end
+function solve_points_on_workers(problem::EstimationProblem, solver::KrigingSolverHIP, procs::Vector{Int})
+  pdomain = domain(problem)
+  m, P = nelements(pdomain), length(procs)
+  lin = linearpath(solver, problem)
+  parts = asyncmap(1:P) do i
+    lo, cnt = blockrange(m, i, P)
+    remotecall_fetch(worker_points, procs[i], problem, lin, lo, cnt)
+  end
+  cols = Dict(name => reduce(vcat, [part[name] for part in parts]) for name in keys(parts[1]))
+  for covars in covariables(problem, solver), var in covars.names
+    order = collect(traverse(pdomain, covars.params[Set([var])].path))
+    for name in (var, Symbol(var, "_variance"))
+      cols[name] = cols[name][order]
+    end
+  end
+  georef((; (name => cols[name] for name in sort(collect(keys(cols)); by=string))...), pdomain)
+end
+
+function solve_on_workers(problem::SimulationProblem, solver, procs::Vector{Int})
+  seed = rand(solver.rng, UInt64)                  # the reference consumes solver.rng in the same place (fft.jl:147)
+  id = rand(UInt64)
+  R, P = nreals(problem), length(procs)
+  try
+    tokens = remotecall_fetch(worker_preprocess, procs[1], id, problem, solver, seed, nothing)   # preprocess ONCE
+    @sync for p in procs[2:end]
+      @async remotecall_fetch(worker_preprocess, p, id, problem, solver, seed, tokens)
+    end
+    parts = asyncmap(1:P) do i
+      lo, cnt = blockrange(R, i, P)
+      remotecall_fetch(worker_block, procs[i], id, problem, solver, lo, cnt)
+    end
+    reals = Dict{Symbol,Vector{Vector{Float64}}}()
+    for var in keys(parts[1])
+      reals[var] = [part[var][:, r] for part in parts for r in 1:size(part[var], 2)]
+    end
+    return ensemble(problem, reals)
+  finally
+    foreach(p -> remotecall_fetch(worker_release, p, id, solver), procs)
+  end
 end
 
 # ---- SGS (sgs.jl:45-89 over seq.jl:42-141) -----------------------------------------------------
@@ -666,7 +884,11 @@ end
 
 const SGS_PATHS_PER_HANDLE = 64   # visiting orders per device handle when every realisation has its own
 
-function preprocess(problem::SimulationProblem, solver::SGSHIP)
+preprocess(problem::SimulationProblem, solver::SGSHIP) = sgs_preprocess(problem, solver)
+
+# (no transferable state: the neighbour lists and weights of a visiting order are built where they are used, so on
+# several GPUs every worker prepares the orders of its own realisations; `compute` is accepted for symmetry)
+function sgs_preprocess(problem::SimulationProblem, solver::SGSHIP; compute=true, seed=nothing)
   pdomain = domain(problem)
   buff, mask = initbuff(pdomain, variables(problem), solver.init, data=data(problem))   # seq.jl:85
   C = coordmatrix(pdomain)
@@ -691,7 +913,7 @@ function preprocess(problem::SimulationProblem, solver::SGSHIP)
                     minneighbors=Int32(p.minneighbors), radius=radius, ir=ir, vg=cvariogram(p.variogram, d),
                     mean=Float64(p.mean), metric=metric, shared=Ref{Union{Nothing,Handle}}(nothing))
   end
-  preproc[:_run] = RunState(problem, solver)
+  preproc[:_run] = RunState(problem, solver; seed)
   preproc
 end
 
@@ -743,7 +965,7 @@ function solvesingle(::SimulationProblem, covars::NamedTuple, solver::SGSHIP, pr
 end
 
 function solve(problem::SimulationProblem, solver::SGSHIP; procs=[myid()])
-  procs == [myid()] || error("SGSHIP keeps its state on this process's GPU: procs must be [myid()]")
+  procs == [myid()] || return solve_on_workers(problem, solver, collect(procs))
   preproc = preprocess(problem, solver)
   reals = Dict{Symbol,Vector{Vector{Float64}}}()
   for covars in covariables(problem, solver), var in covars.names
