@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 1h,2,2h,3,4,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
+    python bench_configs.py [--configs 1h,2,2h,3,4,bigk,lu,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
 """
 import argparse
 import json
@@ -159,6 +159,90 @@ def cfg4_local(a, gss, _lib):
             "parity_max_abs_err_first_%d" % ns: err,
             "cpu_baseline": {"value": round(ns / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
                              "sample": "oracle.kriging.approxsolve (search + fit + predict per point as krig.jl:205-228), %d points in %.1f s" % (ns, cdt)}}
+
+
+def cfg_bigk(a, gss, _lib):
+    """Moving neighbourhoods with more than 64 neighbours (krig.jl:201-210, ui.jl:16-23 accept any count): UK degree 1,
+    5 000 3-D data, Matern-3/2, k = 96 / 128 / 256.  One JSON object with a row per k."""
+    from gss.engine import KrigHandle, UK
+    from oracle import kriging as K
+    from oracle.variogram import Variogram
+    n = 5000
+    x = np.random.default_rng(6).uniform(0, 100, (n, 3))
+    z = 1.0 + 0.03 * x[:, 0] - 0.02 * x[:, 1] + 0.01 * x[:, 2] + np.random.default_rng(60).normal(size=n)
+    h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), UK, x, z, degree=1, factor=False)
+    rows = []
+    for k in (96, 128, 256):
+        m = (20_000 if a.quick else 200_000) if k <= 128 else (10_000 if a.quick else 100_000)
+        x0 = np.random.default_rng(7).uniform(0, 100, (m, 3))
+        x0d = torch.as_tensor(x0, device="cuda")
+        h.predict_knn(x0d[:2000], k)
+        sync()
+        _lib.profile_reset(); _lib.profile_enable(True)
+        t0 = time.perf_counter()
+        mu, var, st = h.predict_knn(x0d, k)
+        sync()
+        dt = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        knn, loc = _lib.profile_read("knn"), _lib.profile_read("krig_local")
+        N1 = k + 4
+        flop_pt = N1 ** 3 / 3 + 2 * N1 ** 2
+        ns = 40
+        t1 = time.perf_counter()
+        rmu, rvar, _ = K.approxsolve(K.UK, Variogram("matern", range=30.0, nu=1.5), x, z, x0[:ns], k, degree=1)
+        cdt = time.perf_counter() - t1
+        err = float(np.max(np.abs(mu[:ns].cpu().numpy() - rmu)))
+        rows.append({"k": k, "points": m, "value": round(m / dt, 1), "unit": "points/s",
+                     "kernel_ms": {"knn": round(knn[0], 2), "krig_local": round(loc[0], 2)},
+                     "roofline": {"bound": "mfma", "kernel": "krig_local (per-point systems)",
+                                  "achieved": round(flop_pt * m / (loc[0] * 1e-3) / 1e12, 3) if loc[0] else None,
+                                  "peak": FP64_PEAK, "unit": "TFLOP/s",
+                                  "frac": round(flop_pt * m / (loc[0] * 1e-3) / 1e12 / FP64_PEAK, 4) if loc[0] else None,
+                                  "flop_per_point": flop_pt},
+                     "parity_max_abs_err_first_%d" % ns: err,
+                     "cpu_baseline": {"value": round(ns / cdt, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                                      "sample": "oracle.kriging.approxsolve, %d points in %.2f s" % (ns, cdt)}})
+    return {"config": "moving neighbourhood beyond 64 neighbours: UK degree 1, 5000 3-D data, Matern-3/2",
+            "metric": "kriged points/s", "rows": rows}
+
+
+def cfg_lu(a, gss, _lib):
+    """LUGS with `factorization = lu` (lu.jl:70,107) at configs[3] size beside the Cholesky preprocess."""
+    from gss.engine import LUGSHandle
+    from oracle import fftgs as O
+    g = 64 if a.quick else 128
+    nd = g * g // 4
+    cent = O.grid_centroids((g, g))
+    N = g * g
+    dlocs = np.sort(np.random.default_rng(5).permutation(N)[:nd])
+    z1 = np.random.default_rng(50).normal(size=nd)
+    vg = gss.SphericalVariogram(range=20.0)
+    ns = N - nd
+    out = {}
+    for fact in ("cholesky", "lu"):
+        LUGSHandle(vg, cent, dlocs, z1, factorization=fact).close()
+        sync()
+        t0 = time.perf_counter()
+        h = LUGSHandle(vg, cent, dlocs, z1, factorization=fact)
+        sync()
+        out[fact] = time.perf_counter() - t0
+        h.close()
+    # LU: 2/3 n^3 per factorisation (nd and ns), the two triangular solves and the Schur product as in the Cholesky path
+    flops = 2 * nd ** 3 / 3 + 2 * nd * nd * ns + 2 * nd * ns * ns + 2 * ns ** 3 / 3
+    import scipy.linalg as sla
+    from oracle.variogram import Variogram, cov_pairwise
+    nb = 2048
+    C = cov_pairwise(Variogram("spherical", range=20.0), cent[:nb])
+    t1 = time.perf_counter()
+    sla.lu(C)
+    cdt = time.perf_counter() - t1
+    return {"config": "LUGS factorization = lu, %dx%d grid, %d conditioning cells, ns=%d" % (g, g, nd, ns),
+            "metric": "preprocess seconds", "value": round(out["lu"], 4), "unit": "s", "cholesky_s": round(out["cholesky"], 4),
+            "ratio_to_cholesky": round(out["lu"] / out["cholesky"], 2),
+            "roofline": {"bound": "mfma", "achieved": round(flops / out["lu"] / 1e12, 3), "peak": FP64_PEAK, "unit": "TFLOP/s",
+                         "frac": round(flops / out["lu"] / 1e12 / FP64_PEAK, 4)},
+            "cpu_baseline": {"value": round(cdt * (ns / nb) ** 3, 2), "unit": "s (getrf of the ns x ns block alone)", "cores": os.cpu_count(),
+                             "kind": "port", "sample": "scipy.linalg.lu on %d x %d in %.2f s, scaled by n^3 to ns" % (nb, nb, cdt)}}
 
 
 def _est(a, gss, _lib, which):
@@ -407,7 +491,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -188,4 +188,67 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
   *bad_col = badc;
 }
 
+// One tile, only what a right-looking block step needs from it: v = U^-1 in tile layout (t = U'U) and the first column
+// whose pivot was not positive (-1 if none).  potrf16_full without the U / V' outputs: 16 x 17 doubles of LDS (S), the
+// calling wave alone when WAVE_LOCAL (the other waves of the workgroup wait at a barrier of their own).
+template <bool WAVE_LOCAL = false>
+__device__ __forceinline__ void potrf16_inv(const d4_t& t, double* S, int lane, d4_t* v, int* bad_col) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
+  tile_sync<WAVE_LOCAL>();
+  const int i = c;
+  double row[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) row[q] = S[i * 17 + q];
+  tile_sync<WAVE_LOCAL>();
+  double myy = 1.0;
+  int badc = -1;
+  static_for<0, 16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    double d = bc16<j>(row[j]);
+    if (!(d > 0.0)) {
+      if (badc < 0) badc = j;
+      d = 1.0;
+    }
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    double lij = row[j] * y;
+    double tm = (i > j) ? -(lij * y) : 0.0;
+    if (i == j) myy = y;
+    if (j < 15) dpp_fence(lij);
+    static_for<j + 1, 16>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      fmac_bc16<q, true>(row[q], lij, lij);
+    });
+    static_for<0, j>([&](auto C) {
+      constexpr int cc = decltype(C)::value;
+      fmac_bc16_after_write<j>(row[cc], row[cc], tm);
+    });
+    row[j] = (i == j) ? 1.0 : tm;
+  });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[r * 17 + i] = row[r] * myy;   // V = W': lane b = i writes column b
+  tile_sync<WAVE_LOCAL>();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) (*v)[r] = S[(g + 4 * r) * 17 + c];
+  tile_sync<WAVE_LOCAL>();
+  *bad_col = badc;
+}
+
+// A tile parked in LDS as the image of its registers: element (lane, r) at [r * 64 + lane] (conflict-free 8-byte
+// accesses); this is how the waves of the many-neighbour kernel hand tiles to each other.
+__device__ __forceinline__ void tile_store(double* p, const d4_t& t, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p[r * 64 + lane] = t[r];
+}
+__device__ __forceinline__ d4_t tile_load(const double* p, int lane) {
+  d4_t t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = p[r * 64 + lane];
+  return t;
+}
+
 }  // namespace gss
