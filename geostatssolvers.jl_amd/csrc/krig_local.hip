@@ -13,6 +13,7 @@
 // Universal-kriging monomials are taken about the estimation point (the polynomial space is
 // translation invariant), so f0 = (1, 0, ..., 0).
 #include "gss_internal.h"
+#include "krig_local.h"
 #include "tile16.h"
 
 #include <cmath>
@@ -21,19 +22,6 @@
 #include <vector>
 
 namespace gss {
-
-constexpr int LMAX_K = 64;
-constexpr int LMAX_NC = 10;
-constexpr int LMAX_RHS = LMAX_NC + 2;
-
-struct LocalSpec {
-  int variant;
-  int nc;
-  int dim;
-  signed char e[LMAX_NC][3];
-  double inv_scale;  // monomial scaling (1 / data extent), conditioning only
-  double sk_mean;
-};
 
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 
@@ -252,70 +240,6 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
     }
   }
 }
-
-// Block elimination on the (2 + nc) x (2 + nc) Gram matrix G = Y'Y of the forward-substituted right-hand sides
-// [c0 | z | F] (one wave; lane i = drift term i, everything in registers; lanes 16..63 shadow lanes 0..15):
-// S = Y_F'Y_F = L L', u = L^-1 (Y_F'y_c - f0), v = L^-1 Y_F'y_z, r'S^-1 r = |u|^2, t'S^-1 r = u.v, then
-// sigma^2 = max(0, sill - q + r'S^-1 r), mu = a - t'S^-1 r (module header).  Writes the point's outputs when `live`.
-__device__ __forceinline__ void gram_finish(const double (*G)[17], const signed char (*se)[4], const VgDev& vg,
-                                            const LocalSpec& sp, const double* __restrict__ drift_dom, int64_t p,
-                                            int lane, bool live, double* __restrict__ mean_out,
-                                            double* __restrict__ var_out, uint8_t* __restrict__ status_out) {
-  const int nc = sp.nc;
-  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
-  const double qf = G[0][0], af = G[1][0];
-  double rsr = 0.0, tsr = 0.0;
-  bool okS = true;
-  if (nc > 0) {
-    const int i = (lane & 15) < LMAX_NC ? (lane & 15) : LMAX_NC - 1;  // lanes 16..63 shadow lanes 0..15 (bc16)
-    double srow[LMAX_NC];
-#pragma unroll
-    for (int cc = 0; cc < LMAX_NC; ++cc) srow[cc] = G[2 + i][2 + cc];
-    double f0 = 1.0;
-    if (sp.variant == GSS_KRIG_UNIVERSAL) f0 = (se[i][0] + se[i][1] + se[i][2]) == 0 ? 1.0 : 0.0;
-    else if (sp.variant == GSS_KRIG_EXTDRIFT) f0 = drift_dom[p * nc + (i < nc ? i : 0)];
-    double u = G[2 + i][0] - f0, v = G[2 + i][1];
-    static_for<0, LMAX_NC>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      if (j < nc) {
-        double d = bc16<j>(srow[j]);
-        if (!(d > 0.0)) {
-          okS = false;
-          d = 1.0;
-        }
-        double y = __builtin_amdgcn_rsq(d);
-        const double h = 0.5 * d;
-        y = fma(y, fma(-h * y, y, 0.5), y);
-        y = fma(y, fma(-h * y, y, 0.5), y);
-        double lij = srow[j] * y;  // L[i][j] for i > j; lane cc holds L[cc][j]
-        if (j + 1 < LMAX_NC) dpp_fence(lij);
-        static_for<j + 1, LMAX_NC>([&](auto CC) {
-          constexpr int cc = decltype(CC)::value;
-          fmac_bc16<cc, true>(srow[cc], lij, lij);  // srow[cc] -= L[cc][j] * L[i][j]
-        });
-        const double uj = bc16<j>(u) * y, vj = bc16<j>(v) * y;
-        rsr = fma(uj, uj, rsr);
-        tsr = fma(uj, vj, tsr);
-        u = fma(-lij, uj, u);
-        v = fma(-lij, vj, v);
-      }
-    });
-  }
-  if (live && lane == 0) {
-    if (!okS) {
-      mean_out[p] = NaN;
-      var_out[p] = NaN;
-      status_out[p] = GSS_PT_SINGULAR;
-    } else {
-      const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
-      const double vv = vg.sill - qf + rsr;
-      mean_out[p] = mu;
-      var_out[p] = vv > 0.0 ? vv : 0.0;
-      status_out[p] = GSS_PT_OK;
-    }
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // K5, MFMA-tiled variant (default).  The k x k system is held in
@@ -543,237 +467,6 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   gram_finish(G, se, vg, sp, drift_dom, p, lane, live, mean_out, var_out, status_out);
 }
 
-// ---------------------------------------------------------------------------------------------
-// 65 .. 256 neighbours on the MFMA tile core: ONE point per workgroup, W = NTMAX / 2 waves, the upper block triangle of
-// the k x k system distributed over the waves' REGISTERS by tile columns -- wave w owns columns w and nt - 1 - w
-// (j + 1 tiles and nt - j tiles: nt + 1 per wave, balanced) plus the right-hand-side tiles [c0 | z | F] of the same
-// two tile rows.  Right-looking block steps, A = U'U as in the 64-neighbour kernel above:
-//   1. the owner of column K factors the diagonal tile (potrf16_inv, 16 dependent column steps) and posts V = U_KK^-1;
-//   2. every wave solves its own tiles of block row K, U_Kj = V'A_Kj and Y_K = V'B_K, and posts -U_Kj / Y_K in LDS
-//      (the pivot row: at most NTMAX + 1 tiles, register images, conflict-free);
-//   3. every wave updates its own columns, A_ij -= U_Ki'U_Kj (operand -U_Ki from the pivot row), B_i -= U_Ki'Y_K.
-// Two workgroup barriers per step; nothing but the pivot row ever leaves the registers.  The Gram matrix Y'Y is summed
-// over the waves and wave 0 finishes as gram_finish does for the small kernel.  k <= 128: 4 waves (3 workgroups per
-// CU), k <= 192: 6 waves, k <= 256: 8 waves (one workgroup per CU).  Beyond 256 neighbours: krig_local_big_kernel.
-// ---------------------------------------------------------------------------------------------
-template <int NTMAX>
-struct TilesLds {
-  static constexpr int W = NTMAX / 2;
-  static constexpr int KMAX = 16 * NTMAX;
-  static constexpr int NX = 0;                            // KMAX x 3 neighbour coordinates
-  static constexpr int PV = NX + KMAX * 3;                // pivot row: NTMAX tiles (-U_Kj at j) + Y_K; before step 0 the
-  static constexpr int VS = PV + (NTMAX + 1) * 256;       //   staged right-hand-side columns (LMAX_RHS x KMAX <= 17 x 256 / ...)
-  static constexpr int SS = VS + 256;                     // 16 x 17 scratch of the diagonal factorisation
-  static constexpr int GG = SS + 272;                     // 16 x 17 Gram matrix
-  static constexpr int GP = GG + 272;                     // W partial Gram tiles
-  static constexpr int DOUBLES = GP + W * 256;
-  static_assert(LMAX_RHS * KMAX <= (NTMAX + 1) * 256, "right-hand-side staging does not fit the pivot row");
-};
-
-template <int DIM, int NTMAX>
-__global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_tiles_kernel(
-    VgDev vg, LocalSpec sp, const double* __restrict__ xdata, const double* __restrict__ z,
-    const double* __restrict__ drift_data, const double* __restrict__ x0, const double* __restrict__ drift_dom, int64_t m,
-    int k, int minneighbors, const int* __restrict__ idx, const int* __restrict__ count, double* __restrict__ mean_out,
-    double* __restrict__ var_out, uint8_t* __restrict__ status_out) {
-  using L = TilesLds<NTMAX>;
-  constexpr int W = L::W, KMAX = L::KMAX;
-  extern __shared__ double tl_sm[];
-  double* nx = tl_sm + L::NX;
-  double* P = tl_sm + L::PV;
-  double* Vs = tl_sm + L::VS;
-  double* S = tl_sm + L::SS;
-  double (*G)[17] = reinterpret_cast<double (*)[17]>(tl_sm + L::GG);
-  double* Gp = tl_sm + L::GP;
-  __shared__ signed char se[LMAX_NC][4];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int g = lane >> 4, c = lane & 15;
-  const int nc = sp.nc;
-  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
-  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-  if (tid == 0) {
-#pragma unroll
-    for (int cc = 0; cc < LMAX_NC; ++cc)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) se[cc][a] = sp.e[cc][a];
-  }
-  for (int64_t p = blockIdx.x; p < m; p += gridDim.x) {
-    const int cnt = __builtin_amdgcn_readfirstlane(count[p]);
-    __syncthreads();   // the point before has been finished by every wave (LDS is re-used)
-    if (cnt < minneighbors || cnt <= 0) {  // krig.jl:213-214
-      if (tid == 0) {
-        mean_out[p] = NaN;
-        var_out[p] = NaN;
-        status_out[p] = GSS_PT_MISSING;
-      }
-      continue;
-    }
-    const int nt = (cnt + 15) >> 4;
-    double c0[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) c0[a] = x0[p * DIM + a];
-    if (tid == 0) s_bad = 0;
-    // neighbour coordinates and the right-hand-side columns (lane = neighbour), staged where the pivot row will live
-    // (the exponents come from their LDS copy: a runtime-indexed read of the argument struct would go through scratch;
-    // the barrier at the top of the loop has published them)
-    double* rhs = P;
-    for (int j = tid; j < 16 * nt; j += 64 * W) {
-      const bool act = j < cnt;
-      const int nj = act ? idx[p * k + j] : 0;
-      double xj[DIM];
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) {
-        xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
-        nx[j * 3 + a] = xj[a];
-      }
-      double zz = act ? z[nj] : 0.0;
-      if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-      rhs[0 * KMAX + j] = act ? cov_pair<DIM>(vg, xj, c0) : 0.0;
-      rhs[1 * KMAX + j] = act ? zz : 0.0;
-      for (int t = 0; t < nc; ++t) {
-        double f = 1.0;
-        if (sp.variant == GSS_KRIG_UNIVERSAL) {
-#pragma unroll
-          for (int a = 0; a < DIM; ++a) {
-            const double u = (xj[a] - c0[a]) * sp.inv_scale;
-            for (int q = 0; q < se[t][a]; ++q) f *= u;
-          }
-        } else if (sp.variant == GSS_KRIG_EXTDRIFT) {
-          f = act ? drift_data[(int64_t)nj * nc + t] : 0.0;
-        }
-        rhs[(2 + t) * KMAX + j] = act ? f : 0.0;
-      }
-    }
-    __syncthreads();
-    // ownership: the columns are paired from the two ends, (0, nt - 1), (1, nt - 2), ...: wave w takes the pair
-    // (cA, cB) = (w, nt - 1 - w) while cA <= cB (the middle column of an odd count stands alone as cA; waves beyond
-    // the pairs own nothing and only keep the barriers company)
-    const int cA = wave;
-    const int cB = nt - 1 - wave;
-    const bool hasA = cA <= cB;
-    const bool hasB = cB > cA;
-    auto build = [&](int i, int col) -> d4_t {   // tile (i, col) of the covariance matrix, identity beyond cnt
-      double xr[4][DIM], xc[DIM], v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int a = 0; a < DIM; ++a) xr[r][a] = nx[(16 * i + g + 4 * r) * 3 + a];
-      const int cj = 16 * col + c;
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) xc[a] = nx[cj * 3 + a];
-      cov_pair4<DIM>(vg, xr, xc, v);
-      d4_t t;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * i + g + 4 * r;
-        t[r] = (row < cnt && cj < cnt) ? v[r] : (row == cj ? 1.0 : 0.0);
-      }
-      return t;
-    };
-    auto build_rhs = [&](int i) -> d4_t {        // right-hand-side tile of block row i: 16 columns, zero beyond 2 + nc
-      d4_t t;
-      const bool used = c < 2 + nc;
-      const double* col = rhs + (used ? c : 0) * KMAX;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v = col[16 * i + g + 4 * r];
-        t[r] = used ? v : 0.0;
-      }
-      return t;
-    };
-    d4_t A[W], Bc[NTMAX], RA = zero4, RB = zero4;
-#pragma unroll
-    for (int i = 0; i < W; ++i) A[i] = (hasA && i <= cA) ? build(i, cA) : zero4;
-#pragma unroll
-    for (int i = 0; i < NTMAX; ++i) Bc[i] = (hasB && i <= cB) ? build(i, cB) : zero4;
-    if (hasA) RA = build_rhs(cA);
-    if (hasB) RB = build_rhs(cB);
-    __syncthreads();   // the staged columns have been read: the pivot row may take their place
-
-    static_for<0, NTMAX>([&](auto KK) {
-      constexpr int K = decltype(KK)::value;
-      if (K < nt) {
-        const bool ownA = hasA && cA == K, ownB = hasB && cB == K;
-        if (ownA || ownB) {
-          d4_t t = Bc[K];
-          if constexpr (K < W) {
-            if (ownA) t = A[K];
-          }
-          d4_t v;
-          int badc;
-          potrf16_inv<true>(t, S, lane, &v, &badc);
-          tile_store(Vs, v, lane);
-          if (badc >= 0 && lane == 0) s_bad = 1;
-        }
-        __syncthreads();
-        const d4_t V = tile_load(Vs, lane);
-        if constexpr (K < W) {
-          if (hasA && cA > K) {
-            A[K] = xty(V, A[K], zero4);
-            tile_store(P + cA * 256, -A[K], lane);
-          }
-          if (ownA) {
-            RA = xty(V, RA, zero4);
-            tile_store(P + NTMAX * 256, RA, lane);
-          }
-        }
-        if (hasB && cB > K) {
-          Bc[K] = xty(V, Bc[K], zero4);
-          tile_store(P + cB * 256, -Bc[K], lane);
-        }
-        if (ownB) {
-          RB = xty(V, RB, zero4);
-          tile_store(P + NTMAX * 256, RB, lane);
-        }
-        __syncthreads();
-        if constexpr (K < W) {
-          if (hasA && cA > K) {
-            const d4_t U = A[K];
-            static_for<K + 1, W>([&](auto II) {
-              constexpr int i = decltype(II)::value;
-              if (i <= cA) A[i] = xty(tile_load(P + i * 256, lane), U, A[i]);
-            });
-            RA = xty(tile_load(P + cA * 256, lane), tile_load(P + NTMAX * 256, lane), RA);
-          }
-        }
-        if (hasB && cB > K) {
-          const d4_t U = Bc[K];
-          static_for<K + 1, NTMAX>([&](auto II) {
-            constexpr int i = decltype(II)::value;
-            if (i <= cB) Bc[i] = xty(tile_load(P + i * 256, lane), U, Bc[i]);
-          });
-          RB = xty(tile_load(P + cB * 256, lane), tile_load(P + NTMAX * 256, lane), RB);
-        }
-      }
-    });
-    // Gram matrix of the forward-substituted right-hand sides, summed over the waves
-    d4_t Gt = zero4;
-    if (hasA) Gt = xty(RA, RA, Gt);
-    if (hasB) Gt = xty(RB, RB, Gt);
-    tile_store(Gp + wave * 256, Gt, lane);
-    __syncthreads();
-    if (wave == 0) {
-      d4_t sum = zero4;
-#pragma unroll
-      for (int w = 0; w < W; ++w) sum += tile_load(Gp + w * 256, lane);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) G[g + 4 * r][c] = sum[r];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (s_bad) {
-        if (lane == 0) {
-          mean_out[p] = NaN;
-          var_out[p] = NaN;
-          status_out[p] = GSS_PT_SINGULAR;
-        }
-      } else {
-        gram_finish(G, se, vg, sp, drift_dom, p, lane, true, mean_out, var_out, status_out);
-      }
-    }
-  }
-}
-
 // Host driver: chunks the domain so that the neighbour-index scratch stays small, runs K4 then K5.
 int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const signed char* exps, double inv_scale,
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
@@ -820,33 +513,9 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     const double* dd = drift_dom ? drift_dom + off * nc : nullptr;
     ProfScope pl("krig_local", s);
     if (big && k <= 256) {
-      // 65 .. 256 neighbours: the register-distributed tile kernel, one point per workgroup
-      const int ntmax = k <= 128 ? 8 : (k <= 192 ? 12 : 16);
-      const int per_cu = ntmax == 8 ? 3 : 1;
-      int64_t blocks = (int64_t)256 * per_cu * 2;   // two rounds of resident workgroups, points handed out by stride
-      if (blocks > mv) blocks = mv;
-#define GSS_TILES_LAUNCH(D, NT)                                                                                       \
-  do {                                                                                                                \
-    const size_t lds = sizeof(double) * (size_t)TilesLds<NT>::DOUBLES;                                                \
-    GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_local_tiles_kernel<D, NT>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
-    hipLaunchKernelGGL((krig_local_tiles_kernel<D, NT>), dim3((unsigned)blocks), dim3(32 * NT), lds, s, vg, sp,       \
-                       xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off,          \
-                       var + off, st);                                                                                \
-  } while (0)
-#define GSS_TILES_DIM(D)                                \
-  do {                                                  \
-    if (ntmax == 8) GSS_TILES_LAUNCH(D, 8);             \
-    else if (ntmax == 12) GSS_TILES_LAUNCH(D, 12);      \
-    else GSS_TILES_LAUNCH(D, 16);                       \
-  } while (0)
-      switch (dim) {
-        case 1: GSS_TILES_DIM(1); break;
-        case 2: GSS_TILES_DIM(2); break;
-        default: GSS_TILES_DIM(3); break;
-      }
-#undef GSS_TILES_DIM
-#undef GSS_TILES_LAUNCH
+      // 65 .. 256 neighbours: the register-distributed tile kernel, one point per workgroup (krig_tiles.hip)
+      GSS_TRY(krig_local_tiles_launch(vg, sp, dim, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx,
+                                      cnt, mean + off, var + off, st, s));
       GSS_HIP(hipGetLastError());
       if (piped) GSS_TRY(pipe->deliver(off, mv, s));
       continue;
