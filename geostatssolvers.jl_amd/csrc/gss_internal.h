@@ -744,6 +744,7 @@ int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, 
 int64_t potrf_inverse_work_doubles(int64_t n);
 // after a *d_info of -1: no more single-launch panels in this process (callers retry on the launch-per-block recursion)
 void potrf_panel_disable();
+void lu_grid_disable();   // lu.hip: 32-column LU panels on one workgroup instead of the grid
 // padded16: the caller guarantees that rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are
 // zero (they stay zero): a size that is not a multiple of 16 then still runs on the single-launch panel kernel.
 int32_t potrf_inverse_f64(double* A, int64_t n, int64_t lda, double* W, int64_t ldw, double* scr, int* d_info,

@@ -95,6 +95,7 @@ static int32_t check_info(DevBuf& info, const char* what, hipStream_t s) {
   GSS_HIP(hipStreamSynchronize(s));
   if (h < 0) {
     potrf_panel_disable();  // from now on the launch-per-block path, which has no residency requirement
+    lu_grid_disable();      // (and single-workgroup LU panels)
     set_error("%s: the single-launch factorisation gave up waiting at a grid barrier (its workgroups were not resident "
               "together); switched off for this process", what);
     return LUGS_RETRY;

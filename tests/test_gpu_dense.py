@@ -216,9 +216,11 @@ def test_potrf_reports_indefinite():
     assert code == _lib.ERR_NOT_POSDEF and "pivot at row 70" in _lib.last_error()
 
 
-@pytest.mark.parametrize("n", [1, 7, 32, 33, 100, 257, 1500])
+@pytest.mark.parametrize("n", [1, 7, 32, 33, 100, 257, 1500, 2500, 4133])
 def test_getrf_unit_lower_matches_lapack(n):
-    """gss_dev_getrf_l: `lu(A).L` with LAPACK's pivoting rule (first row of maximal |a|), on matrices that do pivot."""
+    """gss_dev_getrf_l: `lu(A).L` with LAPACK's pivoting rule (first row of maximal |a|), on matrices that do pivot.
+    Beyond 2 048 rows the 32-column panels run on a grid of workgroups with one barrier per column (lu.hip); 4 133 is
+    ragged against the 128-column outer panels, the 32-column panels and the 1 024-row workgroups."""
     import scipy.linalg as sla
     import torch
     from gss import _lib

@@ -14,6 +14,7 @@ import gss  # noqa: E402
 from gss.engine import LUGSHandle  # noqa: E402
 
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+fact = sys.argv[2] if len(sys.argv) > 2 else "cholesky"       # "lu": the pivoted factorisation of lu.jl:70
 N, nd = g * g, g * g // 4
 cent = gss.CartesianGrid(g, g).centroids()
 dlocs = np.sort(np.random.default_rng(5).permutation(N)[:nd])
@@ -22,7 +23,7 @@ vg = gss.SphericalVariogram(range=20.0)
 for it in range(2):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    h = LUGSHandle(vg, cent, dlocs, z1)
+    h = LUGSHandle(vg, cent, dlocs, z1, factorization=fact)
     torch.cuda.synchronize()
     print("create", it, time.perf_counter() - t0)
     h.close()
