@@ -68,30 +68,42 @@ static void prof_collect(ProfEntry& e) {
   e.stop.clear();
 }
 
-// ---- cross-stream ordering of the library's own work (see to_stream in gss_internal.h) ---------------
-static hipStream_t g_last_stream = nullptr;
-static bool g_have_last_stream = false;
+// ---- cross-stream ordering of the library's own work (see to_stream / EntryGuard in gss_internal.h) -----------
+// All of this runs under the library's lock (api_mutex).
+static hipStream_t g_last_stream = nullptr;    // stream of the last finished call (compared, never used)
+static bool g_have_chain = false;              // g_chain_event has been recorded on it
 static hipEvent_t g_chain_event = nullptr;
+static hipStream_t g_call_stream = nullptr;    // stream of the call in progress
+static bool g_call_has_stream = false;
+static int g_entry_depth = 0;
 
-static std::mutex g_chain_mu;
+EntryGuard::EntryGuard() : lock(api_mutex()) { ++g_entry_depth; }
+
+EntryGuard::~EntryGuard() {
+  if (--g_entry_depth != 0 || !g_call_has_stream) return;
+  g_call_has_stream = false;
+  if (!g_chain_event && hipEventCreateWithFlags(&g_chain_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    g_chain_event = nullptr;
+  }
+  g_have_chain = g_chain_event && hipEventRecord(g_chain_event, g_call_stream) == hipSuccess;
+  if (!g_have_chain) (void)hipGetLastError();
+  g_last_stream = g_call_stream;
+}
 
 hipStream_t to_stream(void* sv) {
   hipStream_t s = reinterpret_cast<hipStream_t>(sv);
-  std::lock_guard<std::mutex> lock(g_chain_mu);
-  if (g_have_last_stream && s != g_last_stream) {
-    bool chained = false;
-    if (!g_chain_event && hipEventCreateWithFlags(&g_chain_event, hipEventDisableTiming) != hipSuccess)
-      g_chain_event = nullptr;
-    if (g_chain_event && hipEventRecord(g_chain_event, g_last_stream) == hipSuccess &&
-        hipStreamWaitEvent(s, g_chain_event, 0) == hipSuccess)
-      chained = true;
-    if (!chained) {  // e.g. the previous stream has been destroyed by its owner: fall back to a full barrier
-      (void)hipGetLastError();
-      (void)hipDeviceSynchronize();
+  if (!g_call_has_stream && g_entry_depth > 0) {
+    if (g_last_stream != s || !g_have_chain) {
+      // a different stream than the call before (or no usable event): wait for what that call queued
+      if (!(g_have_chain && hipStreamWaitEvent(s, g_chain_event, 0) == hipSuccess) && g_chain_event) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+      }
     }
+    g_call_stream = s;
+    g_call_has_stream = true;
   }
-  g_last_stream = s;
-  g_have_last_stream = true;
   return s;
 }
 
@@ -271,6 +283,10 @@ hipStream_t helper_stream(int which) {
 static hipStream_t host_copy_stream(int i) { return helper_stream(HELPER_GEN0 + i); }
 
 HostPipe::~HostPipe() {
+  if (on) {   // an early exit of the caller: copies may still be queued on the copy streams while the device images
+    if (cin) (void)hipStreamSynchronize(cin);     // (whole-call scratch) are about to return to the pool
+    if (cout) (void)hipStreamSynchronize(cout);
+  }
   if (ev_in) (void)hipEventDestroy(ev_in);
   if (ev_done) (void)hipEventDestroy(ev_done);
 }
@@ -336,6 +352,7 @@ int32_t HostPipe::finish(hipStream_t s) {
   pend_n = 0;
   GSS_HIP(hipStreamSynchronize(cout));
   GSS_HIP(hipStreamSynchronize(s));
+  on = false;   // (nothing left for the destructor to join)
   return GSS_OK;
 }
 

@@ -43,7 +43,15 @@ void set_error(const char* fmt, ...);
 // several host threads are serialised, so the stream chain (to_stream), the block cache and the process-wide work
 // buffers see one call at a time whichever handles and streams the threads use.  Recursive: exports call each other.
 std::recursive_mutex& api_mutex();
-#define GSS_ENTRY() std::lock_guard<std::recursive_mutex> gss_entry_lock__(::gss::api_mutex())
+// ... and, when the outermost export returns, records the library's chain event on the stream the call used (the
+// stream is certainly alive then); the next call on a DIFFERENT stream waits for that event (to_stream), so the library
+// never touches a stream of an earlier call again -- its owner may have destroyed it.
+struct EntryGuard {
+  std::lock_guard<std::recursive_mutex> lock;
+  EntryGuard();
+  ~EntryGuard();
+};
+#define GSS_ENTRY() ::gss::EntryGuard gss_entry_guard__
 
 // ---------------------------------------------------------------------------------------------
 // optional per-kernel timing with HIP events (gss_profile_*)
@@ -164,8 +172,8 @@ struct OutStream {
 
 // Every C-ABI entry converts its `stream` argument here.  Scratch memory (the DevBuf pool, the kriging workspace) is
 // recycled without per-block events, which is only safe if everything the library queues is ordered; when a call
-// arrives on a different stream than the previous one, the new stream is made to wait for the work queued on the old
-// one (one event record + one stream wait, nothing when the process keeps to one stream).
+// arrives on a different stream than the previous one, the new stream is made to wait for the event the previous call
+// left behind at its exit (EntryGuard above): one stream wait, nothing when the process keeps to one stream.
 hipStream_t to_stream(void* s);
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 

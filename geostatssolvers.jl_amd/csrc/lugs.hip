@@ -116,9 +116,14 @@ static int32_t lugs_create_impl(gss_lugs_t** out, const gss_variogram_t* vg, con
   GSS_REQUIRE(nd == 0 || (dlocs != nullptr && z1 != nullptr), "gss_lugs_create: NULL conditioning data");
   gss_lugs* h = new (std::nothrow) gss_lugs();
   if (!h) return GSS_ERR_ALLOC;
-  struct Guard {
-    gss_lugs* h;
-    ~Guard() { delete h; }
+  struct Guard {   // an early exit: the look-ahead stream may still be writing the state (C22 is assembled there, the
+    gss_lugs* h;   // trailing updates of the factorisations run there) -- join it before the handle's blocks return to the pool
+    ~Guard() {
+      if (h) {
+        if (hipStream_t side = lookahead_stream()) (void)hipStreamSynchronize(side);
+        delete h;
+      }
+    }
   } guard{h};
   GSS_REQUIRE(vg_is_stationary(vg), "variogram model must be stationary");  // fft.jl:91, lu.jl:110
   GSS_TRY(make_vgdev(vg, &h->vg));
