@@ -529,6 +529,12 @@ struct gss_krig {
     if (fit_info_host) (void)hipHostFree(fit_info_host);
   }
   bool factored = false;
+  // block support (gss_krig_set_block_support): right-hand sides regularised over a cell of size `cell` sampled at
+  // the centres of nsub^dim sub-cells; c_vv = mean covariance between two samples of the cell (replaces the sill in
+  // the variance).  nsub = 0: point support.
+  int block_nsub = 0;
+  double block_cell[3] = {0.0, 0.0, 0.0};
+  double block_cvv = 0.0;
   double* Wp() const { return factor.as<double>(); }
   double* wd() const { return factor.as<double>() + ldw * N1pad; }
 };
@@ -539,6 +545,73 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
                        int* count_out, hipStream_t s, int metric, HostPipe* pipe = nullptr);
+}
+
+
+// Block support (krig.jl:180 passes the cell geometry to predictprob; [RECALL] its covariances are averages over sample
+// points inside the cell): row j of R, column p = mean over the nsub^DIM sub-cell centres s of C(x_j, c_p + s).  Thread
+// = domain point, the datum index is wave-uniform.  An option, not the tuned path: nsub^DIM covariances per entry.
+template <int DIM>
+__global__ __launch_bounds__(256) void krig_rhs_block_kernel(VgDev vg, const double* __restrict__ xd, int n,
+                                                             const double* __restrict__ x0, int64_t m_valid,
+                                                             double* __restrict__ R, int64_t ldr, int nsub,
+                                                             double c1, double c2, double c3) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= ldr) return;
+  const bool live = p < m_valid;
+  double c[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) c[a] = live ? x0[p * DIM + a] : 0.0;
+  const double cell[3] = {c1, c2, c3};
+  const int ns = DIM == 1 ? nsub : (DIM == 2 ? nsub * nsub : nsub * nsub * nsub);
+  const double inv = 1.0 / (double)ns;
+  for (int j = 0; j < n; ++j) {
+    double xj[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) xj[a] = xd[(int64_t)j * DIM + a];
+    double acc = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      int q = s;
+      double sp[DIM];
+#pragma unroll
+      for (int a = DIM - 1; a >= 0; --a) {      // the same order of samples as the oracle (first axis slowest)
+        const int ia = q % nsub;
+        q /= nsub;
+        sp[a] = c[a] + (((double)ia + 0.5) / (double)nsub - 0.5) * cell[a];
+      }
+      acc += cov_pair<DIM>(vg, xj, sp);
+    }
+    R[(int64_t)j * ldr + p] = live ? acc * inv : 0.0;
+  }
+}
+
+// mean covariance between two samples of a cell: one workgroup, pairs dealt to the threads, fixed-order reduction
+template <int DIM>
+__global__ __launch_bounds__(256) void block_cvv_kernel(VgDev vg, int nsub, double c1, double c2, double c3,
+                                                        double* __restrict__ out) {
+  __shared__ double part[256];
+  const double cell[3] = {c1, c2, c3};
+  const int ns = DIM == 1 ? nsub : (DIM == 2 ? nsub * nsub : nsub * nsub * nsub);
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < ns * ns; e += 256) {
+    double a[DIM], b[DIM];
+    int qa = e / ns, qb = e % ns;
+#pragma unroll
+    for (int d = DIM - 1; d >= 0; --d) {
+      a[d] = (((double)(qa % nsub) + 0.5) / (double)nsub - 0.5) * cell[d];
+      b[d] = (((double)(qb % nsub) + 0.5) / (double)nsub - 0.5) * cell[d];
+      qa /= nsub;
+      qb /= nsub;
+    }
+    acc += cov_pair<DIM>(vg, a, b);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += part[i];
+    *out = t / ((double)ns * (double)ns);
+  }
 }
 
 static void uk_exponents(int dim, int degree, std::vector<signed char>& e) {
@@ -1026,6 +1099,15 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
     const int nrows = (int)(h->N1pad - h->n);
     {
       ProfScope ps("krig_rhs", s);
+      if (h->block_nsub > 0) {
+        const dim3 gb((unsigned)((ldr + 255) / 256));
+        const double* bc = h->block_cell;
+        switch (dim) {
+          case 1: hipLaunchKernelGGL(krig_rhs_block_kernel<1>, gb, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, h->block_nsub, bc[0], bc[1], bc[2]); break;
+          case 2: hipLaunchKernelGGL(krig_rhs_block_kernel<2>, gb, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, h->block_nsub, bc[0], bc[1], bc[2]); break;
+          default: hipLaunchKernelGGL(krig_rhs_block_kernel<3>, gb, dim3(256), 0, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, h->block_nsub, bc[0], bc[1], bc[2]); break;
+        }
+      } else
       switch (dim) {
         case 1: launch_krig_rhs<1>(g1, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, seg_len, nblk); break;
         case 2: launch_krig_rhs<2>(g1, s, h->vg, h->xdata.as<double>(), (int)h->n, x0, mv, Rws, ldr, seg_len, nblk); break;
@@ -1046,7 +1128,8 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
       double* qpart = mpart;
       const double mean0 = h->variant == GSS_KRIG_SIMPLE ? h->sk_mean : 0.0;
       uint8_t* stp = status ? sstat.as<uint8_t>() + off : nullptr;
-#define GSS_K3_ARGS(S0, NS) h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, h->vg.sill, mean0, mv, \
+      const double c00 = h->block_nsub > 0 ? h->block_cvv : h->vg.sill;   // variance = C(V, V) - rhs . weights
+#define GSS_K3_ARGS(S0, NS) h->Wp(), h->ldw, (int)h->N1pad, (int)h->n, (int)h->N1, Rws, ldr, c00, mean0, mv, \
                             smean.as<double>() + off, svar.as<double>() + off, stp, qpart, (S0), (NS)
       // Whole rounds of 512 resident workgroups (2 per CU) run one workgroup per strip; the remainder strips
       // would occupy a full extra round, so they run as (strip, row block) units, which pack ~3x tighter.
@@ -1062,7 +1145,7 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
         const int64_t pbeg = (int64_t)nmain * BN;
         if (mv > pbeg)
           hipLaunchKernelGGL(krig_finish_kernel, dim3((unsigned)((mv - pbeg + 255) / 256)), dim3(256), 0, s, qpart + pbeg,
-                             nI, ldr, h->vg.sill, mv - pbeg, svar.as<double>() + off + pbeg, stp ? stp + pbeg : nullptr);
+                             nI, ldr, c00, mv - pbeg, svar.as<double>() + off + pbeg, stp ? stp + pbeg : nullptr);
       }
 #undef GSS_K3_ARGS
     }
@@ -1080,12 +1163,49 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
 }
 
 
+int32_t gss_krig_set_block_support(gss_krig_t* h, const double* cell, int32_t nsub, void* stream) {
+  GSS_ENTRY();
+  GSS_REQUIRE(h != nullptr, "NULL handle");
+  if (nsub <= 0 || cell == nullptr) {   // back to point support
+    h->block_nsub = 0;
+    return GSS_OK;
+  }
+  GSS_REQUIRE(nsub <= 8, "block support: at most 8 samples per axis (got %d)", nsub);
+  GSS_REQUIRE(h->vg.kind != GSS_VG_POWER, "block support needs a stationary variogram");
+  GSS_REQUIRE(h->variant != GSS_KRIG_EXTDRIFT && !(h->variant == GSS_KRIG_UNIVERSAL && h->degree > 1),
+              "block support: simple / ordinary kriging or a drift of degree <= 1 (the cell average of a linear drift is "
+              "its value at the centroid; higher degrees and external drifts would need their own cell averages)");
+  for (int a = 0; a < h->dim; ++a) GSS_REQUIRE(cell[a] > 0.0, "block support: cell sizes must be positive");
+  hipStream_t s = to_stream(stream);
+  DevBuf out;
+  GSS_TRY(out.alloc(sizeof(double)));
+  double c[3] = {0.0, 0.0, 0.0};
+  for (int a = 0; a < h->dim; ++a) c[a] = cell[a];
+  switch (h->dim) {
+    case 1: hipLaunchKernelGGL(block_cvv_kernel<1>, dim3(1), dim3(256), 0, s, h->vg, nsub, c[0], c[1], c[2], out.as<double>()); break;
+    case 2: hipLaunchKernelGGL(block_cvv_kernel<2>, dim3(1), dim3(256), 0, s, h->vg, nsub, c[0], c[1], c[2], out.as<double>()); break;
+    default: hipLaunchKernelGGL(block_cvv_kernel<3>, dim3(1), dim3(256), 0, s, h->vg, nsub, c[0], c[1], c[2], out.as<double>()); break;
+  }
+  GSS_HIP(hipGetLastError());
+  double cvv = 0.0;
+  GSS_HIP(hipMemcpyAsync(&cvv, out.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  h->block_nsub = nsub;
+  for (int a = 0; a < 3; ++a) h->block_cell[a] = c[a];
+  h->block_cvv = cvv;
+  return GSS_OK;
+}
+
 int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m, int32_t k,
                              int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
                              double metric_param, double* mean, double* var, uint8_t* status, int32_t* idx_out,
                              int32_t* count_out, int32_t mem, void* stream) {
   GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
+  if (h->block_nsub > 0) {
+    set_error("block support is available with the global neighbourhood only (gss_krig_predict_global)");
+    return GSS_ERR_UNSUPPORTED;
+  }
   GSS_TRY(check_metric(metric, metric_param, h->dim, radius, inv_radii));
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_knn: NULL array");
   GSS_REQUIRE(k >= 1 && k <= h->n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "gss_krig_factor_buffer": [_p, C.POINTER(_p), C.POINTER(_i64)],
     "gss_krig_adopt_factor": [_p],
     "gss_krig_predict_global": [_p, _p, _p, _i64, _p, _p, _p, _i32, _p],
+    "gss_krig_set_block_support": [_p, _p, _i32, _p],
     "gss_krig_predict_knn": [_p, _p, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _p, _p, _p, _p, _p, _i32, _p],
     "gss_krig_predict_global_batch": [_p, _p, _i64, _p, _i64, _p, _i32, _p],
     "gss_idw_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _f64, _p, _p, _p, _i32, _p],

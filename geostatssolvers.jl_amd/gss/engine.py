@@ -148,6 +148,12 @@ class KrigHandle(_NativeState):
 
     state_tensor, adopt_state = factor_tensor, adopt_factor      # the names parallel.replicate_state uses
 
+    def set_block_support(self, cell, nsub=3):
+        """Regularise the right-hand sides of `predict_global` over cells of size `cell` (gss.h,
+        gss_krig_set_block_support); `nsub=0` returns to point support."""
+        c = None if not nsub else np.ascontiguousarray(np.broadcast_to(np.asarray(cell, dtype=np.float64), (self.dim,)))
+        check(self._l.gss_krig_set_block_support(self._h, ptr(c), int(nsub or 0), current_stream()))
+
     def predict_global(self, xdom, drift_dom=None):
         xdom = _prep_in(xdom)
         m = xdom.shape[0]

@@ -292,7 +292,12 @@ def searcher_ui(domain, maxneighbors, metric, neighborhood):
 # ------------------------------------------------------------------------------------------
 class KrigingSolver(_Solver):
     PARAMS = dict(variogram=GaussianVariogram(), mean=None, degree=None, drifts=None, minneighbors=1,
-                  maxneighbors=None, neighborhood=None, distance="euclidean", path="linear")   # krig.jl:64-74
+                  maxneighbors=None, neighborhood=None, distance="euclidean", path="linear",   # krig.jl:64-74
+                  # not a parameter of the reference, which has no choice: predictprob gets the cell on a grid
+                  # (krig.jl:180) and its dependencies regularise over it.  "point" (default) estimates at the
+                  # centroids; ("block", nsub) regularises over the cells of a CartesianGrid by
+                  # the midpoint rule with nsub points per axis (gss.h, gss_krig_set_block_support)
+                  support="point")
 
     def preprocess(self, problem: EstimationProblem):
         """krig.jl:76-128."""
@@ -341,6 +346,15 @@ class KrigingSolver(_Solver):
             # the fit (krig.jl:176) is replicated by default: below n ~ 2 000 recomputing the factor on every GPU is
             # cheaper than any collective; share="broadcast" sends rank 0's factor instead
             h = parallel.replicate_state(mk, self._share("recompute")) if exact else mk(False)
+            sup = p.get("support", "point")
+            if sup != "point":
+                nsub = 3 if sup == "block" else int(sup[1])
+                g = parent(pdom)
+                if not hasattr(g, "spacing"):
+                    raise ValueError("support='block' needs a Cartesian grid domain (the cells to average over)")
+                if not exact:
+                    raise NotImplementedError("block support is available with the global neighbourhood only")
+                h.set_block_support(g.spacing, nsub)
             try:
                 if hi > lo:
                     if exact:

@@ -230,6 +230,10 @@ coordmatrix(dom) = reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(d
   @param neighborhood = nothing
   @param distance = Euclidean()
   @param path = LinearPath()
+  # not a parameter of the reference (krig.jl:180 always hands the cell of a grid to predictprob, whose dependencies
+  # regularise over it): :point estimates at the centroids; (:block, nsub) regularises over the cells of a Cartesian grid
+  # by the midpoint rule with nsub points per axis (gss_krig_set_block_support), global neighbourhood only
+  @param support = :point
 end
 
 # `procs`: one worker per GPU, each estimates a contiguous block of the domain (krig.jl:180,205: the points are
@@ -280,6 +284,15 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP; procs=[myid
                    Ptr{Float64}, Int64, Int32, Ptr{Cvoid}),
                   h, vg, variant, skmean, degree, ndrift, X, z, Fd, n, exact ? GSS_KRIG_ASYNC_FIT : GSS_KRIG_NO_FACTOR, C_NULL))
       try
+        if p.support !== :point
+          exact || throw(ArgumentError("block support is available with the global neighbourhood only"))
+          pgrid = parent(pdomain)
+          pgrid isa CartesianGrid || throw(ArgumentError("support = :block needs a Cartesian grid domain"))
+          cell = Float64[ustrip.(spacing(pgrid))...]
+          nsub = p.support === :block ? Int32(3) : Int32(p.support[2])
+          GC.@preserve cell check(ccall((:gss_krig_set_block_support, libgss), Int32,
+                                        (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Cvoid}), h[], cell, nsub, C_NULL))
+        end
         if exact                                                         # krig.jl:166-186
           check(ccall((:gss_krig_predict_global, libgss), Int32,
                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32,

@@ -11,7 +11,12 @@ kriging_ui) and the [DEP] GeoStatsModels 0.2 `fit` / `predictprob` pair those ca
     mu      = lambda . z                (SK: mean + lambda . (z - mean))
     sigma^2 = max(0, sill - RHS . [lambda; nu])
 
-Support is a point at the element centroid.
+Support is a point at the element centroid by default.  `support=(cell, nsub)`
+restates what the reference's dependencies do when `predictprob` receives a grid cell (krig.jl:180,226 pass
+`pdomain[ind]`): [RECALL] Variography regularises gamma(point, geometry) by averaging over sample points inside the
+geometry.  The scheme here -- documented, not the dependency's exact one, which is version dependent -- is the midpoint
+rule: `nsub` points per axis at the centres of the sub-cells of a cell of size `cell` around the centroid;
+c0_i = mean_s C(x_i, s), f0 = mean_s f(s), sigma^2 = mean_{s,s'} C(s, s') - RHS . [lambda; nu].
 """
 from __future__ import annotations
 
@@ -135,22 +140,43 @@ def _solve(fk: FittedKriging, rhs: np.ndarray) -> np.ndarray:
     return sol
 
 
-def predict(fk: FittedKriging, x0: np.ndarray, drift_dom: Optional[np.ndarray] = None):
-    """predictprob -> (mean, variance) at points x0 (m x d); vectorised over RHS columns."""
+def block_samples(dim: int, cell, nsub: int) -> np.ndarray:
+    """Offsets (nsub^dim x dim) of the sample points of a cell about its centroid: centres of the sub-cells."""
+    cell = np.asarray(cell, dtype=np.float64).reshape(dim)
+    t = (np.arange(nsub) + 0.5) / nsub - 0.5
+    grids = np.meshgrid(*[t * cell[a] for a in range(dim)], indexing="ij")
+    return np.stack([g.ravel() for g in grids], axis=1)
+
+
+def predict(fk: FittedKriging, x0: np.ndarray, drift_dom: Optional[np.ndarray] = None, support=None):
+    """predictprob -> (mean, variance) at points x0 (m x d); vectorised over RHS columns.  `support=(cell, nsub)`:
+    x0 are cell centroids and the right-hand sides are regularised over the cell (module docstring)."""
     x0 = np.atleast_2d(np.asarray(x0, dtype=np.float64))
     m = x0.shape[0]
     rhs = np.empty((fk.n + fk.nc, m))
     stat = isstationary(fk.vg)
-    rhs[:fk.n] = cov_pairwise(fk.vg, fk.x, x0) if stat else pairwise(fk.vg, fk.x, x0)
-    if fk.nc:
-        rhs[fk.n:] = drift_matrix(fk.variant, x0, fk.degree, drift_dom).T
+    cvv = fk.vg.sill
+    if support is not None:
+        assert stat and fk.variant != EDK, "block support: stationary models, no external drifts"
+        off = block_samples(x0.shape[1], support[0], int(support[1]))
+        rhs[:] = 0.0
+        for o in off:
+            rhs[:fk.n] += cov_pairwise(fk.vg, fk.x, x0 + o)
+            if fk.nc:
+                rhs[fk.n:] += drift_matrix(fk.variant, x0 + o, fk.degree, None).T
+        rhs /= len(off)
+        cvv = float(np.mean(cov_pairwise(fk.vg, off, off)))       # the same for every cell of a regular grid
+    else:
+        rhs[:fk.n] = cov_pairwise(fk.vg, fk.x, x0) if stat else pairwise(fk.vg, fk.x, x0)
+        if fk.nc:
+            rhs[fk.n:] = drift_matrix(fk.variant, x0, fk.degree, drift_dom).T
     w = _solve(fk, rhs)
     lam = w[:fk.n]
     if fk.variant == SK:
         mu = fk.mean + lam.T @ (fk.z - fk.mean)
     else:
         mu = lam.T @ fk.z
-    var = fk.vg.sill - np.sum(rhs * w, axis=0) if stat else np.sum(rhs * w, axis=0)
+    var = cvv - np.sum(rhs * w, axis=0) if stat else np.sum(rhs * w, axis=0)
     return mu, np.maximum(var, 0.0)
 
 
@@ -244,10 +270,10 @@ def knn_search(x: np.ndarray, centers: np.ndarray, k: int, radius: Optional[floa
 # ----------------------------------------------------------------------------
 # exactsolve / approxsolve   (krig.jl:166-234)
 # ----------------------------------------------------------------------------
-def exactsolve(variant, vg, x, z, xdom, mean=0.0, degree=None, drift_data=None, drift_dom=None):
-    """krig.jl:166-186: fit once on all samples, predict every domain point."""
+def exactsolve(variant, vg, x, z, xdom, mean=0.0, degree=None, drift_data=None, drift_dom=None, support=None):
+    """krig.jl:166-186: fit once on all samples, predict every domain point (`support`: see `predict`)."""
     fk = fit(variant, vg, x, z, mean, degree, drift_data)
-    return predict(fk, xdom, drift_dom)
+    return predict(fk, xdom, drift_dom, support)
 
 
 def approxsolve(variant, vg, x, z, xdom, maxneighbors, minneighbors=1, mean=0.0, degree=None,

@@ -26,9 +26,12 @@ class _Krig:
     def close(self):
         pass
 
+    def set_block_support(self, cell, nsub=3):
+        self.support = None if not nsub else (np.broadcast_to(np.asarray(cell, dtype=np.float64), (self.x.shape[1],)), nsub)
+
     def predict_global(self, xdom, drift_dom=None):
         mu, var = OK_.exactsolve(self.variant, self.vg, self.x, self.z, xdom, mean=self.mean, degree=self.degree,
-                                 drift_data=self.drift_data, drift_dom=drift_dom)
+                                 drift_data=self.drift_data, drift_dom=drift_dom, support=getattr(self, "support", None))
         return mu, var, np.zeros(len(mu), dtype=np.uint8)
 
     def predict_knn(self, xdom, k, minneighbors=1, radius=None, radii=None, drift_dom=None, return_idx=False,

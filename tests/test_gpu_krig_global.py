@@ -369,3 +369,63 @@ def test_host_arrays_in_pieces_without_a_status_array():
                                             var.ctypes.data_as(C.c_void_p), None, 0, None)
     assert rc == 0
     assert np.array_equal(mean, ref[0]) and np.array_equal(var, ref[1])
+
+
+@pytest.mark.parametrize("variant,okw,dim", [(K.OK, {}, 2), (K.SK, dict(mean=0.4), 3), (K.UK, dict(degree=1), 2), (K.OK, {}, 1)])
+def test_block_support_matches_oracle(variant, okw, dim):
+    """`support = ("block", nsub)`: right-hand sides regularised over the grid cells by the midpoint rule (krig.jl:180
+    passes the cell to predictprob; gss.h gss_krig_set_block_support) against the oracle's restatement, 1e-9; the block
+    mean equals the average of the point estimates at the samples (weights are linear in the right-hand side)."""
+    from gss.engine import KrigHandle
+    from oracle.kriging import block_samples
+    rng = np.random.default_rng(70 + dim)
+    x = rng.uniform(0, 30, (120, dim))
+    z = rng.normal(size=120)
+    dims = {1: (40,), 2: (12, 10), 3: (6, 5, 4)}[dim]
+    spacing = {1: (0.75,), 2: (2.5, 3.0), 3: (5.0, 6.0, 7.5)}[dim]
+    cent = offt.grid_centroids(dims, (0.0,) * dim, spacing)
+    gvg, ovg = _vg("matern", range=12.0, nu=1.5, nugget=0.05), Variogram("matern", range=12.0, nu=1.5, nugget=0.05)
+    h = KrigHandle(gvg, variant, x, z, mean=okw.get("mean"), degree=okw.get("degree"))
+    mu_pt, var_pt, _ = h.predict_global(cent)
+    h.set_block_support(spacing, 3)
+    mu, var, st = h.predict_global(cent)
+    rmu, rvar = K.exactsolve(variant, ovg, x, z, cent, support=(spacing, 3), **{k: v for k, v in okw.items()})
+    assert not st.any() and np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    assert np.max(np.abs(mu - mu_pt)) > 1e-6                         # it is a different estimate
+    off = block_samples(dim, spacing, 3)
+    pts = (cent[:5, None, :] + off[None, :, :]).reshape(-1, dim)
+    h.set_block_support(None, 0)                                     # back to point support
+    mu_s, _, _ = h.predict_global(pts)
+    assert np.max(np.abs(mu[:5] - mu_s.reshape(5, -1).mean(axis=1))) < 1e-10
+    mu_again, var_again, _ = h.predict_global(cent)
+    assert np.array_equal(mu_again, mu_pt) and np.array_equal(var_again, var_pt)
+    h.close()
+
+
+def test_block_support_through_the_solver_and_refusals():
+    import gss
+    from gss import _lib
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(9)
+    xy = rng.uniform(0, 64, (100, 2))
+    z = rng.normal(size=100)
+    grid = gss.CartesianGrid(64, 64)                                  # the shape of BASELINE configs[0]
+    prob = gss.EstimationProblem(gss.georef({"z": z}, xy), grid, "z")
+    vg = gss.SphericalVariogram(range=20.0)
+    sol = gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, support=("block", 2)))))
+    rmu, rvar = K.exactsolve(K.OK, Variogram("spherical", range=20.0), xy, z, grid.centroids(), support=((1.0, 1.0), 2))
+    assert np.max(np.abs(sol["z"] - rmu)) < 1e-9 and np.max(np.abs(sol["z_variance"] - rvar)) < 1e-9
+    with pytest.raises(ValueError, match="Cartesian grid"):
+        gss.solve(gss.EstimationProblem(gss.georef({"z": z}, xy), gss.PointSet(xy + 0.5), "z"),
+                  gss.KrigingSolver(("z", dict(variogram=vg, support="block"))))
+    with pytest.raises(NotImplementedError):
+        gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, support="block", maxneighbors=8))))
+    h = KrigHandle(vg, K.UK, xy, z, degree=2)
+    with pytest.raises(_lib.GSSError, match="degree <= 1"):
+        h.set_block_support((1.0, 1.0), 3)
+    h.close()
+    h = KrigHandle(vg, K.OK, xy, z, factor=False)
+    h.set_block_support((1.0, 1.0), 3)
+    with pytest.raises(_lib.GSSError, match="global neighbourhood only"):
+        h.predict_knn(grid.centroids()[:10], 8)
+    h.close()

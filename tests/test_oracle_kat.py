@@ -198,3 +198,30 @@ def test_nested_variogram_is_the_weighted_sum():
     assert np.allclose(cov_pairwise(nv, x, y), ref, atol=1e-15) and abs(cov_pairwise(nv, x, y)[0, 0] - 3.5) < 1e-15
     mu, var = K.exactsolve(K.OK, nv, x, RNG.normal(size=7), x)
     assert np.all(var < 1e-9)                                    # still exact at the data (zero lag = total sill)
+
+
+def test_block_support_kats():
+    """Block support (krig.jl:180 hands the grid cell to predictprob): implementation-independent facts of
+    the regularised system.  (1) The kriging weights are linear in the right-hand side, so the block mean equals the
+    average of the point means at the sample points -- exactly; (2) block -> point as the cell shrinks; (3) the block
+    variance is the point formula with C(V, V) in place of the sill and is never above the average point variance."""
+    from oracle.kriging import block_samples
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 20, (25, 2))
+    z = rng.normal(size=25)
+    cent = rng.uniform(2, 18, (7, 2))
+    for variant, kw, vg in ((K.OK, {}, Variogram("spherical", range=8.0, nugget=0.1)),
+                            (K.SK, dict(mean=0.3), Variogram("exponential", range=6.0)),
+                            (K.UK, dict(degree=1), Variogram("matern", range=9.0, nu=1.5))):
+        cell, nsub = (1.0, 2.0), 3
+        mu_b, var_b = K.exactsolve(variant, vg, x, z, cent, support=(cell, nsub), **kw)
+        off = block_samples(2, cell, nsub)
+        assert off.shape == (9, 2) and np.allclose(off.mean(axis=0), 0.0)
+        pts = (cent[:, None, :] + off[None, :, :]).reshape(-1, 2)
+        mu_p, var_p = K.exactsolve(variant, vg, x, z, pts, **kw)
+        assert np.max(np.abs(mu_b - mu_p.reshape(7, 9).mean(axis=1))) < 1e-12          # (1)
+        assert np.all(var_b <= var_p.reshape(7, 9).mean(axis=1) + 1e-12)                # (3)
+        mu_s, var_s = K.exactsolve(variant, vg, x, z, cent, support=((1e-7, 1e-7), 2), **kw)
+        mu_0, var_0 = K.exactsolve(variant, vg, x, z, cent, **kw)
+        tol = 1e-5 if vg.nugget == 0 else np.inf     # with a nugget C(V, V) -> sill - nugget, not sill: only the mean converges
+        assert np.max(np.abs(mu_s - mu_0)) < 1e-6 and np.max(np.abs(var_s - var_0)) < tol   # (2)
