@@ -36,7 +36,7 @@ struct TilesLds {
 };
 
 template <int DIM, int KIND, int NTMAX>
-__global__ __launch_bounds__(32 * NTMAX, 2) void krig_local_tiles_kernel(
+__global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_tiles_kernel(
     VgDev vg, LocalSpec sp, const double* __restrict__ xdata, const double* __restrict__ z,
     const double* __restrict__ drift_data, const double* __restrict__ x0, const double* __restrict__ drift_dom, int64_t m,
     int k, int minneighbors, const int* __restrict__ idx, const int* __restrict__ count, double* __restrict__ mean_out,

@@ -4,10 +4,19 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/round_end
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
-tail -1 $O/bench_n1.json | cut -c1-400
-timeout -k 10 600 python3 bench_configs.py --configs 1h,2,3,4,cond_fftgs,idw,lwr,sgs > $O/bench_configs.jsonl 2> $O/bench_configs.err || exit 1
+tail -1 $O/bench_n1.json | cut -c1-300
+timeout -k 10 900 python3 bench_configs.py --configs 1h,2,2h,3,4,bigk,lu,cond_fftgs,idw,lwr,sgs > $O/bench_configs.jsonl 2> $O/bench_configs.err || exit 1
+echo configs done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -o k -- python3 bench_configs.py --configs 4,idw,lwr > $O/cfg4_under_rocprof.jsonl 2> $O/rocprof4.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -o k -- python3 bench_configs.py --configs 4,bigk,idw,lwr > $O/cfg4_under_rocprof.jsonl 2> $O/rocprof4.err || exit 1
+echo stats done
+bash tools/pmc_run.sh $O/pmc_k5 -- bench_configs.py --configs 4 > $O/pmc_k5.log 2>&1
+python3 tools/pmc_summary.py $O/pmc_k5 krig_local > $O/pmc_k5_summary.txt 2>&1
+python3 tools/pmc_summary.py $O/pmc_k5 knn_pruned >> $O/pmc_k5_summary.txt 2>&1
+# keep what is small: the stats CSVs and the summaries (the traces and counter dumps are tens of MB)
+find $O -name "*kernel_stats.csv" | while read f; do cp "$f" "$O/$(echo $f | sed 's#/#_#g' | sed 's#.*round_end_##')"; done
+rm -rf $O/stats $O/stats4 $O/pmc_k5
+ls -la $O
 echo done
