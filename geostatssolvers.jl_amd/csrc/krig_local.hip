@@ -276,6 +276,38 @@ __device__ __forceinline__ void k5_block_step(d4_t (&T)[10], d4_t (&B)[4], const
   }
 }
 
+// The same step in two parts for the look-ahead order (GSS_K5_LOOKAHEAD, an experiment of round 3): the head produces
+// the next diagonal tile -- U_KK,KK+1 and A_KK+1,KK+1 -= U'U -- so that it can be handed to the factoring wave before
+// the rest of the step's products.
+template <int KK>
+__device__ __forceinline__ void k5_step_head(d4_t (&T)[10], const d4_t& V, int nt) {
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (KK + 1 < 4) {
+    if (KK + 1 < nt) {
+      T[tile_id(KK, KK + 1)] = xty(V, T[tile_id(KK, KK + 1)], zero4);
+      T[tile_id(KK + 1, KK + 1)] = xty(-T[tile_id(KK, KK + 1)], T[tile_id(KK, KK + 1)], T[tile_id(KK + 1, KK + 1)]);
+    }
+  }
+}
+template <int KK>
+__device__ __forceinline__ void k5_step_rest(d4_t (&T)[10], d4_t (&B)[4], const d4_t& V, int nt) {
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = KK + 2; j < 4; ++j)
+    if (j < nt) T[tile_id(KK, j)] = xty(V, T[tile_id(KK, j)], zero4);
+  B[KK] = xty(V, B[KK], zero4);
+#pragma unroll
+  for (int i = KK + 1; i < 4; ++i) {
+    if (i < nt) {
+      const d4_t N = -T[tile_id(KK, i)];
+#pragma unroll
+      for (int j = i; j < 4; ++j)
+        if (j < nt && !(i == KK + 1 && j == KK + 1)) T[tile_id(i, j)] = xty(N, T[tile_id(KK, j)], T[tile_id(i, j)]);
+      B[i] = xty(N, B[KK], B[i]);
+    }
+  }
+}
+
 // Four domain points per workgroup, one per wave.  The waves only meet for the diagonal tiles: the row broadcasts of
 // the 16 x 16 factorisation are local to a 16-lane row (tile16.h), so ONE wave factors the four waves' diagonal tiles
 // in its four lane rows for the issue cost of one, and the duty rotates with the block step (wave kk does step kk)
@@ -425,6 +457,39 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   }
   bool bad = false;
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+#ifdef GSS_K5_LOOKAHEAD
+  // look-ahead order (experiment, round 3; measured in DESIGN.md section 8): the diagonal tile of step kk + 1 is updated
+  // and handed over first, the wave on duty factors it while the others do the rest of step kk
+  {
+    double* mine0 = S4[0][wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine0[(g + 4 * r) * 17 + c] = (0 < nt) ? T[tile_id(0, 0)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
+    __syncthreads();
+    if (wave == 0) potrf16_inverse_x4(&S4[0][0][0], lane, badflag[0]);
+    __syncthreads();
+  }
+  static_for<0, 4>([&](auto KKc) {
+    constexpr int kk = decltype(KKc)::value;
+    double* mine = S4[kk & 1][wave];
+    d4_t V;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[r] = mine[(g + 4 * r) * 17 + c];
+    if (kk < nt) {
+      bad = bad || (badflag[kk & 1][wave] != 0);
+      k5_step_head<kk>(T, V, nt);
+    }
+    if constexpr (kk + 1 < 4) {
+      double* next = S4[(kk + 1) & 1][wave];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        next[(g + 4 * r) * 17 + c] = (kk + 1 < nt) ? T[tile_id(kk + 1, kk + 1)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
+      __syncthreads();
+      if (wave == kk + 1) potrf16_inverse_x4(&S4[(kk + 1) & 1][0][0], lane, badflag[(kk + 1) & 1]);
+    }
+    if (kk < nt) k5_step_rest<kk>(T, B, V, nt);
+    if constexpr (kk + 1 < 4) __syncthreads();
+  });
+#else
   // fully unrolled block steps (a rolled loop around one copy of the diagonal factorisation, with switch-selected
   // per-step code, shrinks the kernel from 84 KB to 53 KB but measured 5 % slower)
 #pragma unroll
@@ -449,6 +514,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
       }
     }
   }
+#endif
   if (bad && live) {
     if (lane == 0) {
       mean_out[p] = NaN;
