@@ -707,6 +707,46 @@ int32_t gss_shutdown(void) {
   return GSS_OK;
 }
 
+int32_t gss_dev_to_host(void* dst, const void* src_dev, int64_t bytes, void* stream) {
+  GSS_ENTRY();
+  GSS_REQUIRE(bytes >= 0 && (bytes == 0 || (dst != nullptr && src_dev != nullptr)), "gss_dev_to_host: bad arguments");
+  if (bytes == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  if (host_pointer_is_pinned(dst) && host_pointer_is_pinned(static_cast<char*>(dst) + bytes - 1)) {
+    GSS_HIP(hipMemcpyAsync(dst, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, s));
+    GSS_HIP(hipStreamSynchronize(s));
+    return GSS_OK;
+  }
+  // pageable destination: the bounce pipeline of OutStream (pieces of 32 MiB alternating over two copy streams, a host
+  // function behind each transfer copies the piece home with a few threads)
+  hipStream_t cs[2] = {helper_stream(HELPER_GEN2), helper_stream(HELPER_LOOKAHEAD)};
+  GSS_REQUIRE(cs[0] && cs[1] && bounce_buffer(0) && bounce_buffer(1), "gss_dev_to_host: no copy streams / pinned memory");
+  ScopedEvent ev;
+  GSS_HIP(ev.create());
+  GSS_HIP(hipEventRecord(ev, s));
+  GSS_HIP(hipStreamWaitEvent(cs[0], ev, 0));
+  GSS_HIP(hipStreamWaitEvent(cs[1], ev, 0));
+  int32_t rc = GSS_OK;
+  int64_t piece = 0;
+  for (int64_t off = 0; off < bytes && rc == GSS_OK; off += (int64_t)BOUNCE_BYTES, ++piece) {
+    const int b = (int)(piece & 1);
+    const size_t n = (size_t)(bytes - off < (int64_t)BOUNCE_BYTES ? bytes - off : (int64_t)BOUNCE_BYTES);
+    if (hipMemcpyAsync(g_bounce[b], static_cast<const char*>(src_dev) + off, n, hipMemcpyDeviceToHost, cs[b]) != hipSuccess) {
+      rc = GSS_ERR_HIP;
+      break;
+    }
+    BounceCopy* job = new BounceCopy{static_cast<char*>(dst) + off, static_cast<const char*>(g_bounce[b]), n};
+    if (hipLaunchHostFunc(cs[b], bounce_copy_fn, job) != hipSuccess) {
+      delete job;
+      rc = GSS_ERR_HIP;
+    }
+  }
+  (void)hipStreamSynchronize(cs[0]);   // whatever happened: nothing of this call is left in flight
+  (void)hipStreamSynchronize(cs[1]);
+  if (rc != GSS_OK) set_error("gss_dev_to_host: a transfer could not be queued");
+  return rc;
+}
+
 int32_t gss_trim_pool(void) {
   GSS_ENTRY();
   GSS_HIP(hipDeviceSynchronize());   // a cached block may still be read by work queued before its release

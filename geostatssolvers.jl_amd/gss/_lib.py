@@ -61,6 +61,7 @@ SIGNATURES = {
     "gss_shutdown": [],
     "gss_last_error": [C.c_char_p, _i32],
     "gss_synchronize": [_p],
+    "gss_dev_to_host": [_p, _p, _i64, _p],
     "gss_trim_pool": [],
     "gss_stat": [C.c_char_p, C.POINTER(_i64)],
     "gss_comm_unique_id": [_p],

@@ -74,6 +74,17 @@ def _prep_in(x, dtype=np.float64):
     return np.ascontiguousarray(x, dtype=dtype)
 
 
+def to_host(t):
+    """numpy copy of a contiguous CUDA tensor through the library's transfer path (gss_dev_to_host: pinned bounce
+    buffers, ~45 GB/s into pageable memory where `tensor.cpu()` manages ~10)."""
+    import torch
+    t = t.contiguous()
+    dt = {torch.float64: np.float64, torch.int32: np.int32, torch.uint8: np.uint8, torch.int64: np.int64}[t.dtype]
+    out = np.empty(tuple(t.shape), dtype=dt)
+    check(_lib.lib().gss_dev_to_host(ptr(out), C.c_void_p(t.data_ptr()), out.nbytes, current_stream()))
+    return out
+
+
 def _alias_tensor(owner, dev_ptr, nbytes):
     """CUDA float64 tensor aliasing `nbytes` of library-owned HBM at `dev_ptr` (for torch.distributed.broadcast over
     RCCL); it keeps `owner` (the handle) alive."""

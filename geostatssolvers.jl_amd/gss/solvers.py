@@ -630,7 +630,8 @@ def _fftgs_condition_on_device(self, q, cent, dinds, seed, first, count, inds):
         h.close()
     zu -= zbar_u
     zu += q["zbar"][None, :]                                                          # fft.jl:191
-    return zu.cpu().numpy()
+    from .engine import to_host
+    return to_host(zu)
 
 
 FFTGS._condition_on_device = _fftgs_condition_on_device

@@ -124,6 +124,11 @@ int32_t gss_init(int32_t device);          /* bind the calling process to `devic
 int32_t gss_shutdown(void);
 int32_t gss_last_error(char* buf, int32_t len);
 int32_t gss_synchronize(void* stream);
+/* Copy `bytes` from device memory (produced on `stream`) to host memory at the rate the simulation calls deliver their
+ * results: a page-locked destination directly, a pageable one through the library's pinned bounce buffers (pieces of
+ * 32 MiB, the host copy of one piece beside the transfer of the next).  For hosts that compose results on the device
+ * (the conditional branch fft.jl:176-192) and hand the reference's host vectors back.  Returns when the data are there. */
+int32_t gss_dev_to_host(void* dst, const void* src_dev, int64_t bytes, void* stream);
 /* Released device blocks are cached for re-use (up to GSS_POOL_MAX_MB, default a quarter of the device memory that
  * was free at the first allocation, at most 16 GiB); gss_trim_pool gives them all back to the driver -- for a host
  * program whose own allocator (torch, RCCL, rocFFT) has just failed.  Synchronises the device. */

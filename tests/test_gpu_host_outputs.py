@@ -110,3 +110,17 @@ def test_sgs_host_blocks_equal_device_outputs(per_realisation_paths, monkeypatch
     got = h.realize(21, 0, R)
     assert np.array_equal(got, ref.cpu().numpy())
     h.close()
+
+
+def test_dev_to_host_copies_exactly():
+    """gss_dev_to_host (the transfer path the twin uses for results composed on the device): pageable and page-locked
+    destinations, sizes around the 32 MiB pieces of the bounce pipeline, data produced on the current stream just before."""
+    import torch
+    from gss.engine import to_host
+    for n in (1, 1000, (32 << 20) // 8 - 1, (32 << 20) // 8 + 5, 3 * (32 << 20) // 8 + 17):
+        t = torch.arange(n, dtype=torch.float64, device="cuda") * 0.5 + 1.0
+        t = t * 2.0                                    # queued on the current stream: the copy must wait for it
+        got = to_host(t)
+        assert got.shape == (n,) and got[0] == 2.0 and got[-1] == (n - 1) + 2.0 and np.array_equal(got, t.cpu().numpy())
+    ti = torch.arange(12, dtype=torch.int32, device="cuda").reshape(3, 4)
+    assert np.array_equal(to_host(ti), np.arange(12, dtype=np.int32).reshape(3, 4))
