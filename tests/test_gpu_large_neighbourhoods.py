@@ -37,9 +37,12 @@ CASES = [(K.OK, {}, "matern", dict(range=30.0, nu=1.5)),
 
 
 @pytest.mark.parametrize("variant,okw,kind,vkw", CASES)
-@pytest.mark.parametrize("n,m,dim,k", [(500, 120, 3, 65), (900, 100, 3, 128), (1500, 60, 2, 170), (1200, 40, 3, 260)])
+@pytest.mark.parametrize("n,m,dim,k", [(500, 120, 3, 65), (900, 100, 3, 128), (1500, 60, 2, 170), (1200, 40, 3, 260),
+                                       (1400, 50, 3, 192), (1600, 40, 2, 256)])
 def test_local_kriging_with_more_than_64_neighbours(variant, okw, kind, vkw, n, m, dim, k):
-    """k' + constraints up to ~180 rows: system in LDS; beyond: per-workgroup slab in HBM (k = 260 here)."""
+    """65 .. 256 neighbours: the register-distributed tile kernel (4 waves up to 128, 8 waves up to 256; 128, 192 and 256
+    fill their tile counts exactly, 65 / 170 leave the last tile ragged and waves without a column pair); beyond
+    256 (k = 260 here) the scalar kernel with its system in a per-workgroup slab."""
     import gss
     from gss.engine import KrigHandle
     ctor = dict(exponential=gss.ExponentialVariogram, spherical=gss.SphericalVariogram, matern=gss.MaternVariogram)[kind]
@@ -120,3 +123,46 @@ def test_idw_lwr_with_more_than_64_neighbours(n, m, dim, k):
     assert np.array_equal(st, rst)
     ok = st == 0
     assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-10
+
+
+def test_many_neighbours_anisotropic_nested_and_external_drift():
+    """The many-neighbour kernel's model-specific instantiations divide the coordinates by the radii of the model's
+    ball once per point (anisotropic exponential model); a nested model and a Gaussian one take the general
+    instantiation; an external drift supplies its own right-hand-side columns.  k = 100, against the oracle, 1e-9
+    (Gaussian: 1e-6)."""
+    import gss
+    from gss.engine import KrigHandle
+    from oracle.variogram import Nested
+    rng = np.random.default_rng(33)
+    x = rng.uniform(0, 100, (900, 3))
+    z = np.sin(x[:, 0] / 20.0) + 0.02 * x[:, 1] + 0.2 * rng.normal(size=900)
+    x0 = rng.uniform(5, 95, (60, 3))
+    cases = [
+        (gss.ExponentialVariogram(gss.MetricBall((40.0, 20.0, 10.0)), nugget=0.05),
+         Variogram("exponential", radii=(40.0, 20.0, 10.0), nugget=0.05), 1e-9),
+        (0.6 * gss.SphericalVariogram(range=30.0, nugget=0.05) + 0.4 * gss.ExponentialVariogram(range=60.0),
+         Nested([(0.6, Variogram("spherical", range=30.0, nugget=0.05)), (0.4, Variogram("exponential", range=60.0))]), 1e-9),
+        (gss.GaussianVariogram(range=15.0, nugget=0.05), Variogram("gaussian", range=15.0, nugget=0.05), 1e-6),
+    ]
+    for gvg, ovg, tol in cases:
+        h = KrigHandle(gvg, K.OK, x, z, factor=False)
+        mu, var, st = h.predict_knn(x0, 100)
+        h.close()
+        rmu, rvar, rst = K.approxsolve(K.OK, ovg, x, z, x0, 100)
+        assert not st.any() and np.max(np.abs(mu - rmu)) < tol and np.max(np.abs(var - rvar)) < tol
+    # 1-D (the general instantiation); a nugget keeps 100 collinear neighbours of a smooth model well conditioned
+    x1 = rng.uniform(0, 100, (300, 1))
+    z1 = rng.normal(size=300)
+    h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5, nugget=0.1), K.UK, x1, z1, degree=1, factor=False)
+    mu, var, st = h.predict_knn(x0[:, :1], 100)
+    h.close()
+    rmu, rvar, rst = K.approxsolve(K.UK, Variogram("matern", range=30.0, nu=1.5, nugget=0.1), x1, z1, x0[:, :1], 100, degree=1)
+    assert not st.any() and np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
+    fd = np.c_[np.ones(900), x[:, 0] / 100.0, (x[:, 1] / 100.0) ** 2]
+    f0 = np.c_[np.ones(60), x0[:, 0] / 100.0, (x0[:, 1] / 100.0) ** 2]
+    gvg, ovg = gss.MaternVariogram(range=30.0, order=1.5, nugget=0.02), Variogram("matern", range=30.0, nu=1.5, nugget=0.02)
+    h = KrigHandle(gvg, K.EDK, x, z, drift_data=fd, factor=False)
+    mu, var, st = h.predict_knn(x0, 100, drift_dom=f0)
+    h.close()
+    rmu, rvar, rst = K.approxsolve(K.EDK, ovg, x, z, x0, 100, drift_data=fd, drift_dom=f0)
+    assert not st.any() and np.max(np.abs(mu - rmu)) < 1e-9 and np.max(np.abs(var - rvar)) < 1e-9
