@@ -362,9 +362,12 @@ def fftgs_leg(c):
     # SURVEY 8d's second number: the same realisations delivered to HOST memory, as the reference returns them
     # (fft.jl:173,197).  The library streams them out chunk by chunk behind the computation (csrc OutStream); beside it
     # the plain device -> pinned-host copy rate of this box, which bounds it.
+    # (rank-local measurement inside the try, the collectives outside it: a rank that fails must not leave the
+    # others alone in a barrier)
+    import numpy as np
+    Rh = max(2, min(8, R))
+    loc, err_h = None, None
     try:
-        import numpy as np
-        Rh = max(2, min(8, R))
         hbuf = torch.empty((Rh, N), dtype=torch.float64, pin_memory=True)
         hbuf.zero_()
         torch.cuda.synchronize()
@@ -373,11 +376,9 @@ def fftgs_leg(c):
         torch.cuda.synchronize()
         copy_gbs = B * N * 8 / (time.perf_counter() - t0) / 1e9
         f.realize(4, rank * R, 1, out=hbuf[:1])                       # warm: bounce buffers, ring blocks
-        c["barrier"]()
         t0 = time.perf_counter()
-        f.realize(4, rank * R, Rh, out=hbuf)
-        c["barrier"]()
-        dth = c["max_over_ranks"](time.perf_counter() - t0)
+        f.realize(4, rank * R, Rh, out=hbuf)                          # returns when the last byte has arrived
+        dt_local = time.perf_counter() - t0
         staged = _lib.stat("out_ring_bytes")
         same = bool(torch.equal(hbuf[0].cuda(), f.realize(4, rank * R, 1, out=obuf[:1])[0]))
         pg = np.empty((2, N))
@@ -385,16 +386,24 @@ def fftgs_leg(c):
         t0 = time.perf_counter()
         f.realize(4, rank * R, 2, out=pg)
         dtp = time.perf_counter() - t0
-        res["with_d2h"] = {"value": round(world * Rh / dth, 2), "unit": "realisations/s",
-                           "realisations_per_gpu": Rh, "destination": "page-locked host memory",
-                           "achieved_GBs": round(Rh * N * 8 / dth / 1e9, 2), "pcie_copy_rate_GBs": round(copy_gbs, 2),
-                           "frac_of_copy_rate": round(Rh * N * 8 / dth / 1e9 / copy_gbs, 3),
-                           "hbm_staged_bytes": staged, "bit_identical_to_device_path": same,
-                           "pageable": {"value": round(2 / dtp, 2), "GBs": round(2 * N * 8 / dtp / 1e9, 2),
-                                        "note": "numpy destination: pinned bounce buffers + host copies in stream order"}}
+        loc = dict(dt=dt_local, copy_gbs=copy_gbs, staged=staged, same=same, dtp=dtp)
         del hbuf, pg
     except Exception as err:                                          # noqa: BLE001 -- the leg must not lose the line
-        res["with_d2h"] = {"error": repr(err)}
+        err_h = repr(err)
+    failed = c["max_over_ranks"](0.0 if loc is not None else 1.0) > 0.0
+    dth = c["max_over_ranks"](loc["dt"] if loc is not None else 0.0)   # slowest rank (all ranks transfer at once)
+    if failed or loc is None:
+        res["with_d2h"] = {"error": err_h or "a peer rank failed"}
+    else:
+        res["with_d2h"] = {"value": round(world * Rh / dth, 2), "unit": "realisations/s",
+                           "realisations_per_gpu": Rh, "destination": "page-locked host memory",
+                           "achieved_GBs": round(Rh * N * 8 / dth / 1e9, 2),
+                           "pcie_copy_rate_GBs": round(loc["copy_gbs"], 2),
+                           "frac_of_copy_rate": round(Rh * N * 8 / loc["dt"] / 1e9 / loc["copy_gbs"], 3),
+                           "hbm_staged_bytes": loc["staged"], "bit_identical_to_device_path": loc["same"],
+                           "pageable": {"value": round(2 / loc["dtp"], 2), "GBs": round(2 * N * 8 / loc["dtp"] / 1e9, 2),
+                                        "note": "numpy destination: pinned bounce buffers + host copies in stream order"},
+                           "note": "per-GPU figures (achieved, copy rate, pageable) are rank 0's; value = all ranks / slowest rank"}
     tfile = _latest_profile("fftgs_512_pmc_traffic.json")
     if e == 512 and tfile:
         tj = json.load(open(tfile))
