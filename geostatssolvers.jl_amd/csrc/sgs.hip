@@ -774,10 +774,14 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
   h->path_base = path_base;
   h->filter_after = (flags & GSS_SGS_MASK_AFTER_SEARCH) ? 1 : 0;
   const int metric = (flags >> GSS_SGS_METRIC_SHIFT) & 7;
-  GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV,
-              "gss_sgs_create: search distance %d -- Euclidean, Cityblock or Chebyshev (the haversine distance has no "
-              "masked search)", metric);
-  GSS_TRY(check_metric(metric, 0.0, dim, radius, inv_radii));   // a ball only with the Euclidean distance (ui.jl:25-31)
+  // Haversine(r) (seq.jl:91-98 hands `distance` to the searcher): its ranking key does not depend on r and has no box
+  // bounds, so it runs on the exhaustive search -- which exists unmasked only: available with the mask applied to the
+  // search result (GSS_SGS_MASK_AFTER_SEARCH, the front-ends' default), not for the masked search
+  GSS_REQUIRE(metric == GSS_METRIC_EUCLIDEAN || metric == GSS_METRIC_CITYBLOCK || metric == GSS_METRIC_CHEBYSHEV ||
+                  (metric == GSS_METRIC_HAVERSINE && h->filter_after),
+              "gss_sgs_create: search distance %d -- Euclidean, Cityblock or Chebyshev; Haversine only with "
+              "GSS_SGS_MASK_AFTER_SEARCH (there is no masked exhaustive search)", metric);
+  GSS_TRY(check_metric(metric, 1.0, dim, radius, inv_radii));   // a ball only with the Euclidean distance (ui.jl:25-31)
   const int64_t P = npaths;
 
   // visiting rank of every cell (-1 = conditioning cell) per path; each path must be a permutation of 0..N-1
@@ -835,7 +839,10 @@ int32_t gss_sgs_create_paths(gss_sgs_t** out, const gss_variogram_t* vg, double 
       if (h->filter_after) {   // one unmasked search serves every path: k nearest cells of the whole domain
         if (pp == 0) {
           GSS_TRY(rawidx.alloc(sizeof(int) * (size_t)(N * h->k)));
-          if (h->k > SGS_MAX_K)
+          if (metric == GSS_METRIC_HAVERSINE)   // exhaustive (passes of 64 beyond 64 neighbours)
+            GSS_TRY(knn_search_dev(cent.as<double>(), N, dim, cent.as<double>(), N, h->k, -1.0, nullptr, rawidx.as<int>(),
+                                   cnt.as<int>(), s, metric));
+          else if (h->k > SGS_MAX_K)
             GSS_TRY(knn_search_indexed_any(ix, cent.as<double>(), cent.as<double>(), N, h->k, radius, inv_radii,
                                            rawidx.as<int>(), cnt.as<int>(), s, metric));
           else

@@ -789,8 +789,9 @@ class SGS(_Solver):
         for (var,) in [g for g in self.covariables(problem)]:
             p = self.params(var)
             dist = _distance(p)                                                        # seq.jl:91-98
-            if dist is not None and not isinstance(dist, str):
-                raise NotImplementedError("the haversine search distance is not available in SGS on the device")
+            if dist is not None and not isinstance(dist, str) and self.globals.get("mask", "after") != "after":
+                raise NotImplementedError("the haversine search distance needs mask='after' in SGS on the device "
+                                          "(the masked search has no exhaustive variant)")
             path = p["path"]
             order = path_seed = None
             if path is None or (isinstance(path, str) and path == "linear"):

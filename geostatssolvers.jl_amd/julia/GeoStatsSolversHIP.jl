@@ -910,8 +910,8 @@ function sgs_preprocess(problem::SimulationProblem, solver::SGSHIP; compute=true
   for covars in covariables(problem, solver), var in covars.names
     p = covars.params[Set([var])]
     metric, _ = searchmetric(p)                                           # seq.jl:91-98; a ball replaces the metric
-    metric == Int32(3) &&   # GSS_METRIC_HAVERSINE
-      throw(ArgumentError("SGSHIP: the haversine search distance is not available (no masked exhaustive search)"))
+    # (GSS_METRIC_HAVERSINE runs on the exhaustive search, which the library offers for the mask-after-search reading
+    # this shim always passes)
     dlocs = Int64.(findall(mask[var]) .- 1)
     zdata = Float64.(buff[var][mask[var]])
     k = p.maxneighbors

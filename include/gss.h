@@ -363,8 +363,8 @@ int32_t gss_lugs_realize(gss_lugs_t* h, uint64_t seed, int64_t first_real, int64
  * to do (the mask is applied to the result of the tree query); the front-ends pass it by default. */
 enum { GSS_SGS_MASK_AFTER_SEARCH = 1 };
 /* bits 4..6 of flags: GSS_METRIC_* of the neighbour search (the solver parameter `distance`, seq.jl:91-98):
- * Euclidean (0, the only one that combines with a ball), Cityblock or Chebyshev; the haversine distance is refused
- * (the masked search has no exhaustive variant). */
+ * Euclidean (0, the only one that combines with a ball), Cityblock or Chebyshev; Haversine (its key has no box bounds:
+ * exhaustive search) with GSS_SGS_MASK_AFTER_SEARCH only -- the masked search has no exhaustive variant. */
 #define GSS_SGS_METRIC_SHIFT 4
 int32_t gss_sgs_create(gss_sgs_t** out, const gss_variogram_t* vg, double mean, const double* centroids, int64_t N,
                        int32_t dim, const int64_t* path, const int64_t* dlocs, const double* zdata, int64_t nd,

@@ -126,8 +126,39 @@ def test_search_distance_parameter(distance, mask_after):
     assert np.all(np.isfinite(sol["z"][1])) and np.max(np.abs(sol["z"][1] - sole["z"][1])) > 1e-6
     with pytest.raises(_lib.GSSError, match="ball"):
         SGSHandle(gvg, cent, None, dl, zd, 0.0, 8, 1, 5.0, distance=distance)
-    with pytest.raises(_lib.GSSError, match="haversine"):
+    with pytest.raises(_lib.GSSError, match="Haversine only with"):      # no masked exhaustive search
         SGSHandle(gvg, cent, None, dl, zd, 0.0, 8, 1, distance=("haversine", 1.0))
+
+
+def test_haversine_search_distance_with_the_mask_after_search():
+    """`distance = Haversine(r)` (seq.jl:91-98; the reference accepts any Distances.jl metric): the key has no box bounds,
+    so the search is exhaustive -- available for the reading in which the mask filters the search result (the front-ends'
+    default).  (longitude, latitude) cells near 60 degrees north, where a degree of longitude is half a degree of
+    latitude: the neighbourhoods differ from the Euclidean ones.  12 and 70 neighbours, handle and solve."""
+    import gss
+    from gss.engine import SGSHandle
+    gvg, ovg = _vg("exponential", range=6.0, sill=0.8)
+    rng = np.random.default_rng(23)
+    cent = offt.grid_centroids((24, 18), (10.0, 55.0), (0.5, 0.5)) + rng.uniform(-0.1, 0.1, (24 * 18, 2))
+    N = cent.shape[0]
+    dl = np.sort(rng.choice(N, 8, replace=False))
+    zd = rng.normal(size=8)
+    path = rng.permutation(N)
+    dist = ("haversine", 6371.0)
+    for k in (12, 70):
+        h = SGSHandle(gvg, cent, path, dl, zd, 0.0, k, 1, mask_after_search=True, distance=dist)
+        z = h.realize(5, 0, 2)
+        h.close()
+        ref = S.realize(ovg, 0.0, cent, path, dl, zd, 5, 0, 2, maxneighbors=k, mask_after_search=True, distance=dist)
+        assert np.max(np.abs(z - ref)) < 1e-9
+        refe = S.realize(ovg, 0.0, cent, path, dl, zd, 5, 0, 2, maxneighbors=k, mask_after_search=True)
+        assert np.max(np.abs(ref - refe)) > 1e-6
+    grid = gss.CartesianGrid((20, 15), (10.0, 55.0), (0.5, 0.5))
+    prob = gss.SimulationProblem(gss.georef({"z": zd[:3]}, grid.centroids()[[7, 111, 250]]), grid, "z", 2)
+    sol = gss.solve(prob, gss.SGS(("z", dict(variogram=gvg, maxneighbors=9, distance=dist)), rng=4))
+    assert np.all(np.isfinite(sol["z"][1]))
+    with pytest.raises(NotImplementedError, match="mask='after'"):
+        gss.solve(prob, gss.SGS(("z", dict(variogram=gvg, maxneighbors=9, distance=dist)), rng=4, mask="during"))
 
 
 def test_solver_front_end_with_ninety_neighbours():
