@@ -19,6 +19,7 @@ namespace gss {
 
 struct EstSpec {
   int method;       // 0 = IDW, 1 = LWR
+  const double* wsup;   // LWR: weights supplied per (point, neighbour) instead of wkind (gss_lwr_predict_weights)
   int wkind;        // GSS_WEIGHT_*
   double exponent;  // IDW
   double wa, wp;    // LWR weight parameters
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
     return;
   }
   double mu, var;
-  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  const bool ok = (sp.wsup != nullptr || dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
   mean_out[p] = ok ? mu : NaN;
   aux_out[p] = ok ? var : NaN;
   status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
@@ -608,7 +609,8 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
 #pragma unroll
     for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
     const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
-    const double w = lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
+    const double w = sp.wsup ? sp.wsup[p * k + j]
+                             : lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
     double u[NP];
     u[0] = 1.0;
 #pragma unroll
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
     }
   }
   double mu, var;
-  const bool ok = (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+  const bool ok = (sp.wsup != nullptr || dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
   mean_out[p] = ok ? mu : NaN;
   aux_out[p] = ok ? var : NaN;
   status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
@@ -838,6 +840,54 @@ int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t
   sp.mparam = metric_param;
   return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, dist, status, mem,
                      stream);
+}
+
+int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
+                                int32_t k, int32_t minneighbors, const int32_t* idx, const int32_t* count,
+                                const double* weights, double* mean, double* var, uint8_t* status, int32_t mem,
+                                void* stream) {
+  GSS_ENTRY();
+  GSS_REQUIRE(n >= 1 && n < INT_MAX && dim >= 1 && dim <= 3 && k >= 1 && k <= n, "gss_lwr_predict_weights: bad sizes");
+  GSS_REQUIRE(m >= 0 && (m == 0 || (xdata && z && xdom && idx && count && weights && mean && var)), "NULL array");
+  if (m == 0) return GSS_OK;
+  hipStream_t s = to_stream(stream);
+  Staged sxd, sz, sx, si, sc, sw, smean, svar, sstat;
+  GSS_TRY(sxd.in(xdata, sizeof(double) * n * dim, mem, s));
+  GSS_TRY(sz.in(z, sizeof(double) * n, mem, s));
+  GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
+  GSS_TRY(si.in(idx, sizeof(int32_t) * (size_t)(m * k), mem, s));
+  GSS_TRY(sc.in(count, sizeof(int32_t) * (size_t)m, mem, s));
+  GSS_TRY(sw.in(weights, sizeof(double) * (size_t)(m * k), mem, s));
+  GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
+  GSS_TRY(svar.out(var, sizeof(double) * m, mem));
+  DevBuf st_own;
+  uint8_t* st = nullptr;
+  if (status) {
+    GSS_TRY(sstat.out(status, (size_t)m, mem));
+    st = sstat.as<uint8_t>();
+  } else {
+    GSS_TRY(st_own.alloc((size_t)m));
+    st = st_own.as<uint8_t>();
+  }
+  EstSpec sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.method = 1;
+  sp.wsup = sw.as<double>();
+  const dim3 grid((unsigned)((m + 255) / 256));
+#define GSS_LWRW_ARGS sp, sxd.as<double>(), sz.as<double>(), sx.as<double>(), m, (int)k, (int)minneighbors, si.as<int>(), \
+                      sc.as<int>(), 0, 1.0, 1.0, 1.0, smean.as<double>(), svar.as<double>(), st
+  switch (dim) {
+    case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+    case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+    default: hipLaunchKernelGGL((est_list_kernel<3>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+  }
+#undef GSS_LWRW_ARGS
+  GSS_HIP(hipGetLastError());
+  GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
+  GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));
+  if (status) GSS_TRY(sstat.back(status, (size_t)m, mem, s));
+  GSS_HIP(hipStreamSynchronize(s));   // the staged copies are released on return
+  return GSS_OK;
 }
 
 int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,

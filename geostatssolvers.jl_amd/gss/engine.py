@@ -509,5 +509,48 @@ class HipEngine:
                                    minneighbors, radius, radii, distance)
 
 
+    @staticmethod
+    def lwr_callable(xdata, z, xdom, k, minneighbors, weightfun, radius=None, radii=None, distance=None):
+        """LWR with an arbitrary `weightfun` callable (lwr.jl:58,136): the search runs on the device, delta = d / max d
+        and w = weightfun(delta) are evaluated here on the host (the callable cannot cross the C-ABI), the normal
+        equations and norm(r) on the device again (gss_lwr_predict_weights).  Host arrays."""
+        x = np.ascontiguousarray(xdata, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        zz = np.ascontiguousarray(z, dtype=np.float64)
+        c = np.ascontiguousarray(xdom, dtype=np.float64).reshape(-1, x.shape[1])
+        m = c.shape[0]
+        idx, cnt = HipEngine.knn_search(x, c, k, radius, radii, distance)
+        valid = np.arange(k)[None, :] < cnt[:, None]
+        nb = np.where(valid, idx, 0)
+        diff = x[nb] - c[:, None, :]                              # m x k x d
+        name = "euclidean" if distance is None else (distance if isinstance(distance, str) else distance[0])
+        if radii is not None:
+            diff = diff / np.asarray(radii, dtype=np.float64)
+        if name == "euclidean":
+            d = np.sqrt(np.sum(diff * diff, axis=-1))
+        elif name == "cityblock":
+            d = np.sum(np.abs(diff), axis=-1)
+        elif name == "chebyshev":
+            d = np.max(np.abs(diff), axis=-1)
+        else:                                                    # ("haversine", r): (longitude, latitude) in degrees
+            D = np.pi / 180.0
+            s1 = np.sin((c[:, None, 1] - x[nb][..., 1]) * 0.5 * D)
+            s2 = np.sin((c[:, None, 0] - x[nb][..., 0]) * 0.5 * D)
+            key = s1 * s1 + np.cos(x[nb][..., 1] * D) * np.cos(c[:, None, 1] * D) * (s2 * s2)
+            d = 2.0 * float(distance[1]) * np.arcsin(np.minimum(np.sqrt(key), 1.0))
+        d = np.where(valid, d, 0.0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            delta = d / d.max(axis=1, keepdims=True)             # lwr.jl:132
+        w = np.where(valid, np.asarray(weightfun(delta), dtype=np.float64), 0.0)   # lwr.jl:136
+        w = np.ascontiguousarray(np.nan_to_num(w, nan=0.0))
+        mean, var, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
+        check(_lib.lib().gss_lwr_predict_weights(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k),
+                                                 int(minneighbors), ptr(np.ascontiguousarray(idx)),
+                                                 ptr(np.ascontiguousarray(cnt)), ptr(w), ptr(mean), ptr(var), ptr(st),
+                                                 MEM_HOST, current_stream()))
+        return mean, var, st
+
+
 def default_engine():
     return HipEngine

@@ -481,8 +481,11 @@ class LWRSolver(_NeighborEstimator):
     def _estimate(self, p, x, z, xdom, k, nmin, radius, radii):
         wf = p["weightfun"] or ExpWeight()
         if not hasattr(wf, "spec"):
-            raise NotImplementedError("weightfun must be ExpWeight(a, p) or TricubeWeight(): the weights are "
-                                      "evaluated inside the device kernel, arbitrary callables cannot cross the C-ABI")
+            # an arbitrary callable h -> weight (lwr.jl:58): it cannot cross the C-ABI, so the weights are evaluated on
+            # the host between the device's search and the device's normal equations (engine.lwr_callable)
+            if not callable(wf) or not hasattr(self.engine, "lwr_callable"):
+                raise NotImplementedError("weightfun must be ExpWeight(a, p), TricubeWeight() or a callable h -> weight")
+            return self.engine.lwr_callable(x, z, xdom, k, nmin, wf, radius, radii, distance=_distance(p))
         return self.engine.lwr(x, z, xdom, k, nmin, wf.spec(), radius, radii, distance=_distance(p))
 
 

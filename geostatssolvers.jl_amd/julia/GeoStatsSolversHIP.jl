@@ -34,6 +34,7 @@ using Tables
 using Random
 using Unitful
 using LinearAlgebra: cholesky, lu      # values of LUGS' `factorization` parameter (lu.jl:70)
+using Distances: evaluate              # the search metric applied to a pair of points (closure weights of LWR)
 using Distributed: myid, remotecall_fetch
 
 import GeoStatsBase: solve, preprocess, solvesingle
@@ -332,7 +333,7 @@ struct TricubeWeight end         # h -> (1 - h^3)^3
 (::TricubeWeight)(h) = (1 - h^3)^3
 weightspec(w::ExpWeight) = (Int32(0), w.a, w.p)
 weightspec(::TricubeWeight) = (Int32(1), 0.0, 0.0)
-weightspec(f) = throw(ArgumentError("weightfun must be ExpWeight(a, p) or TricubeWeight(): weights are evaluated on the device"))
+weightspec(f) = throw(ArgumentError("weightfun of this kind is evaluated on the host (lwr_with_closure)"))
 
 @estimsolver IDWSolverHIP begin
   @param minneighbors = 1
@@ -400,8 +401,33 @@ solve(problem::EstimationProblem, solver::IDWSolverHIP) =
           status, GSS_MEM_HOST, C_NULL)
   end)
 
+# an arbitrary `weightfun` closure (lwr.jl:58) cannot cross the C-ABI: the device searches, the weights are evaluated
+# here, the device solves the normal equations (gss_lwr_predict_weights)
+function lwr_with_closure(p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status)
+  met, mpar = searchmetric(p)
+  idx = Matrix{Int32}(undef, k, m); cnt = Vector{Int32}(undef, m)          # k x m == m x k row-major
+  GC.@preserve X X0 ir idx cnt check(ccall((:gss_knn_search, libgss), Int32,
+    (Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Float64, Ptr{Float64}, Int32, Float64, Ptr{Int32},
+     Ptr{Int32}, Int32, Ptr{Cvoid}), X, n, Int32(d), X0, m, k, radius, ir, met, mpar, idx, cnt, GSS_MEM_HOST, C_NULL))
+  dist = isnothing(p.neighborhood) ? p.distance : metric(p.neighborhood)   # what the searcher ranks by (ui.jl:25-31)
+  W = zeros(Float64, k, m)
+  for j in 1:m
+    c = Int(cnt[j])
+    c == 0 && continue
+    ds = [evaluate(dist, view(X, :, Int(idx[i, j]) + 1), view(X0, :, j)) for i in 1:c]
+    δs = ds ./ maximum(ds)                                                  # lwr.jl:132
+    W[1:c, j] .= p.weightfun.(δs)                                           # lwr.jl:136
+  end
+  GC.@preserve X z X0 idx cnt W μ aux status ccall((:gss_lwr_predict_weights, libgss), Int32,
+    (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+     Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+    X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), idx, cnt, W, μ, aux, status, GSS_MEM_HOST, C_NULL)
+end
+
 solve(problem::EstimationProblem, solver::LWRSolverHIP) =
   neighbor_estimate(problem, solver, "_variance", u -> u^2, (p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status) -> begin   # lwr.jl:153
+    p.weightfun isa Union{ExpWeight,TricubeWeight} ||
+      return lwr_with_closure(p, X, z, n, d, X0, m, k, radius, ir, μ, aux, status)
     wk, wa, wp = weightspec(p.weightfun)
     met, mpar = searchmetric(p)
     ccall((:gss_lwr_predict, libgss), Int32,

@@ -282,6 +282,14 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
                         int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
                         int32_t metric, double metric_param, int32_t weight_kind, double weight_a,
                         double weight_p, double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
+/* LWR with the neighbours' weights supplied by the caller, for weight functions that cannot cross the ABI -- an arbitrary
+ * `weightfun` closure (lwr.jl:58,136): the host searches (gss_knn_search), evaluates delta = d / max d and w = f(delta)
+ * itself and hands over idx (m x k, 0-based, as the search wrote it), count (m) and weights (m x k); the rest of
+ * lwr.jl:137-145 (normal equations about the estimation point, norm(r)) runs here. */
+int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
+                                int32_t k, int32_t minneighbors, const int32_t* idx, const int32_t* count,
+                                const double* weights, double* mean, double* var, uint8_t* status, int32_t mem,
+                                void* stream);
 
 /* ---- FFTGS ------------------------------------------------------------------------------
  * gss_fftgs_create replaces preprocess fft.jl:62-103 (unconditional part): covariance to the
