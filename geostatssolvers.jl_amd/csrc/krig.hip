@@ -544,7 +544,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s, int metric, HostPipe* pipe = nullptr);
+                       int* count_out, hipStream_t s, int metric, HostPipe* pipe = nullptr, int block_nsub = 0,
+                       const double* block_cell = nullptr, double block_cvv = 0.0);
 }
 
 
@@ -1202,10 +1203,7 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
                              int32_t* count_out, int32_t mem, void* stream) {
   GSS_ENTRY();
   GSS_REQUIRE(h != nullptr, "NULL handle");
-  if (h->block_nsub > 0) {
-    set_error("block support is available with the global neighbourhood only (gss_krig_predict_global)");
-    return GSS_ERR_UNSUPPORTED;
-  }
+
   GSS_TRY(check_metric(metric, metric_param, h->dim, radius, inv_radii));
   GSS_REQUIRE(m >= 0 && (m == 0 || (xdom && mean && var)), "gss_krig_predict_knn: NULL array");
   GSS_REQUIRE(k >= 1 && k <= h->n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
@@ -1242,7 +1240,8 @@ int32_t gss_krig_predict_knn(gss_krig_t* h, const double* xdom, const double* dr
   GSS_TRY(krig_local_dev(h->vg, h->variant, h->nc, dim, &h->ds.e[0][0], h->ds.inv_scale[0], h->sk_mean,
                          h->xdata.as<double>(), h->z.as<double>(), h->drift_data.as<double>(), h->n,
                          sx.as<double>(), sd.as<double>(), m, k, minneighbors, radius, inv_radii, smean.as<double>(),
-                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s, metric, &pipe));
+                         svar.as<double>(), sstat.as<uint8_t>(), sidx.as<int>(), scnt.as<int>(), s, metric, &pipe,
+                         h->block_nsub, h->block_cell, h->block_cvv));
   if (pipe.on) return GSS_OK;   // everything is home (krig_local_dev ends with pipe.finish)
   GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
   GSS_TRY(svar.back(var, sizeof(double) * m, mem, s));

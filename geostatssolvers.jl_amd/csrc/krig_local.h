@@ -18,7 +18,37 @@ struct LocalSpec {
   signed char e[LMAX_NC][3];
   double inv_scale;  // monomial scaling (1 / data extent), conditioning only
   double sk_mean;
+  // block support (gss_krig_set_block_support): c0 is the mean covariance to the bsub^dim sub-cell centres of a cell of
+  // size bcell about the estimation point; c00 = mean covariance between two of them (the sill for point support)
+  int bsub;
+  double bcell[3];
+  double c00;
 };
+
+// c0 entry of one neighbour.  xs: the neighbour (already divided by the radii of the model's ball when KIND >= 0 and the
+// model is anisotropic), c: the estimation point as given, cs: the same scaled like xs.  Point support: one covariance;
+// block support: the mean over the sub-cell centres, first axis slowest as in the oracle.
+template <int DIM, int KIND>
+__device__ __forceinline__ double c0_entry(const VgDev& vg, const LocalSpec& sp, const double* xs, const double* c,
+                                           const double* cs) {
+  if (sp.bsub <= 0) return cov_pair_k<DIM, KIND>(vg, xs, cs);
+  const int nsub = sp.bsub;
+  const int ns = DIM == 1 ? nsub : (DIM == 2 ? nsub * nsub : nsub * nsub * nsub);
+  double acc = 0.0;
+  for (int s = 0; s < ns; ++s) {
+    int q = s;
+    double pt[DIM];
+#pragma unroll
+    for (int a = DIM - 1; a >= 0; --a) {
+      const int ia = q % nsub;
+      q /= nsub;
+      const double v = c[a] + (((double)ia + 0.5) / (double)nsub - 0.5) * sp.bcell[a];
+      pt[a] = (KIND >= 0 && vg.aniso) ? v * vg.ir[a] : v;
+    }
+    acc += cov_pair_k<DIM, KIND>(vg, xs, pt);
+  }
+  return acc / (double)ns;
+}
 
 
 // Block elimination on the (2 + nc) x (2 + nc) Gram matrix G = Y'Y of the forward-substituted right-hand sides
@@ -76,7 +106,7 @@ __device__ __forceinline__ void gram_finish(const double (*G)[17], const signed 
       status_out[p] = GSS_PT_SINGULAR;
     } else {
       const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
-      const double vv = vg.sill - qf + rsr;
+      const double vv = sp.c00 - qf + rsr;
       mean_out[p] = mu;
       var_out[p] = vv > 0.0 ? vv : 0.0;
       status_out[p] = GSS_PT_OK;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
       double xj[DIM];
 #pragma unroll
       for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
-      M[ntri + j] = cov_pair<DIM>(vg, xj, c0);
+      M[ntri + j] = c0_entry<DIM, -1>(vg, sp, xj, c0, c0);
       double zz = z[nj];
       if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
       M[ntri + K1 + j] = zz;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
         status_out[p] = GSS_PT_SINGULAR;
       } else {
         const double mu = (sp.variant == GSS_KRIG_SIMPLE ? sp.sk_mean : 0.0) + af - tsr;
-        const double v = vg.sill - qf + rsr;
+        const double v = sp.c00 - qf + rsr;
         mean_out[p] = mu;
         var_out[p] = v > 0.0 ? v : 0.0;
         status_out[p] = GSS_PT_OK;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
     }
     double zz = act ? z[nj] : 0.0;
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-    rhs_col(0)[lane] = act ? cov_pair_k<DIM, KIND>(vg, xjs, c0s) : 0.0;
+    rhs_col(0)[lane] = act ? c0_entry<DIM, KIND>(vg, sp, xjs, c0, c0s) : 0.0;
     rhs_col(1)[lane] = act ? zz : 0.0;
     // drift columns: monomials about the estimation point (uniform exponents), external drifts, or the constant
     double um[DIM];
@@ -538,7 +538,8 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
                        double sk_mean, const double* xdata, const double* z, const double* drift_data, int64_t n,
                        const double* x0, const double* drift_dom, int64_t m, int k, int minneighbors, double radius,
                        const double* inv_radii_host, double* mean, double* var, uint8_t* status, int* idx_out,
-                       int* count_out, hipStream_t s, int metric, HostPipe* pipe) {
+                       int* count_out, hipStream_t s, int metric, HostPipe* pipe, int block_nsub,
+                       const double* block_cell, double block_cvv) {
   GSS_REQUIRE(nc <= LMAX_NC, "moving-neighbourhood kriging supports at most %d drift terms (got %d)", LMAX_NC, nc);
   GSS_REQUIRE(k >= 1 && k <= BIG_MAX_K, "maxneighbors = %d: moving neighbourhoods hold at most %d neighbours "
                                         "(use the global neighbourhood beyond that)", k, BIG_MAX_K);
@@ -552,6 +553,9 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     for (int a = 0; a < 3; ++a) sp.e[c][a] = exps ? exps[3 * c + a] : 0;
   sp.inv_scale = inv_scale;
   sp.sk_mean = sk_mean;
+  sp.bsub = block_nsub > 0 ? block_nsub : 0;
+  for (int a = 0; a < 3; ++a) sp.bcell[a] = (block_nsub > 0 && block_cell) ? block_cell[a] : 0.0;
+  sp.c00 = block_nsub > 0 ? block_cvv : vg.sill;
 
   const bool piped = pipe && pipe->on;   // host arrays arrive and leave piece by piece (gss_internal.h)
   const int64_t chunk = big ? (k > 512 ? (1 << 14) : (1 << 17)) : (piped ? HostPipe::PIECE : (1 << 20));

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
       }
       double zz = act ? z[nj] : 0.0;
       if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-      rhs[0 * KMAX + j] = act ? cov_pair_k<DIM, KIND>(vg, xjs, c0s) : 0.0;
+      rhs[0 * KMAX + j] = act ? c0_entry<DIM, KIND>(vg, sp, xjs, c0, c0s) : 0.0;
       rhs[1 * KMAX + j] = act ? zz : 0.0;
       for (int t = 0; t < nc; ++t) {
         double f = 1.0;

@@ -296,7 +296,8 @@ class KrigingSolver(_Solver):
                   # not a parameter of the reference, which has no choice: predictprob gets the cell on a grid
                   # (krig.jl:180) and its dependencies regularise over it.  "point" (default) estimates at the
                   # centroids; ("block", nsub) regularises over the cells of a CartesianGrid by
-                  # the midpoint rule with nsub points per axis (gss.h, gss_krig_set_block_support)
+                  # the midpoint rule with nsub points per axis (gss.h, gss_krig_set_block_support), global and
+                  # moving neighbourhoods alike
                   support="point")
 
     def preprocess(self, problem: EstimationProblem):
@@ -352,8 +353,6 @@ class KrigingSolver(_Solver):
                 g = parent(pdom)
                 if not hasattr(g, "spacing"):
                     raise ValueError("support='block' needs a Cartesian grid domain (the cells to average over)")
-                if not exact:
-                    raise NotImplementedError("block support is available with the global neighbourhood only")
                 h.set_block_support(g.spacing, nsub)
             try:
                 if hi > lo:

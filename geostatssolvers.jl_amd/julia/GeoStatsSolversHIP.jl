@@ -233,7 +233,7 @@ coordmatrix(dom) = reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(d
   @param path = LinearPath()
   # not a parameter of the reference (krig.jl:180 always hands the cell of a grid to predictprob, whose dependencies
   # regularise over it): :point estimates at the centroids; (:block, nsub) regularises over the cells of a Cartesian grid
-  # by the midpoint rule with nsub points per axis (gss_krig_set_block_support), global neighbourhood only
+  # by the midpoint rule with nsub points per axis (gss_krig_set_block_support)
   @param support = :point
 end
 
@@ -286,7 +286,6 @@ function solve(problem::EstimationProblem, solver::KrigingSolverHIP; procs=[myid
                   h, vg, variant, skmean, degree, ndrift, X, z, Fd, n, exact ? GSS_KRIG_ASYNC_FIT : GSS_KRIG_NO_FACTOR, C_NULL))
       try
         if p.support !== :point
-          exact || throw(ArgumentError("block support is available with the global neighbourhood only"))
           pgrid = parent(pdomain)
           pgrid isa CartesianGrid || throw(ArgumentError("support = :block needs a Cartesian grid domain"))
           cell = Float64[ustrip.(spacing(pgrid))...]

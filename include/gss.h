@@ -230,10 +230,10 @@ int32_t gss_krig_adopt_factor(gss_krig_t* h);
 int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double* drift_dom, int64_t m,
                                 double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
 
-/* Block support for the global neighbourhood (optional; default: point support at the centroids).
+/* Block support (optional; default: point support at the centroids).
  * krig.jl:180 hands `pdomain[ind]` -- on a grid the CELL -- to predictprob, and [RECALL] the reference's dependencies
- * then average the covariances over sample points inside the cell.  After this call gss_krig_predict_global treats
- * xdom as centroids of cells of size cell[0..d-1] and regularises by the midpoint rule with nsub points per axis
+ * then average the covariances over sample points inside the cell.  After this call gss_krig_predict_global and
+ * gss_krig_predict_knn treat xdom as centroids of cells of size cell[0..d-1] and regularises by the midpoint rule with nsub points per axis
  * (nsub^d samples s): c0_i = mean_s C(x_i, c + s), variance = mean_{s,s'} C(s, s') - c0 . weights.  Simple / ordinary
  * kriging and drifts of degree <= 1 (whose cell average is the centroid value).  nsub = 0 or cell = NULL: back to
  * point support.  The dependency's own sampling scheme is version dependent and not in the tree: this one is the

@@ -277,7 +277,7 @@ def exactsolve(variant, vg, x, z, xdom, mean=0.0, degree=None, drift_data=None, 
 
 
 def approxsolve(variant, vg, x, z, xdom, maxneighbors, minneighbors=1, mean=0.0, degree=None,
-                drift_data=None, drift_dom=None, radius=None, radii=None, return_idx=False, distance=None):
+                drift_data=None, drift_dom=None, radius=None, radii=None, return_idx=False, distance=None, support=None):
     """krig.jl:188-234: per point k-NN, fit on the neighbours, predict; too few -> missing (NaN)."""
     x = np.atleast_2d(np.asarray(x, dtype=np.float64))
     xdom = np.atleast_2d(np.asarray(xdom, dtype=np.float64))
@@ -296,7 +296,7 @@ def approxsolve(variant, vg, x, z, xdom, maxneighbors, minneighbors=1, mean=0.0,
         dd = None if drift_data is None else np.asarray(drift_data)[ii]
         d0 = None if drift_dom is None else np.asarray(drift_dom)[p:p + 1]
         fk = fit(variant, vg, x[ii], z[ii], mean, degree, dd)
-        a, b = predict(fk, xdom[p:p + 1], d0)
+        a, b = predict(fk, xdom[p:p + 1], d0, support)     # krig.jl:226 hands the cell itself: `support`, see predict
         mu[p], var[p] = a[0], b[0]
     if return_idx:
         return mu, var, status, idx, cnt

@@ -38,7 +38,7 @@ class _Krig:
                     distance=None):
         return OK_.approxsolve(self.variant, self.vg, self.x, self.z, xdom, k, minneighbors, mean=self.mean,
                                degree=self.degree, drift_data=self.drift_data, drift_dom=drift_dom, radius=radius,
-                               radii=radii, return_idx=return_idx, distance=distance)
+                               radii=radii, return_idx=return_idx, distance=distance, support=getattr(self, "support", None))
 
     def predict_global_batch(self, xdom, zbatch):
         return np.stack([OK_.exactsolve(self.variant, self.vg, self.x, zb, xdom, mean=self.mean)[0] for zb in zbatch])

@@ -418,14 +418,18 @@ def test_block_support_through_the_solver_and_refusals():
     with pytest.raises(ValueError, match="Cartesian grid"):
         gss.solve(gss.EstimationProblem(gss.georef({"z": z}, xy), gss.PointSet(xy + 0.5), "z"),
                   gss.KrigingSolver(("z", dict(variogram=vg, support="block"))))
-    with pytest.raises(NotImplementedError):
-        gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=vg, support="block", maxneighbors=8))))
+    # moving neighbourhoods regularise the same way (krig.jl:226 hands the cell to predictprob as well): 8 and 80
+    # neighbours here; tests/test_gpu_large_neighbourhoods.py takes every kernel and model path
+    for k, d in ((8, 1), (80, None)):
+        kw = dict(variogram=vg, support=("block", 2), maxneighbors=k)
+        okw = {}
+        if d is not None:
+            kw["degree"], okw["degree"] = d, d
+        sol = gss.solve(prob, gss.KrigingSolver(("z", kw)))
+        rmu, rvar, rst = K.approxsolve(K.UK if d else K.OK, Variogram("spherical", range=20.0), xy, z, grid.centroids(), k,
+                                       support=((1.0, 1.0), 2), **okw)
+        assert np.max(np.abs(sol["z"] - rmu)) < 1e-9 and np.max(np.abs(sol["z_variance"] - rvar)) < 1e-9, k
     h = KrigHandle(vg, K.UK, xy, z, degree=2)
     with pytest.raises(_lib.GSSError, match="degree <= 1"):
         h.set_block_support((1.0, 1.0), 3)
-    h.close()
-    h = KrigHandle(vg, K.OK, xy, z, factor=False)
-    h.set_block_support((1.0, 1.0), 3)
-    with pytest.raises(_lib.GSSError, match="global neighbourhood only"):
-        h.predict_knn(grid.centroids()[:10], 8)
     h.close()
