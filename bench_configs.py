@@ -325,7 +325,8 @@ def cfg_lwr(a, gss, _lib):
 
 def cfg_sgs(a, gss, _lib):
     """Section 8f.4 row: SGS on a 512 x 512 grid, spherical range 35, k = 16, ball 30, 200 conditioning cells,
-    1024 realisations per sweep (the recursion runs level by level over its dependency graph, sgs.hip)."""
+    1024 realisations per sweep (the recursion runs level by level over its dependency graph; the row-by-row order
+    of this row has ~3 100 levels of ~85 nodes, which `sgs_level_team_kernel` sweeps in one launch: sgs.hip)."""
     from gss.engine import SGSHandle
     from oracle import fftgs as offt
     e = 128 if a.quick else 512
@@ -369,8 +370,8 @@ def cfg_sgs(a, gss, _lib):
     return {"config": "8f.4 SGS %dx%d grid, spherical range 35, k=16, ball 30, 200 data, %d realisations" % (e, e, R),
             "metric": "simulated cells/s (all realisations)", "value": round(N * R / dt, 1), "unit": "cells/s",
             "preprocess_s": round(t_pre, 3), "realize_s": round(dt, 4),
-            "roofline": {"bound": "hbm (gathers of the level sweep; launch gaps of the levels below ~2 000 realisations)",
-                         "kernel": "sgs_level_sweep_kernel, all levels",
+            "roofline": {"bound": "hbm (gathers of the level sweep); in fact the latency of a level: ~3 100 dependent levels",
+                         "kernel": "sgs_level_team_kernel (one launch; GSS_SGS_TEAM=0: sgs_level_sweep_kernel, one launch per level)",
                          "achieved": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9 / HBM_PEAK, 5)},
             "kernel_ms": {"sgs_sweep": round(sweep[0], 2)}, "us_per_path_node": round(sweep[0] * 1e3 / N, 3),

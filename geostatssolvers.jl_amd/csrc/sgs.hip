@@ -480,6 +480,217 @@ __global__ __launch_bounds__(256) void sgs_level_sweep_kernel(const int* __restr
   if (live) zt[node * R + r] = v;
 }
 
+// ---- short levels: the whole schedule in one launch (sgs_level_team_kernel) -------------------------------------------
+// An order whose levels are short (the row-by-row LinearPath: ~3 100 levels of ~85 nodes on 512 x 512 cells) spends its
+// sweep on launches: ~5 us per level whatever the level holds.  Realisations do not depend on each other, so a
+// workgroup (a team) takes RL of them through every level by itself and the step from one level to the next is a
+// workgroup barrier.  The team path keeps its own layout of everything it touches:
+//   field    zq[team][position in the schedule][RL]: a team's part is contiguous, a 128-byte line belongs to ONE
+//            team (in the node-major [N][R] field two teams on different XCDs share a line and every gather of a
+//            half-written line goes to memory: 2.7 us per level), a level's normals and results are one contiguous run;
+//   lists    neighbours as schedule positions, weights, sigma -- in schedule order, entries beyond a node's ncond
+//            replaced by (the node itself, weight 0): exact zeros at the end of the same sum, so the values are those of
+//            sgs_level_sweep_kernel.
+__global__ __launch_bounds__(256) void sgs_team_inverse_kernel(const int* __restrict__ order, int64_t N,
+                                                               int* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) inv[order[i]] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void sgs_team_lists_kernel(const int* __restrict__ order, const int* __restrict__ inv,
+                                                             int64_t N, int k, int kn, int kw,
+                                                             const int* __restrict__ ncond,
+                                                             const int* __restrict__ idx, const double* __restrict__ w,
+                                                             const double* __restrict__ sigma, int* __restrict__ nb_s,
+                                                             double* __restrict__ w_s, double* __restrict__ sg_s) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * kn) return;   // kn >= kw: rows of kn ints and kw doubles, padded so that the rows of a wave's node slots
+  const int64_t pos = e / kn;   // start in different LDS banks (sgs_team_strides)
+  const int j = (int)(e - pos * kn);
+  const int64_t node = order[pos];
+  const bool kept = j < ncond[node];   // ncond <= k
+  nb_s[e] = kept ? inv[idx[node * k + j]] : (int)pos;
+  if (j < kw) w_s[pos * kw + j] = kept ? w[node * k + j] : 0.0;
+  if (j == 0) sg_s[pos] = sigma[node];
+}
+
+// zq[team][pos][rl] = eps(seed, realisation, cell at pos); realisations beyond R (the last team's padding) get zeros
+__global__ __launch_bounds__(256) void sgs_team_noise_kernel(uint64_t seed, int64_t first_real, int64_t N, int R, int RL,
+                                                             int nteams, const double* __restrict__ noise,
+                                                             const int* __restrict__ order, double* __restrict__ zq) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)nteams * N * RL) return;
+  const int rl = (int)(e % RL);
+  const int64_t pos = (e / RL) % N;
+  const int r = (int)(e / ((int64_t)RL * N)) * RL + rl;
+  const int64_t cell = order[pos];
+  zq[e] = r < R ? (noise ? noise[(int64_t)r * N + cell] : philox_normal(seed, (uint32_t)(first_real + r), (uint64_t)cell))
+                : 0.0;
+}
+
+__global__ __launch_bounds__(256) void sgs_team_seed_data_kernel(const int64_t* __restrict__ dlocs,
+                                                                 const double* __restrict__ zd, int64_t nd,
+                                                                 const int* __restrict__ inv, int64_t N, int R, int RL,
+                                                                 double* __restrict__ zq) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nd * R) return;
+  const int64_t j = e / R;
+  const int r = (int)(e % R);
+  zq[((int64_t)(r / RL) * N + inv[dlocs[j]]) * RL + r % RL] = zd[j];
+}
+
+// out[r][cell] from the team layout through an LDS tile: 64 cells of one team; RL * 8 bytes per cell come in, 512-byte
+// runs go out
+__global__ __launch_bounds__(256) void sgs_team_out_kernel(const double* __restrict__ zq, const int* __restrict__ inv,
+                                                           int64_t N, int R, int RL, double* __restrict__ out) {
+  __shared__ double tile[64][65];
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int team = blockIdx.y;
+  for (int e = threadIdx.x; e < 64 * RL; e += 256) {
+    const int i = e / RL, rl = e % RL;
+    if (c0 + i < N) tile[rl][i] = zq[((int64_t)team * N + inv[c0 + i]) * RL + rl];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * RL; e += 256) {
+    const int rl = e >> 6, i = e & 63;
+    const int r = team * RL + rl;
+    if (c0 + i < N && r < R) out[(int64_t)r * N + c0 + i] = tile[rl][i];
+  }
+}
+
+// Fourteen waves compute: lane = (node slot, realisation), 896 / RL nodes per round, every gather of a node in flight
+// at once.  Two waves stage: what a level needs besides its neighbours' values -- lists, weights, sigma, the level's
+// normals -- does not depend on the sweep and is copied into LDS three chunks ahead with LDS-direct loads (no registers,
+// so the copies stay in flight across the barriers: the staging waves wait with a COUNTED vmcnt, the barrier is the raw
+// instruction; a wave's ordinary loads return in order, which is why the computing waves do not fetch any of this
+// themselves).  Levels are cut into chunks of at most `cap` nodes (chunk_off); all LDS is one array.
+constexpr int SGS_TEAM_THREADS = 1024;
+constexpr int SGS_TEAM_STAGERS = 2;            // staging waves
+constexpr int SGS_TEAM_ENTRIES = 2560;         // list entries per chunk: cap * (padded row) <= 2560
+constexpr int SGS_TEAM_NORMALS = 1024;         // normals per chunk: cap * RL <= 1024
+constexpr int SGS_TEAM_CAP = 128;              // nodes per chunk at most
+constexpr int SGS_TEAM_AHEAD = 3;              // chunks in flight; LDS holds one stage more
+// Row lengths of the staged lists (k a multiple of 4): the node slots of a wave read the same column of consecutive rows
+// at once, so a row of k doubles (k = 16: 128 bytes) would put all of them into the same LDS banks.  kw = k + 2 doubles
+// and kn = 4 mod 8 ints (both whole 16-byte pieces) spread eight consecutive rows over the 32 banks.
+inline void sgs_team_strides(int k, int* kn, int* kw) {
+  *kw = k + 2;
+  *kn = k % 8 == 0 ? k + 4 : k + 8;
+}
+constexpr int SGS_TEAM_STAGES = SGS_TEAM_AHEAD + 1;
+struct SgsTeamStage {
+  double ww[SGS_TEAM_ENTRIES];
+  double eps[SGS_TEAM_NORMALS];
+  double sg[SGS_TEAM_CAP];
+  int nb[SGS_TEAM_ENTRIES];
+};
+static_assert(SGS_TEAM_STAGES * sizeof(SgsTeamStage) <= 160 * 1024, "LDS of a CU");
+// LDS-direct copies issued per staging wave and chunk; the staging waves' vmcnt leaves AHEAD - 1 chunks in flight
+constexpr int SGS_TEAM_GLDS = (SGS_TEAM_ENTRIES * 4 + SGS_TEAM_ENTRIES * 8 + SGS_TEAM_NORMALS * 8) / 1024 / SGS_TEAM_STAGERS +
+                              SGS_TEAM_CAP * 8 / 256 / SGS_TEAM_STAGERS;
+static_assert(SGS_TEAM_GLDS == 21 && SGS_TEAM_AHEAD == 3, "the waits below are written for 21 copies and 3 chunks: vmcnt(42), (21)");
+static_assert(SGS_TEAM_GLDS * SGS_TEAM_AHEAD <= 63, "vmcnt counts to 63");
+
+// `bytes` valid bytes from src to dst (LDS), the staging waves together: pieces of 64 lanes x SIZE bytes, a piece per
+// instruction, lanes beyond the end repeat the last SIZE bytes (every instruction is issued: the vmcnt count is fixed)
+template <int SIZE, int PIECES>
+__device__ __forceinline__ void sgs_team_copy(void* dst, const void* src, int bytes, int sw, int lane) {
+  static_assert(PIECES % SGS_TEAM_STAGERS == 0 && (SIZE == 16 || SIZE == 4), "pieces divide among the staging waves");
+#pragma unroll
+  for (int u = 0; u < PIECES / SGS_TEAM_STAGERS; ++u) {
+    const int piece = u * SGS_TEAM_STAGERS + sw;
+    const int off = piece * 64 * SIZE + lane * SIZE;
+    const char* g = static_cast<const char*>(src) + (off < bytes ? off : bytes - SIZE);
+    auto gp = (const __attribute__((address_space(1))) void*)g;
+    auto lp = (__attribute__((address_space(3))) void*)(static_cast<char*>(dst) + piece * 64 * SIZE);
+    if constexpr (SIZE == 16)   // the builtin wants a literal
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(gp, lp, 4, 0, 0);
+  }
+}
+
+template <int RL>
+__global__ __launch_bounds__(SGS_TEAM_THREADS) void sgs_level_team_kernel(
+    const int* __restrict__ nb_s, const double* __restrict__ w_s, const double* __restrict__ sg_s,
+    const int* __restrict__ chunk_off, int nchunks, int k, int kn, int kw, int64_t N, double mean,
+    double* __restrict__ zq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char team_lds[];
+  SgsTeamStage* stages = reinterpret_cast<SgsTeamStage*>(team_lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CW = SGS_TEAM_THREADS / 64 - SGS_TEAM_STAGERS;   // computing waves
+  constexpr int NPW = 64 / RL, NPR = CW * NPW;
+  const int q = lane / RL, rl = lane % RL;
+  double* zb = zq + (int64_t)blockIdx.x * N * RL;   // this team's realisations, [position][RL]
+  const int sw = __builtin_amdgcn_readfirstlane(wave) - CW;   // >= 0: staging wave
+
+  auto issue = [&](int c) {
+    SgsTeamStage& S = stages[c % SGS_TEAM_STAGES];
+    const int first = chunk_off[c], cnt = chunk_off[c + 1] - first;
+    sgs_team_copy<16, SGS_TEAM_ENTRIES * 4 / 1024>(S.nb, nb_s + (int64_t)first * kn, cnt * kn * 4, sw, lane);
+    sgs_team_copy<16, SGS_TEAM_ENTRIES * 8 / 1024>(S.ww, w_s + (int64_t)first * kw, cnt * kw * 8, sw, lane);
+    sgs_team_copy<16, SGS_TEAM_NORMALS * 8 / 1024>(S.eps, zb + (int64_t)first * RL, cnt * RL * 8, sw, lane);
+    sgs_team_copy<4, SGS_TEAM_CAP * 8 / 256>(S.sg, sg_s + first, cnt * 8, sw, lane);
+  };
+  // all but the newest `left` chunks' copies have landed (left = chunks issued after the one that is needed)
+  auto landed = [&](int left) {
+    if (left >= 2) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+    else if (left == 1) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  if (sw >= 0) {
+    const int pre = nchunks < SGS_TEAM_AHEAD ? nchunks : SGS_TEAM_AHEAD;
+    for (int c = 0; c < pre; ++c) issue(c);
+    landed(pre - 1);   // chunk 0
+  }
+  int first = chunk_off[0], end = chunk_off[1];
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int c = 0; c < nchunks; ++c) {
+    const int end_next = chunk_off[c + 2 <= nchunks ? c + 2 : nchunks];   // boundaries one chunk ahead: off the chain
+    if (sw >= 0) {
+      // stage (c + AHEAD) % STAGES held chunk c - 1, and the barrier behind that chunk has been passed
+      if (c + SGS_TEAM_AHEAD < nchunks) issue(c + SGS_TEAM_AHEAD);
+      const int issued = c + SGS_TEAM_AHEAD < nchunks ? c + SGS_TEAM_AHEAD : nchunks - 1;   // newest chunk on its way
+      landed(issued - (c + 1) > 0 ? issued - (c + 1) : 0);                                   // chunk c + 1 has landed
+    } else {
+      const SgsTeamStage& S = stages[c % SGS_TEAM_STAGES];
+      const int cnt = end - first;
+      for (int base = 0; base < cnt; base += NPR) {
+        const int i = base + wave * NPW + q;
+        const bool on = i < cnt;
+        const int ii = on ? i : 0;
+        const double sg = S.sg[ii];
+        const double eps = S.eps[ii * RL + rl];   // the cell's own slot held its normal
+        double acc = 0.0;
+        const int* nbr = S.nb + ii * kn;
+        const double* wwr = S.ww + ii * kw;
+        auto batch = [&](int j, auto count) {     // `count` gathers in flight, then their terms in list order
+          constexpr int C = decltype(count)::value;
+          double zz[C];
+#pragma unroll
+          for (int u = 0; u < C; ++u) zz[u] = zb[(int64_t)nbr[j + u] * RL + rl];
+#pragma unroll
+          for (int u = 0; u < C; ++u) acc = fma(wwr[j + u], zz[u] - mean, acc);
+        };
+        int j = 0;
+        for (; j + 16 <= k; j += 16) batch(j, std::integral_constant<int, 16>{});
+        switch (k - j) {                          // k is a multiple of 4
+          case 12: batch(j, std::integral_constant<int, 12>{}); break;
+          case 8: batch(j, std::integral_constant<int, 8>{}); break;
+          case 4: batch(j, std::integral_constant<int, 4>{}); break;
+          default: break;
+        }
+        if (on) zb[(int64_t)(first + i) * RL + rl] = mean + acc + sg * eps;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the level's results have left before a wave of this CU gathers them
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    first = end;
+    end = end_next;
+  }
+}
+
 // one level of every visiting order at once (one order per realisation): thread = (path, node) of the level; the
 // recursion step of sgs_sweep_paths_kernel on the realisation-major field
 __global__ __launch_bounds__(256) void sgs_level_sweep_paths_kernel(const int* __restrict__ order, int first, int count,
@@ -687,6 +898,9 @@ struct gss_sgs {
   DevBuf field;  // node-major [N][R] working field of gss_sgs_realize, kept between calls (grows to the largest R seen)
   DevBuf order;  // shared visiting order: nodes sorted by level of the dependency graph
   std::vector<int> lvl_off;   // lvl_off[l] .. lvl_off[l + 1] - 1: positions of level l in `order` (level 0 = conditioning cells)
+  // short levels (sgs_level_team_kernel): schedule-ordered padded lists / weights / sigma, chunk boundaries in `order`
+  DevBuf nb_sched, w_sched, sg_sched, inv_sched, chunk_off;
+  int team_chunks = 0, team_cap = 0, team_rl = 0;
 };
 
 // levels of the dependency graph of path 0 (see sgs_level_sweep_kernel); leaves h->lvl_off empty when switched off
@@ -735,6 +949,39 @@ static int32_t sgs_build_levels(gss_sgs* h, hipStream_t s) {
   for (int l = L; l >= 0; --l)   // a level without nodes (only level 0 can be: no conditioning cells) starts where the next does
     if (ho[(size_t)l] < 0) ho[(size_t)l] = ho[(size_t)l + 1];
   h->lvl_off = std::move(ho);
+  // Orders with short levels sweep in one launch (sgs_level_team_kernel).  The average level size decides: a launch per
+  // level costs ~5 us whatever it holds, a team's level ~2.8 us up to 112 nodes (measured).
+  h->team_chunks = 0;
+  static const char* team_env = std::getenv("GSS_SGS_TEAM");   // "0": never, "1": whenever it applies (measurements)
+  const int64_t nsim = N - h->lvl_off[1];
+  const double avg = L > 0 ? (double)nsim / (double)L : 0.0;
+  const bool want = team_env ? team_env[0] != '0' : avg <= 128.0;
+  if (h->npaths == 1 && h->k <= 64 && h->k % 4 == 0 && L > 0 && want) {
+    h->team_rl = avg <= 14.0 ? 64 : avg <= 28.0 ? 32 : avg <= 56.0 ? 16 : 8;   // one round (896 / RL nodes) per level where possible
+    int kn = 0, kw = 0;
+    sgs_team_strides(h->k, &kn, &kw);
+    int cap = SGS_TEAM_ENTRIES / kn < SGS_TEAM_CAP ? SGS_TEAM_ENTRIES / kn : SGS_TEAM_CAP;
+    if (cap > SGS_TEAM_NORMALS / h->team_rl) cap = SGS_TEAM_NORMALS / h->team_rl;
+    std::vector<int> co;
+    for (int l = 1; l <= L; ++l)
+      for (int a = h->lvl_off[(size_t)l]; a < h->lvl_off[(size_t)l + 1]; a += cap) co.push_back(a);
+    co.push_back((int)N);
+    GSS_TRY(h->chunk_off.alloc(sizeof(int) * co.size()));
+    GSS_HIP(hipMemcpyAsync(h->chunk_off.p, co.data(), sizeof(int) * co.size(), hipMemcpyHostToDevice, s));
+    GSS_TRY(h->nb_sched.alloc(sizeof(int) * (size_t)(N * kn)));
+    GSS_TRY(h->w_sched.alloc(sizeof(double) * (size_t)(N * kw)));
+    GSS_TRY(h->sg_sched.alloc(sizeof(double) * (size_t)N));
+    GSS_TRY(h->inv_sched.alloc(sizeof(int) * (size_t)N));
+    hipLaunchKernelGGL(sgs_team_inverse_kernel, grid, dim3(256), 0, s, h->order.as<int>(), N, h->inv_sched.as<int>());
+    hipLaunchKernelGGL(sgs_team_lists_kernel, dim3((unsigned)((N * kn + 255) / 256)), dim3(256), 0, s,
+                       h->order.as<int>(), h->inv_sched.as<int>(), N, h->k, kn, kw, h->ncond.as<int>(), h->idx.as<int>(),
+                       h->w.as<double>(), h->sigma.as<double>(), h->nb_sched.as<int>(), h->w_sched.as<double>(),
+                       h->sg_sched.as<double>());
+    GSS_HIP(hipGetLastError());
+    GSS_HIP(hipStreamSynchronize(s));   // co is a local
+    h->team_chunks = (int)co.size() - 1;
+    h->team_cap = cap;
+  }
   return GSS_OK;
 }
 
@@ -990,11 +1237,60 @@ static int32_t sgs_realize_block(gss_sgs_t* h, uint64_t seed, int64_t first_real
     return GSS_OK;
   }
   // the working field is GBs (8 N R bytes): allocating and freeing it on every call costs more than a short sweep
-  if (h->field.bytes < sizeof(double) * (size_t)(N * R)) {
+  const bool team = !h->lvl_off.empty() && h->team_chunks > 0;
+  const int RL = team ? h->team_rl : 1;
+  const int nteams = (R + RL - 1) / RL;
+  const size_t field_doubles = team ? (size_t)nteams * (size_t)N * (size_t)RL : (size_t)(N * R);
+  if (h->field.bytes < sizeof(double) * field_doubles) {
     h->field.release();
-    GSS_TRY(h->field.alloc(sizeof(double) * (size_t)(N * R)));
+    GSS_TRY(h->field.alloc(sizeof(double) * field_doubles));
   }
   DevBuf& zt = h->field;
+  if (team) {   // short levels: one launch, the field in the team layout (sgs_level_team_kernel)
+    {
+      ProfScope ps("sgs_noise", s);
+      hipLaunchKernelGGL(sgs_team_noise_kernel, dim3((unsigned)((field_doubles + 255) / 256)), dim3(256), 0, s, seed,
+                         first_real, N, R, RL, nteams, noise ? noise : nullptr, h->order.as<int>(), zt.as<double>());
+      GSS_HIP(hipGetLastError());
+    }
+    if (h->nd > 0) {
+      hipLaunchKernelGGL(sgs_team_seed_data_kernel, dim3((unsigned)((h->nd * R + 255) / 256)), dim3(256), 0, s,
+                         h->dlocs.as<int64_t>(), h->zd.as<double>(), h->nd, h->inv_sched.as<int>(), N, R, RL,
+                         zt.as<double>());
+      GSS_HIP(hipGetLastError());
+    }
+    {
+      ProfScope ps("sgs_sweep", s);
+      int kn = 0, kw = 0;
+      sgs_team_strides(h->k, &kn, &kw);
+#define GSS_SGS_TEAM_LAUNCH(W)                                                                                         \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sgs_level_team_kernel<W>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
+                                  (int)(SGS_TEAM_STAGES * sizeof(SgsTeamStage))));                                     \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((sgs_level_team_kernel<W>), dim3((unsigned)nteams), dim3(SGS_TEAM_THREADS),                     \
+                       SGS_TEAM_STAGES * sizeof(SgsTeamStage), s, h->nb_sched.as<int>(), h->w_sched.as<double>(),      \
+                       h->sg_sched.as<double>(), h->chunk_off.as<int>(), h->team_chunks, h->k, kn, kw, N, h->mean,     \
+                       zt.as<double>());                                                                               \
+  } while (0)
+      switch (RL) {
+        case 64: GSS_SGS_TEAM_LAUNCH(64); break;
+        case 32: GSS_SGS_TEAM_LAUNCH(32); break;
+        case 16: GSS_SGS_TEAM_LAUNCH(16); break;
+        default: GSS_SGS_TEAM_LAUNCH(8); break;
+      }
+#undef GSS_SGS_TEAM_LAUNCH
+      GSS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(sgs_team_out_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)nteams), dim3(256), 0, s,
+                       zt.as<double>(), h->inv_sched.as<int>(), N, R, RL, out);
+    GSS_HIP(hipGetLastError());
+    return GSS_OK;
+  }
   {
     ProfScope ps("sgs_noise", s);
     hipLaunchKernelGGL(sgs_noise_kernel, dim3((unsigned)((N * R + 255) / 256)), dim3(256), 0, s, seed, first_real, N, R,

@@ -323,3 +323,46 @@ def test_level_schedule_is_bit_identical_to_the_walk_along_the_path():
     assert len(outs[0]) == 5
     for a, b in zip(*outs):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_short_levels_in_one_launch_are_bit_identical_to_both_other_sweeps():
+    """The row-by-row order (LinearPath) has thousands of short levels; `sgs_level_team_kernel` sweeps them in ONE launch
+    with the field in a layout of its own (a workgroup per group of realisations, workgroup barriers between levels,
+    lists and normals staged by LDS-direct loads).  Forced on (GSS_SGS_TEAM=1) it must give, bit for bit, the fields of
+    the launch-per-level sweep (GSS_SGS_TEAM=0) and of the wave that walks the path (GSS_SGS_LEVELS=0): 2-D and 3-D
+    grids, 4 ... 20 neighbours, conditioning data, realisation counts that do not fill the last group, a random order
+    (long levels: several chunks and rounds per level), supplied normals."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = ("import sys, numpy as np, gss\n"
+            "from gss.engine import SGSHandle\n"
+            "out = sys.argv[1]\n"
+            "res = []\n"
+            "for dims, k, R, order in (((96, 80), 16, 67, None), ((70, 50), 12, 8, None), ((24, 18, 10), 20, 130, None),\n"
+            "                          ((64, 64), 4, 9, None), ((90, 70), 16, 33, 'random'), ((40, 30), 8, 3, 'noise')):\n"
+            "    N = int(np.prod(dims)); rng = np.random.default_rng(N)\n"
+            "    g = np.meshgrid(*[np.arange(d) + 0.5 for d in dims], indexing='ij')\n"
+            "    cent = np.stack([a.ravel(order='F') for a in g], 1)\n"
+            "    dl = np.sort(rng.choice(N, 25, replace=False)); zd = rng.normal(size=25)\n"
+            "    path = rng.permutation(N) if order == 'random' else None\n"
+            "    h = SGSHandle(gss.SphericalVariogram(range=12.0, nugget=0.05), cent, path, dl, zd, 0.3, k, 1)\n"
+            "    noise = rng.normal(size=(R, N)) if order == 'noise' else None\n"
+            "    res.append(h.realize(7, 2, R, noise=noise)); h.close()\n"
+            "np.savez(out, *res)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for tag, extra in (("team", dict(GSS_SGS_TEAM="1")), ("launches", dict(GSS_SGS_TEAM="0")),
+                           ("walk", dict(GSS_SGS_LEVELS="0"))):
+            out = os.path.join(d, f"{tag}.npz")
+            env = dict(os.environ, PYTHONPATH=os.pathsep.join(
+                [os.path.join(root, "geostatssolvers.jl_amd"), os.environ.get("PYTHONPATH", "")]), **extra)
+            subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+            with np.load(out) as f:
+                outs.append([f[k] for k in f.files])
+    assert len(outs[0]) == 6
+    for a, b, c in zip(*outs):
+        assert a.shape == b.shape == c.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b) and np.array_equal(a, c)
