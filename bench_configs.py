@@ -365,12 +365,14 @@ def cfg_sgs(a, gss, _lib):
     S.realize(Variogram("spherical", range=35.0), 0.0, cc, None, np.array([100, 2000]), np.array([1.0, 0.0]), 1, 0, 1,
               maxneighbors=16, radius=30.0)
     cdt = time.perf_counter() - t1
-    # stage B algorithmic bytes per node and realisation: k gathered values + the value written twice
-    bytes_nr = (16 + 2) * 8
+    # stage B bytes that have to cross HBM per node and realisation: the normal read and the value written (the k
+    # gathered values were written a few levels earlier and are served on chip); the sweep is bound by the latency of
+    # its ~3 100 dependent levels, which is what the small fraction says
+    bytes_nr = 2 * 8
     return {"config": "8f.4 SGS %dx%d grid, spherical range 35, k=16, ball 30, 200 data, %d realisations" % (e, e, R),
             "metric": "simulated cells/s (all realisations)", "value": round(N * R / dt, 1), "unit": "cells/s",
             "preprocess_s": round(t_pre, 3), "realize_s": round(dt, 4),
-            "roofline": {"bound": "hbm (gathers of the level sweep); in fact the latency of a level: ~3 100 dependent levels",
+            "roofline": {"bound": "hbm (normals in, values out); in fact the latency of ~3 100 dependent levels",
                          "kernel": "sgs_level_team_kernel (one launch; GSS_SGS_TEAM=0: sgs_level_sweep_kernel, one launch per level)",
                          "achieved": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(bytes_nr * N * R / (sweep[0] * 1e-3) / 1e9 / HBM_PEAK, 5)},
