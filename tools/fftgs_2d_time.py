@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")]
 import numpy as np, torch, gss
 from gss.engine import FFTGSHandle
-for dims in ((1024, 1024), (2048, 2048), (4096, 4096), (1000, 1000), (256, 256, 256), (200, 200, 200)):
+for dims in ((1024, 1024), (2048, 2048), (4096, 4096), (1000, 1000), (100, 100), (256, 256, 256), (200, 200, 200),
+             (500, 500, 500), (300, 300, 100), (512, 512, 512)):
     vg = gss.ExponentialVariogram(range=dims[0] / 10.0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h = FFTGSHandle(vg, dims)
