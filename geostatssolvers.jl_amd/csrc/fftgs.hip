@@ -28,7 +28,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <list>
+#include <memory>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace gss {
@@ -158,14 +162,30 @@ static std::once_flag g_rocfft_once;
 
 using namespace gss;
 
+// The two rocFFT plans of a grid size.  A plan describes the transform and is executed with the execution info of the
+// handle that runs it (its own work buffer and stream), so handles of the same size share one pair; the library keeps
+// the pairs of the last eight sizes alive between handles -- creating a pair costs 2-3 ms even when rocFFT finds its
+// compiled kernels, which is most of a `solve` on the 100 x 100 grids of the reference's tests
+// (tools/small_problem_latency.py).
+struct FftPlans {
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  size_t work_bytes = 0;
+  ~FftPlans() {
+    if (fwd) rocfft_plan_destroy(fwd);
+    if (inv) rocfft_plan_destroy(inv);
+  }
+};
+
 struct gss_fftgs {
   VgDev vg;
   GridSpec g;
   int ndim = 0;
   int64_t N = 0, NH = 0;
   double mean = 0.0;
-  // rocFFT pipeline (general grids): plans, work buffer, U and Xn are created on first use
-  rocfft_plan fwd = nullptr, inv = nullptr;
+  // rocFFT pipeline (general grids): plans (shared with other handles of the same grid size: fft_plans), work buffer,
+  // U and Xn are created on first use
+  std::shared_ptr<struct FftPlans> plans;
+  rocfft_plan fwd = nullptr, inv = nullptr;   // = plans->fwd / inv
   rocfft_execution_info info = nullptr;
   DevBuf state;  // Fh (NH doubles) followed by scal[2]
   DevBuf U, Xn, work, Z;
@@ -206,9 +226,7 @@ struct gss_fftgs {
         (void)hipEventDestroy(slab_e[i]);
       }
     if (slab_e0) (void)hipEventDestroy(slab_e0);
-    if (fwd) rocfft_plan_destroy(fwd);
-    if (inv) rocfft_plan_destroy(inv);
-    if (info) rocfft_execution_info_destroy(info);
+    if (info) rocfft_execution_info_destroy(info);   // (the plans go with the last holder of `plans`)
   }
 };
 
@@ -249,15 +267,34 @@ static int32_t ensure_rocfft(gss_fftgs* h) {
     rocfft_kernel_cache_default();
     rocfft_setup();
   });
-  size_t lengths[3] = {(size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
-  GSS_FFT(rocfft_plan_create(&h->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                             rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
-  GSS_FFT(rocfft_plan_create(&h->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                             rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
-  size_t w1 = 0, w2 = 0;
-  GSS_FFT(rocfft_plan_get_work_buffer_size(h->fwd, &w1));
-  GSS_FFT(rocfft_plan_get_work_buffer_size(h->inv, &w2));
-  const size_t wb = w1 > w2 ? w1 : w2;
+  using Key = std::array<size_t, 4>;
+  // most recent first; calls hold the library lock; never destroyed (at exit rocFFT's own statics may be gone first)
+  static auto& cache = *new std::list<std::pair<Key, std::shared_ptr<FftPlans>>>();
+  const Key key = {(size_t)h->ndim, (size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
+  for (auto it = cache.begin(); it != cache.end(); ++it)
+    if (it->first == key) {
+      h->plans = it->second;
+      cache.splice(cache.begin(), cache, it);
+      break;
+    }
+  if (!h->plans) {
+    auto pl = std::make_shared<FftPlans>();
+    size_t lengths[3] = {(size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
+    GSS_FFT(rocfft_plan_create(&pl->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
+    GSS_FFT(rocfft_plan_create(&pl->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                               rocfft_precision_double, (size_t)h->ndim, lengths, 1, nullptr));
+    size_t w1 = 0, w2 = 0;
+    GSS_FFT(rocfft_plan_get_work_buffer_size(pl->fwd, &w1));
+    GSS_FFT(rocfft_plan_get_work_buffer_size(pl->inv, &w2));
+    pl->work_bytes = w1 > w2 ? w1 : w2;
+    cache.emplace_front(key, pl);
+    if (cache.size() > 8) cache.pop_back();   // handles that still use the pair keep it alive
+    h->plans = std::move(pl);
+  }
+  h->fwd = h->plans->fwd;
+  h->inv = h->plans->inv;
+  const size_t wb = h->plans->work_bytes;
   GSS_FFT(rocfft_execution_info_create(&h->info));
   if (wb > 0) {
     GSS_TRY(h->work.alloc(wb));
