@@ -258,9 +258,12 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
               : 0;
   const bool ai = (sa_i == 1) || (sa_k != 1);
   const bool bj = (sb_j == 1) || (sb_k != 1);
-  // Tile shape by wave quantisation: 512 workgroups of 128-tiles or 768 of 64-tiles are resident at once (LDS), and
-  // a 64-tile workgroup reaches about 3/4 of the 128-tile rate.  A launch whose last round is mostly empty (e.g. the
-  // 528 lower tiles of a 4096^2 trailing update: 2 rounds for 1.03 rounds of work) is better off with small tiles.
+  // Tile shape by the time the launch takes (round 3, tools/gemm_late_steps.py, K = 1 024; both scale with K): 128-tiles
+  // behave as if one workgroup ran per CU, in rounds of 256 (two are resident, but one already keeps the CU's matrix
+  // pipes busy): 0.03 + 0.14 ms per round, whether the round is full or not (256 tiles 0.18 ms, 320 ... 512 tiles 0.30); 64-tiles stream through two per CU without visible rounds, 0.035 + 0.038 ms per
+  // 256 of them (4 096 x 1 024 x 1 024: 0.19 ms either way; 5 120 x 1 024: 0.24 against 0.31 ms; the 4 560 lower tiles of
+  // a 12 288^2 trailing update: 128-tiles by 7 %).  The products of the late steps of a blocked factorisation are
+  // partial rounds, which is where the choice matters.
   auto tiles = [&](int64_t T) {
     const int64_t tm = (M + T - 1) / T, tn = (N + T - 1) / T;
     if (!lower_only) return tm * tn;
@@ -268,9 +271,9 @@ int32_t gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
     return d * (d + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0);
   };
   const int64_t t128 = tiles(128), t64 = tiles(64);
-  const double eff128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-  const double eff64 = 0.75 * (double)t64 / (double)(((t64 + 767) / 768) * 768);
-  if (t128 >= 128 && eff128 >= eff64) return gemm_dispatch<128>(g, ai, bj, s);
+  const double cost128 = 0.03 + 0.14 * (double)((t128 + 255) / 256);
+  const double cost64 = 0.035 + 0.038 * (double)t64 / 256.0;
+  if (cost128 <= cost64) return gemm_dispatch<128>(g, ai, bj, s);
   return gemm_dispatch<64>(g, ai, bj, s);
 }
 
