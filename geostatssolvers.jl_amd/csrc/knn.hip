@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const double* __restric
                     key_less(my_lowd, my_lowi, d2, oidx);
         if (MASKED) qual = qual && rank[valid ? oidx : 0] < myrank;
         unsigned long long qm = __ballot(qual);
-        if (k >= KNN_SORT_MIN_K && __popcll(qm) >= KNN_SORT_MIN) {
+        // (short lists take the sort too while they are not full: the first batch would otherwise be 64 insertions)
+        if ((k >= KNN_SORT_MIN_K || tau_i == INT_MAX) && __popcll(qm) >= KNN_SORT_MIN) {
           // many candidates beat the current k-th key (always true for the first batches): sort the batch and merge
           // it into the list with bitonic networks instead of inserting one candidate at a time
           double bd = qual ? d2 : INF;
