@@ -257,19 +257,19 @@ __global__ __launch_bounds__(BIG_NT) void krig_local_big_kernel(VgDev vg, LocalS
 // ---------------------------------------------------------------------------------------------
 
 // step KK of the tile factorisation, after V = U_KK^-1 is known: U_KK,j = V' A_KK,j; Y_KK = V' B_KK; trailing updates
-template <int KK>
+template <int KK, int NT = 4>
 __device__ __forceinline__ void k5_block_step(d4_t (&T)[10], d4_t (&B)[4], const d4_t& V, int nt) {
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int j = KK + 1; j < 4; ++j)
+  for (int j = KK + 1; j < NT; ++j)
     if (j < nt) T[tile_id(KK, j)] = xty(V, T[tile_id(KK, j)], zero4);
   B[KK] = xty(V, B[KK], zero4);
 #pragma unroll
-  for (int i = KK + 1; i < 4; ++i) {
+  for (int i = KK + 1; i < NT; ++i) {
     if (i < nt) {
       const d4_t N = -T[tile_id(KK, i)];
 #pragma unroll
-      for (int j = i; j < 4; ++j)
+      for (int j = i; j < NT; ++j)
         if (j < nt) T[tile_id(i, j)] = xty(N, T[tile_id(KK, j)], T[tile_id(i, j)]);
       B[i] = xty(N, B[KK], B[i]);
     }
@@ -315,8 +315,13 @@ __device__ __forceinline__ void k5_step_rest(d4_t (&T)[10], d4_t (&B)[4], const 
 // steps beyond a point's neighbour count, take part with an identity tile.
 constexpr int K5_WAVES = 4;
 
-template <int DIM, int KIND>
-__global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
+// NT = tiles of 16 neighbours the instantiation holds (1, 2 or 4: maxneighbors <= 16 NT).  The common moving
+// neighbourhoods are small -- 8 ... 32 neighbours --, and an instantiation that carries one or three tiles instead
+// of ten needs a third of the registers: five or four workgroups per CU instead of three hide the latencies of the
+// gathers and of the one factorisation such a point needs.
+template <int DIM, int KIND, int NT>
+__global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 4 : 3, NT == 1 ? 5 : (NT == 2 ? 4 : 3))))
+void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ xdata,
                                                              const double* __restrict__ z,
                                                              const double* __restrict__ drift_data,
                                                              const double* __restrict__ x0,
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   // system matrix, upper block triangle, tile layout; the four rows a lane holds of a tile are evaluated together
   d4_t T[10];
 #pragma unroll
-  for (int I = 0; I < 4; ++I) {
+  for (int I = 0; I < NT; ++I) {
     if (I < nt) {
       double xr[4][DIM];
 #pragma unroll
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
         for (int a = 0; a < DIM; ++a) xr[r][a] = nxs[16 * I + g + 4 * r][a];
 #pragma unroll
-      for (int J = I; J < 4; ++J) {
+      for (int J = I; J < NT; ++J) {
         if (J < nt) {
           const int col = 16 * J + c;
           double xcol[DIM], v[4];
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
     const double* colc = rhs_col(c < LMAX_RHS ? c : 0);
     const bool used = c < 2 + nc;
 #pragma unroll
-    for (int K = 0; K < 4; ++K) {
+    for (int K = 0; K < NT; ++K) {
       if (K < nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   // moving neighbourhood -- that leaves one diagonal factorisation instead of four: 5.6 -> 2.x ms per 1.25e6 points.
   const int ntk = (k + 15) >> 4;
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
+  for (int kk = 0; kk < NT; ++kk) {
     if (kk >= ntk) break;
     double* mine = S4[kk & 1][wave];
 #pragma unroll
@@ -512,10 +517,10 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
       for (int r = 0; r < 4; ++r) V[r] = mine[(g + 4 * r) * 17 + c];
       bad = bad || (badflag[kk & 1][wave] != 0);
       switch (kk) {
-        case 0: k5_block_step<0>(T, B, V, nt); break;
-        case 1: k5_block_step<1>(T, B, V, nt); break;
-        case 2: k5_block_step<2>(T, B, V, nt); break;
-        default: k5_block_step<3>(T, B, V, nt); break;
+        case 0: k5_block_step<0, NT>(T, B, V, nt); break;
+        case 1: k5_block_step<(1 < NT ? 1 : 0), NT>(T, B, V, nt); break;
+        case 2: k5_block_step<(2 < NT ? 2 : 0), NT>(T, B, V, nt); break;
+        default: k5_block_step<(3 < NT ? 3 : 0), NT>(T, B, V, nt); break;
       }
     }
   }
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(64 * K5_WAVES) __attribute__((amdgpu_waves_per_eu(3
   }
   d4_t Gt = zero4;
 #pragma unroll
-  for (int K = 0; K < 4; ++K)
+  for (int K = 0; K < NT; ++K)
     if (K < nt) Gt = xty(B[K], B[K], Gt);
 #pragma unroll
   for (int r = 0; r < 4; ++r) G[g + 4 * r][c] = Gt[r];
@@ -631,9 +636,15 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
     {
 #define GSS_K5_ARGS vg, sp, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt, mean + off, \
                     var + off, st
-#define GSS_K5_LAUNCH(D, K) \
-  hipLaunchKernelGGL((krig_local_mfma_kernel<D, K>), dim3((unsigned)((mv + K5_WAVES - 1) / K5_WAVES)), \
+#define GSS_K5_LAUNCH_NT(D, K, NTV) \
+  hipLaunchKernelGGL((krig_local_mfma_kernel<D, K, NTV>), dim3((unsigned)((mv + K5_WAVES - 1) / K5_WAVES)), \
                      dim3(64 * K5_WAVES), 0, s, GSS_K5_ARGS)
+#define GSS_K5_LAUNCH(D, K)                        \
+  do {                                             \
+    if (k <= 16) GSS_K5_LAUNCH_NT(D, K, 1);        \
+    else if (k <= 32) GSS_K5_LAUNCH_NT(D, K, 2);   \
+    else GSS_K5_LAUNCH_NT(D, K, 4);                \
+  } while (0)
       // one instantiation per common single-structure model in 2-D / 3-D, the general kernel otherwise
       const int kind = vg.nextra == 0 ? vg.kind : -1;
       if (dim == 3) {
@@ -658,6 +669,7 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
         GSS_K5_LAUNCH(1, -1);
       }
 #undef GSS_K5_LAUNCH
+#undef GSS_K5_LAUNCH_NT
 #undef GSS_K5_ARGS
       GSS_HIP(hipGetLastError());
       if (piped) GSS_TRY(pipe->deliver(off, mv, s));
