@@ -28,3 +28,10 @@ cond = gss.SimulationProblem(gss.georef({"z": z[:25]}, xy[:25] * 100 / 64), g100
 timed("LUGS 100 x 100 conditional on 25 data, spherical range 10", lambda: gss.solve(cond, gss.LUGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0))))))
 timed("SGS 100 x 100 conditional, 16 neighbours, 3 realisations", lambda: gss.solve(cond, gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=10.0), maxneighbors=16, neighborhood=gss.MetricBall(20.0))))))
 timed("IDW 100 data -> 64 x 64 cells", lambda: gss.solve(prob, gss.IDWSolver(("z", dict(maxneighbors=8)))))
+timed("FFTGS 100 x 100 conditional on 25 data (fft.jl:25-32), 3 realisations", lambda: gss.solve(cond, gss.FFTGS(("z", dict(variogram=gss.GaussianVariogram(range=10.0), maxneighbors=10)))))
+timed("FFTGS 100 x 100 conditional, global kriging of the residuals", lambda: gss.solve(cond, gss.FFTGS(("z", dict(variogram=gss.GaussianVariogram(range=10.0))))))
+timed("UK degree 1, 100 data -> 64 x 64 cells, spherical", lambda: gss.solve(prob, gss.KrigingSolver(("z", dict(variogram=gss.SphericalVariogram(range=20.0), degree=1)))))
+timed("LWR 100 data -> 64 x 64 cells, 10 neighbours", lambda: gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=10)))))
+big = gss.EstimationProblem(gss.georef({"z": rng.normal(size=2000)}, rng.uniform(0, 256, (2000, 2))), gss.CartesianGrid(256, 256), "z")
+timed("OK, 2000 data -> 256 x 256 cells, 16 neighbours", lambda: gss.solve(big, gss.KrigingSolver(("z", dict(variogram=gss.SphericalVariogram(range=30.0), maxneighbors=16)))))
+timed("OK, 2000 data -> 256 x 256 cells, global", lambda: gss.solve(big, gss.KrigingSolver(("z", dict(variogram=gss.SphericalVariogram(range=30.0))))))
