@@ -379,28 +379,98 @@ __global__ __launch_bounds__(256) void sgs_level_chain_kernel(const int64_t* __r
                                                               const int* __restrict__ rank, const int* __restrict__ idx,
                                                               const int* __restrict__ ncond, int k, int64_t N,
                                                               int64_t npaths, int* level, int* __restrict__ gave_up) {
+  // Consecutive nodes of an order are neighbours of each other, and a level that a lane of the same wave has just
+  // found is taken from its register instead of waiting for it to come back from memory: up to SC of a thread's
+  // neighbours (the first ones of its list that lanes of its own wave own -- the list is sorted by distance, so these
+  // are the nodes just before it in a row) are followed that way, the others are polled.
+  constexpr int SC = 6;
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;   // paths one after the other, N nodes each
-  if (g >= N * npaths) return;
-  const int64_t base = g / N * N;                    // first entry of this thread's path in the per-path arrays
-  const int64_t p = base + path[g];                  // (path, node) as one index
-  if (rank[p] < 0) return;   // conditioning cell: level 0 (sgs_level_init_kernel)
-  const int c = ncond[p];
+  const bool inside = g < N * npaths;
+  const int64_t gg = inside ? g : N * npaths - 1;
+  const int64_t base = gg / N * N;                   // first entry of this thread's path in the per-path arrays
+  const int64_t p = base + path[gg];                 // (path, node) as one index
+  const bool mine = inside && rank[p] >= 0;          // not a conditioning cell (level 0, sgs_level_init_kernel)
+  const int c = mine ? ncond[p] : 0;
   const int* nb = idx + p * k;                       // node numbers within the path
   level += base;
+  const int lane = threadIdx.x & 63;
+  int so[SC], sj[SC];                                // owner lane and list position of the followed neighbours
+  unsigned long long intra = 0;                      // their positions as a mask (all within the first 64)
+#pragma unroll
+  for (int u = 0; u < SC; ++u) so[u] = sj[u] = -1;
+  {
+    const int cl = c < 64 ? c : 64;
+    int nf = 0;
+    for (int j = 0; j < cl && nf < SC; ++j) {
+      const int rj = rank[base + nb[j]];
+      const int64_t og = base + rj;                  // thread that owns the neighbour: its rank in the order
+      if (rj >= 0 && (og >> 6) == (gg >> 6)) {
+#pragma unroll
+        for (int u = 0; u < SC; ++u)
+          if (u == nf) {
+            so[u] = (int)(og & 63);
+            sj[u] = j;
+          }
+        intra |= 1ull << j;
+        ++nf;
+      }
+    }
+  }
   // neighbours are polled 64 at a time and a neighbour whose level is known is never asked again: with hundreds of
   // thousands of threads in flight, polling everything on every round makes the polls the bottleneck
   // The loop is left by the whole wave at once (__all): a lane that has published must not be parked behind the
   // loop's exit while lanes of its own wave still wait for what it published -- and a store on a path that leaves
   // the loop is, for the compiler, a store after the loop.
-  bool done = false;
+  bool done = !mine;
+  int mylevel = mine ? -1 : 0;                       // (a conditioning cell's level is 0; lanes outside are never asked)
   int polls = 0, mx = 0, j0 = 0;
   int cc = c < 64 ? c : 64;
   unsigned long long pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
+  auto settle = [&]() {   // pend == 0: next 64 neighbours, or publish
+    j0 += 64;
+    if (j0 >= c) {
+      mylevel = mx + 1;
+      __hip_atomic_store(&level[p - base], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = true;
+    } else {
+      cc = c - j0 < 64 ? c - j0 : 64;
+      pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
+    }
+  };
+  bool news = false;   // a lane of this wave has found its level since the last exchange inside the wave (uniform)
+  int idle = 0;        // rounds in a row without any answer (uniform)
   for (;;) {
+    // inside the wave: every lane offers its level, every lane takes what its first 64 neighbours in this wave have;
+    // repeated while that lets another lane finish (a row of the row-by-row order resolves lane after lane).  Only
+    // when there is news: a wave that waits for other waves keeps to its polls.
+    for (int sweep = 0; news && sweep < 64; ++sweep) {
+      bool fresh = false;
+      int lv[SC];
+#pragma unroll
+      for (int u = 0; u < SC; ++u) lv[u] = __shfl(mylevel, so[u] >= 0 ? so[u] : lane);   // every lane takes part
+#pragma unroll
+      for (int u = 0; u < SC; ++u) {
+        if (!done && so[u] >= 0 && lv[u] >= 0 && ((pend >> sj[u]) & 1ull) && j0 == 0) {
+          mx = lv[u] > mx ? lv[u] : mx;
+          pend &= ~(1ull << sj[u]);
+        }
+      }
+      if (!done && pend == 0) {
+        settle();
+        fresh = done;
+      }
+      if (!__any(fresh)) break;
+    }
+    news = false;
+    const bool was_done = done;
+    const unsigned long long pend_before = pend;
+    const int j0_before = j0;
     if (!done) {
       // up to eight of the unknown neighbours per round, their loads in flight together: a round is one memory
-      // round trip, and a round is what a hop of the chain costs (consecutive nodes of an order share a wave)
-      unsigned long long m = pend;
+      // round trip, and a round is what a hop of the chain costs between waves
+      // (what a lane of this wave owns arrives through the exchange above and is not asked for in memory: with
+      // hundreds of thousands of threads polling, the polls themselves are what the kernel waits for)
+      unsigned long long m = j0 == 0 ? pend & ~intra : pend;
       int js[8], ls[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -420,23 +490,30 @@ __global__ __launch_bounds__(256) void sgs_level_chain_kernel(const int64_t* __r
         }
       }
       if (pend == 0) {
-        j0 += 64;
-        if (j0 >= c) {
-          __hip_atomic_store(&level[p - base], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          done = true;
-        } else {
-          cc = c - j0 < 64 ? c - j0 : 64;
-          pend = cc == 64 ? ~0ull : ((1ull << cc) - 1ull);
-        }
+        settle();
       } else if (++polls > (1 << 18)) {
         // never seen; the wait is bounded all the same: publish, report, and the host drops the schedule
+        mylevel = 1 << 29;
         __hip_atomic_store(&level[p - base], 1 << 29, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *gave_up = 1;
         done = true;
       }
     }
     if (__all(done)) break;
-    __builtin_amdgcn_s_sleep(8);
+    news = __any(done && !was_done);
+    // A wave that learns nothing backs off (up to ~16 us between polls): with a quarter of a million threads asking,
+    // the polls of the waves far behind the front are what the waves at the front wait for.  Any answer -- one
+    // neighbour's level is enough -- brings the wave back to polling at once.
+    if (__any(pend != pend_before || j0 != j0_before || done != was_done)) idle = 0;
+    else ++idle;
+    if (!news) {
+      if (idle < 4) {
+        __builtin_amdgcn_s_sleep(8);
+      } else {
+        const int reps = idle - 3 < 4 ? idle - 3 : 4;
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+      }
+    }
   }
 }
 
