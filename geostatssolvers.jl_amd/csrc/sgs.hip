@@ -1033,10 +1033,12 @@ static int32_t sgs_build_levels(gss_sgs* h, hipStream_t s) {
   const int64_t nsim = N - h->lvl_off[1];
   const double avg = L > 0 ? (double)nsim / (double)L : 0.0;
   const bool want = team_env ? team_env[0] != '0' : avg <= 128.0;
-  if (h->npaths == 1 && h->k <= 64 && h->k % 4 == 0 && L > 0 && want) {
+  // (any maxneighbors up to 64 -- the reference's default is 10 --: the staged rows are padded to a multiple of four,
+  //  the padding adds exact zeros like the entries beyond a node's ncond)
+  if (h->npaths == 1 && h->k <= 64 && L > 0 && want) {
     h->team_rl = avg <= 14.0 ? 64 : avg <= 28.0 ? 32 : avg <= 56.0 ? 16 : 8;   // one round (896 / RL nodes) per level where possible
     int kn = 0, kw = 0;
-    sgs_team_strides(h->k, &kn, &kw);
+    sgs_team_strides((h->k + 3) & ~3, &kn, &kw);
     int cap = SGS_TEAM_ENTRIES / kn < SGS_TEAM_CAP ? SGS_TEAM_ENTRIES / kn : SGS_TEAM_CAP;
     if (cap > SGS_TEAM_NORMALS / h->team_rl) cap = SGS_TEAM_NORMALS / h->team_rl;
     std::vector<int> co;
@@ -1339,7 +1341,8 @@ static int32_t sgs_realize_block(gss_sgs_t* h, uint64_t seed, int64_t first_real
     {
       ProfScope ps("sgs_sweep", s);
       int kn = 0, kw = 0;
-      sgs_team_strides(h->k, &kn, &kw);
+      const int kp = (h->k + 3) & ~3;   // list length the kernel walks: the rows are padded beyond it
+      sgs_team_strides(kp, &kn, &kw);
 #define GSS_SGS_TEAM_LAUNCH(W)                                                                                         \
   do {                                                                                                                 \
     static bool attr_set = false;                                                                                      \
@@ -1351,7 +1354,7 @@ static int32_t sgs_realize_block(gss_sgs_t* h, uint64_t seed, int64_t first_real
     }                                                                                                                  \
     hipLaunchKernelGGL((sgs_level_team_kernel<W>), dim3((unsigned)nteams), dim3(SGS_TEAM_THREADS),                     \
                        SGS_TEAM_STAGES * sizeof(SgsTeamStage), s, h->nb_sched.as<int>(), h->w_sched.as<double>(),      \
-                       h->sg_sched.as<double>(), h->chunk_off.as<int>(), h->team_chunks, h->k, kn, kw, N, h->mean,     \
+                       h->sg_sched.as<double>(), h->chunk_off.as<int>(), h->team_chunks, kp, kn, kw, N, h->mean,       \
                        zt.as<double>());                                                                               \
   } while (0)
       switch (RL) {

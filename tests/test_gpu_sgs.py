@@ -330,7 +330,7 @@ def test_short_levels_in_one_launch_are_bit_identical_to_both_other_sweeps():
     with the field in a layout of its own (a workgroup per group of realisations, workgroup barriers between levels,
     lists and normals staged by LDS-direct loads).  Forced on (GSS_SGS_TEAM=1) it must give, bit for bit, the fields of
     the launch-per-level sweep (GSS_SGS_TEAM=0) and of the wave that walks the path (GSS_SGS_LEVELS=0): 2-D and 3-D
-    grids, 4 ... 20 neighbours, conditioning data, realisation counts that do not fill the last group, a random order
+    grids, 4 ... 20 neighbours (10, the reference's default, and 7: lists that are not a multiple of four), conditioning data, realisation counts that do not fill the last group, a random order
     (long levels: several chunks and rounds per level), supplied normals."""
     import os
     import subprocess
@@ -341,7 +341,8 @@ def test_short_levels_in_one_launch_are_bit_identical_to_both_other_sweeps():
             "out = sys.argv[1]\n"
             "res = []\n"
             "for dims, k, R, order in (((96, 80), 16, 67, None), ((70, 50), 12, 8, None), ((24, 18, 10), 20, 130, None),\n"
-            "                          ((64, 64), 4, 9, None), ((90, 70), 16, 33, 'random'), ((40, 30), 8, 3, 'noise')):\n"
+            "                          ((64, 64), 4, 9, None), ((90, 70), 16, 33, 'random'), ((40, 30), 8, 3, 'noise'),\n"
+            "                          ((60, 45), 10, 5, None), ((50, 40), 7, 3, None)):\n"
             "    N = int(np.prod(dims)); rng = np.random.default_rng(N)\n"
             "    g = np.meshgrid(*[np.arange(d) + 0.5 for d in dims], indexing='ij')\n"
             "    cent = np.stack([a.ravel(order='F') for a in g], 1)\n"
@@ -362,7 +363,7 @@ def test_short_levels_in_one_launch_are_bit_identical_to_both_other_sweeps():
             subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
             with np.load(out) as f:
                 outs.append([f[k] for k in f.files])
-    assert len(outs[0]) == 6
+    assert len(outs[0]) == 8
     for a, b, c in zip(*outs):
         assert a.shape == b.shape == c.shape and np.isfinite(a).all()
         assert np.array_equal(a, b) and np.array_equal(a, c)
