@@ -3,7 +3,7 @@
 line per config with its roofline and a bounded CPU baseline (oracle).  `bench.py` stays the headline
 (configs[1]); this script feeds DESIGN.md section 5 and profiles/.
 
-    python bench_configs.py [--configs 1h,2,2h,3,4,bigk,lu,idw,lwr,sgs,est_all,cond_fftgs] [--quick]
+    python bench_configs.py [--configs 1h,2,2h,3,4,bigk,lu,idw,lwr,sgs,sgs_bigk,est_all,cond_fftgs] [--quick]
 """
 import argparse
 import json
@@ -484,6 +484,51 @@ def cfg_cond_fftgs(a, gss, _lib):
             "cells_per_s": round(N * R / dt, 1), "solve_s": round(dt, 3), "field_std": round(float(np.std(z0)), 4)}
 
 
+def cfg_sgs_bigk(a, gss, _lib):
+    """SGS with more than 64 neighbours (seq.jl:91-98 accepts any maxneighbors): the functional path of the library --
+    search in passes of 64, `sgs_weights_big_kernel` (one workgroup per node), `sgs_level_sweep_kernel` / the walk along
+    the path.  128 x 128 grid, spherical range 35, 100 neighbours, 64 realisations."""
+    from gss.engine import SGSHandle
+    from oracle import fftgs as offt
+    e, k, R = (64 if a.quick else 128), 100, 64
+    cent = offt.grid_centroids((e, e))
+    N = cent.shape[0]
+    rng = np.random.default_rng(5)
+    dl = np.sort(rng.choice(N, 50, replace=False))
+    zd = rng.normal(size=50)
+    vg = gss.SphericalVariogram(range=35.0)
+    SGSHandle(vg, cent[:2000], None, dl[dl < 2000], zd[dl < 2000], 0.0, k, 1, 30.0).close()
+    sync()
+    t0 = time.perf_counter()
+    h = SGSHandle(vg, cent, None, dl, zd, 0.0, k, 1, 30.0)
+    sync()
+    t_pre = time.perf_counter() - t0
+    z = h.realize(1, 0, R, device=True)
+    sync()
+    t0 = time.perf_counter()
+    h.realize(1, 0, R, out=z)
+    sync()
+    dt = time.perf_counter() - t0
+    zc = z.cpu().numpy()
+    honoured = bool(np.array_equal(zc[:, dl], np.tile(zd, (R, 1))))
+    h.close()
+    from oracle import sgs as S
+    from oracle.variogram import Variogram
+    ce = 32
+    cc = offt.grid_centroids((ce, ce))
+    t1 = time.perf_counter()
+    S.realize(Variogram("spherical", range=35.0), 0.0, cc, None, np.array([100, 700]), np.array([1.0, 0.0]), 1, 0, 1,
+              maxneighbors=k, radius=30.0)
+    cdt = time.perf_counter() - t1
+    return {"config": "8f.4 SGS %dx%d grid, spherical range 35, k=%d (functional path beyond 64 neighbours), ball 30, 50 data, "
+                      "%d realisations" % (e, e, k, R),
+            "metric": "simulated cells/s (all realisations)", "value": round(N * R / dt, 1), "unit": "cells/s",
+            "preprocess_s": round(t_pre, 3), "realize_s": round(dt, 4), "hard_data_honoured": honoured,
+            "field_std": round(float(zc.std()), 4),
+            "cpu_baseline": {"value": round(ce * ce / cdt, 1), "unit": "cells/s", "cores": 1, "kind": "port",
+                             "sample": "oracle.sgs.realize, one realisation of a %dx%d grid in %.1f s" % (ce, ce, cdt)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="2,3,4")
@@ -494,7 +539,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -7,7 +7,7 @@ O=gpurun_out/round_end
 rm -rf $O; mkdir -p $O
 timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 tail -1 $O/bench_n1.json | cut -c1-300
-timeout -k 10 900 python3 bench_configs.py --configs 1h,2,2h,3,4,bigk,lu,cond_fftgs,idw,lwr,sgs > $O/bench_configs.jsonl 2> $O/bench_configs.err || exit 1
+timeout -k 10 900 python3 bench_configs.py --configs 1h,2,2h,3,4,bigk,lu,cond_fftgs,idw,lwr,sgs,sgs_bigk > $O/bench_configs.jsonl 2> $O/bench_configs.err || exit 1
 echo configs done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats4 -o k -- python3 bench_configs.py --configs 4,bigk,idw,lwr > $O/cfg4_under_rocprof.jsonl 2> $O/rocprof4.err || exit 1
