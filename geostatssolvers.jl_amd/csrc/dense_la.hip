@@ -221,11 +221,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_generic_kernel(GemmArgs g) {
 
 template <int T, bool AI, bool BJ>
 static int32_t gemm_launch(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
+  static uint64_t attr = 0;
+  if (first_on_this_device(attr)) {
     GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_generic_kernel<T, AI, BJ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmTile<T>::LDS_BYTES));
-    attr = true;
   }
   const unsigned tn = (unsigned)((g.N + T - 1) / T), tm = (unsigned)((g.M + T - 1) / T);
   const bool by_col = (g.tri & (GEMM_TRI_B_UPPER | GEMM_TRI_B_LOWER)) != 0;   // see the kernel: row tile = fast index
@@ -1210,12 +1209,11 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
     return GSS_OK;
   }
   if (use_panel(n) && lda < PANEL_MAX_LD && ldw < PANEL_MAX_LD && (n % 16 == 0 || padded16)) {
-    static bool attr = false;
-    if (!attr) {
+    static uint64_t attr = 0;
+    if (first_on_this_device(attr)) {
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_panel_kernel<PANEL_WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
-      attr = true;
-    }
+      }
     // test hook: GSS_PANEL_FAIL=1 makes the first such launch of the process report what a launch whose workgroups did
     // not all arrive reports (*d_info = -1), so that the callers' recovery (potrf_panel_disable, retry) can be exercised
     static std::atomic<bool> fail_once{std::getenv("GSS_PANEL_FAIL") != nullptr};
@@ -1258,12 +1256,11 @@ static int32_t potrf_inverse_rec(double* A, int64_t lda, double* W, int64_t ldw,
     return GSS_OK;
   }
   if (n <= 2 * LEAF) {
-    static bool attr = false;
-    if (!attr) {
+    static uint64_t attr = 0;
+    if (first_on_this_device(attr)) {
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_inv_leaf128_kernel<8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L128_LDS_BYTES));
-      attr = true;
-    }
+      }
     hipLaunchKernelGGL(potrf_inv_leaf128_kernel<8>, dim3(1), dim3(512), L128_LDS_BYTES, s, A, (int)n, lda, (int)row_offset,
                        d_info, W, ldw);
     GSS_HIP(hipGetLastError());

@@ -267,10 +267,12 @@ static int32_t ensure_rocfft(gss_fftgs* h) {
     rocfft_kernel_cache_default();
     rocfft_setup();
   });
-  using Key = std::array<size_t, 4>;
+  using Key = std::array<size_t, 5>;   // rocFFT plans belong to the device that was current when they were made
   // most recent first; calls hold the library lock; never destroyed (at exit rocFFT's own statics may be gone first)
   static auto& cache = *new std::list<std::pair<Key, std::shared_ptr<FftPlans>>>();
-  const Key key = {(size_t)h->ndim, (size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
+  int dev = 0;
+  GSS_HIP(hipGetDevice(&dev));
+  const Key key = {(size_t)h->ndim, (size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3, (size_t)dev};
   for (auto it = cache.begin(); it != cache.end(); ++it)
     if (it->first == key) {
       h->plans = it->second;

@@ -752,6 +752,16 @@ int32_t potrf_f64(double* A, int64_t n, int64_t lda, int* d_info, double* dinv, 
 int64_t potrf_inverse_work_doubles(int64_t n);
 // after a *d_info of -1: no more single-launch panels in this process (callers retry on the launch-per-block recursion)
 void potrf_panel_disable();
+// Settings that HIP keeps per device (function attributes, library plans): true the first time this is called with
+// `mask` on the current device.  Exports hold the library lock, so the word needs no atomics.
+inline bool first_on_this_device(uint64_t& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
 void lu_grid_disable();   // lu.hip: 32-column LU panels on one workgroup instead of the grid
 // padded16: the caller guarantees that rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are
 // zero (they stay zero): a size that is not a multiple of 16 then still runs on the single-launch panel kernel.

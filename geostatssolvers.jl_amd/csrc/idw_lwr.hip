@@ -546,7 +546,8 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
                                                        int64_t m, int k, int minneighbors, const int* __restrict__ idx,
                                                        const int* __restrict__ count, int aniso, double ir0, double ir1,
                                                        double ir2, double* __restrict__ mean_out,
-                                                       double* __restrict__ aux_out, uint8_t* __restrict__ status_out) {
+                                                       double* __restrict__ aux_out, uint8_t* __restrict__ status_out,
+                                                       int ncheck) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= m) return;
   const double ir[3] = {ir0, ir1, ir2};
@@ -555,8 +556,19 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
   double qc[DIM];
 #pragma unroll
   for (int a = 0; a < DIM; ++a) qc[a] = x0[p * DIM + a];
-  const int cnt = count[p];
+  int cnt = count[p];
   const int* nb = idx + p * k;
+  if (ncheck > 0) {   // lists that come from the caller (gss_lwr_predict_weights): never gather through a bad entry
+    cnt = cnt > k ? k : cnt;
+    bool bad = false;
+    for (int j = 0; j < cnt; ++j) bad |= (unsigned)nb[j] >= (unsigned)ncheck;
+    if (bad) {
+      mean_out[p] = NaN;
+      aux_out[p] = NaN;
+      status_out[p] = GSS_PT_SINGULAR;
+      return;
+    }
+  }
   if (cnt < minneighbors || cnt < 1) {
     mean_out[p] = NaN;
     aux_out[p] = NaN;
@@ -671,7 +683,7 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
       ProfScope pl(pname, s);
       const dim3 grid((unsigned)((mv + 255) / 256));
 #define GSS_EST_LIST_ARGS sp, xdata, z, x0 + off * dim, mv, k, minneighbors, idx_s.as<int>(), cnt_s.as<int>(), aniso, \
-                          ir[0], ir[1], ir[2], mean + off, aux + off, status + off
+                          ir[0], ir[1], ir[2], mean + off, aux + off, status + off, 0
       switch (dim) {
         case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
         case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
@@ -875,7 +887,7 @@ int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n,
   sp.wsup = sw.as<double>();
   const dim3 grid((unsigned)((m + 255) / 256));
 #define GSS_LWRW_ARGS sp, sxd.as<double>(), sz.as<double>(), sx.as<double>(), m, (int)k, (int)minneighbors, si.as<int>(), \
-                      sc.as<int>(), 0, 1.0, 1.0, 1.0, smean.as<double>(), svar.as<double>(), st
+                      sc.as<int>(), 0, 1.0, 1.0, 1.0, smean.as<double>(), svar.as<double>(), st, (int)n
   switch (dim) {
     case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
     case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;

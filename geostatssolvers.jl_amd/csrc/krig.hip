@@ -1048,13 +1048,12 @@ int32_t gss_krig_predict_global(gss_krig_t* h, const double* xdom, const double*
   hipStream_t s = to_stream(stream);
   const int dim = h->dim;
 
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_set = 0;
+  if (first_on_this_device(attr_set)) {
     GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
     GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_quadform_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)QUADFORM_LDS_BYTES));
-    attr_set = true;
   }
 
   int64_t mc = krig_chunk_points(h->N1pad, m);

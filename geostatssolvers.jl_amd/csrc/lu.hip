@@ -120,43 +120,70 @@ struct LuCand {                   // what a workgroup publishes per column: its 
   double a[LU_NB];
 };
 
-__device__ __forceinline__ void lu_grid_sync(unsigned* cnt, unsigned* dead, unsigned& epoch, int* info, int G) {
+// One grid barrier.  bar[0] counts arrivals; its top bit says "this panel is given up".  A workgroup gives up by a
+// compare-and-swap against the count it last saw, so the bit can only be set while the barrier it waits at is incomplete:
+// once ANY workgroup has passed the last barrier of a panel nobody can give up any more, and once the bit is set nobody
+// passes a barrier -- the verdict is the same for every workgroup of the launch (and, through LDS, for every thread of a
+// workgroup).  Returns true when the panel is dead.
+constexpr unsigned LU_DEAD = 0x80000000u;
+__device__ __forceinline__ bool lu_grid_sync(unsigned* cnt, unsigned& epoch, int G, unsigned spin_limit, unsigned* s_dead) {
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
     __threadfence();
-    atomicAdd(cnt, 1u);
     const unsigned target = epoch * (unsigned)G;
-    unsigned spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-      if (++spins > 4000000u) {   // the workgroups are not all resident: give up, the host repeats the panel
-        __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v = atomicAdd(cnt, 1u) + 1u;
+    unsigned spins = 0, dead = 0u;
+    for (;;) {
+      if (v & LU_DEAD) {
+        dead = 1u;
         break;
       }
+      if (v >= target) break;
+      if (++spins > spin_limit) {   // the workgroups are not all resident: give up, the host repeats the factorisation
+        const unsigned old = atomicCAS(cnt, v, v | LU_DEAD);
+        if (old == v) {
+          dead = 1u;
+          break;
+        }
+        v = old;                    // somebody arrived (or gave up) meanwhile: look again
+        continue;
+      }
       __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();
+    *s_dead = dead;
   }
   __syncthreads();
+  return *s_dead != 0u;
 }
 
-// bar[0] arrivals, bar[1] gave up (the host then falls back), bar[2] departures; cand: 2 x (LUG_WG_MAX candidates + row c)
+// bar[0] arrivals (+ LU_DEAD), bar[1] a panel of this factorisation was given up (sticky: the later panels of the same
+// factorisation return at once, the host repeats it on the single-workgroup panels), bar[2] departures; cand: 2 x
+// (LUG_WG_MAX candidates + row c).  A panel that is given up leaves P as it found it, identity interchanges in ipiv
+// and *info = -1.
 __global__ __launch_bounds__(LUG_NT) void getrf_panel_grid_kernel(double* __restrict__ P, int64_t m, int jb, int64_t lda,
                                                                   int64_t j0, int* __restrict__ ipiv,
                                                                   int* __restrict__ info, unsigned* __restrict__ bar,
-                                                                  LuCand* __restrict__ cand) {
+                                                                  LuCand* __restrict__ cand, unsigned spin_limit) {
   __shared__ double s_val[LUG_NT / 64];
   __shared__ long long s_row[LUG_NT / 64];
   __shared__ double s_urow[LU_NB];
   __shared__ double s_crow[LU_NB];
   __shared__ double s_rec[(LUG_WG_MAX + 1) * (LU_NB + 2)];
   __shared__ long long s_piv;
+  __shared__ unsigned s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int RPT = 1;
   const int wg = blockIdx.x;
   const int G = gridDim.x;
   unsigned epoch = 0;
+  // (bar[1] was written by an earlier launch of this stream: every workgroup of this launch reads the same value)
+  if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (wg == 0 && tid < jb) ipiv[tid] = (int)(j0 + tid);
+    return;
+  }
   // rows of this thread: r = (q * LUG_WG + wg) * LUG_NT + tid  (consecutive threads, consecutive rows: coalesced)
   double a[RPT][LU_NB];
   int64_t row[RPT];
@@ -227,8 +254,11 @@ __global__ __launch_bounds__(LUG_NT) void getrf_panel_grid_kernel(double* __rest
           }
         }
       }
-      lu_grid_sync(bar, bar + 1, epoch, info, G);
-      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
+      dead = lu_grid_sync(bar, epoch, G, spin_limit, &s_dead);
+    }
+    // (a dead panel decides nothing: its peers' records may never have been written)
+    if (c < jb && c < m && !dead) {
+      LuCand* slot = cand + (size_t)(c & 1) * (LUG_WG_MAX + 1);
       // ---- the decision, the same on every workgroup: best candidate, ties to the smaller row.  Every candidate
       // record and row c come into LDS with ONE round trip to memory (the records were written by other XCDs:
       // agent-scope loads), the choice is made there
@@ -301,19 +331,25 @@ __global__ __launch_bounds__(LUG_NT) void getrf_panel_grid_kernel(double* __rest
       __syncthreads();   // s_urow / s_crow are rewritten by the next column
     }
   });
+  if (!dead) {
 #pragma unroll
-  for (int q = 0; q < RPT; ++q)
+    for (int q = 0; q < RPT; ++q)
 #pragma unroll
-    for (int c = 0; c < LU_NB; ++c)
-      if (row[q] < m && c < jb) P[row[q] + (int64_t)c * lda] = a[q][c];
+      for (int c = 0; c < LU_NB; ++c)
+        if (row[q] < m && c < jb) P[row[q] + (int64_t)c * lda] = a[q][c];
+  } else if (wg == 0 && tid < jb) {
+    ipiv[tid] = (int)(j0 + tid);   // whatever the columns before the give-up chose: P was not touched
+  }
   // the last workgroup out resets the barrier words for the next panel on this stream
   __syncthreads();
   if (tid == 0) {
     __threadfence();
     if (atomicAdd(&bar[2], 1u) == (unsigned)G - 1u) {
-      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicCAS(info, 0, -1);
+      if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & LU_DEAD) {
+        atomicExch(info, -1);      // unconditionally: a "singular" verdict of this factorisation means nothing now
+        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -399,8 +435,12 @@ static int32_t lu_panel(double* P, int64_t m, int jb, int64_t lda, int64_t j0, i
                         LuCand* cand, bool* grid_ok, hipStream_t s) {
   if (*grid_ok && m > 1024 && m <= (int64_t)LUG_WG_MAX * LUG_NT) {
     const int G = m <= (int64_t)LUG_WG * LUG_NT ? LUG_WG : (m <= (int64_t)32 * LUG_NT ? 32 : LUG_WG_MAX);
+    // test hook: GSS_LU_PANEL_FAIL=1 gives the first grid panel of the process no patience at its barriers, so that its
+    // workgroups really take the give-up path (tests/test_gpu_dense.py)
+    static std::atomic<bool> fail_once{std::getenv("GSS_LU_PANEL_FAIL") != nullptr};
+    const unsigned spin_limit = fail_once.exchange(false) ? 0u : 4000000u;
     hipLaunchKernelGGL(getrf_panel_grid_kernel, dim3((unsigned)G), dim3(LUG_NT), 0, s, P, m, jb, lda, j0, ipiv, d_info, bar,
-                       cand);
+                       cand, spin_limit);
   } else {
     hipLaunchKernelGGL(getrf_panel_kernel, dim3(1), dim3(LU_NT), 0, s, P, m, jb, lda, j0, ipiv, d_info);
   }
@@ -413,6 +453,7 @@ int32_t getrf_unit_lower_f64(double* A, int64_t n, int64_t lda, int* ipiv, int* 
   GSS_TRY(barbuf.alloc(64));
   GSS_TRY(candbuf.alloc(sizeof(LuCand) * 2 * (LUG_WG_MAX + 1)));
   GSS_TRY(dev_zero_bytes(barbuf.p, 64, s));
+  GSS_TRY(dev_zero_bytes(candbuf.p, sizeof(LuCand) * 2 * (LUG_WG_MAX + 1), s));
   unsigned* bar = barbuf.as<unsigned>();
   LuCand* cand = candbuf.as<LuCand>();
   bool grid_ok = !g_lu_grid_off.load();
@@ -462,8 +503,9 @@ int32_t getrf_unit_lower_f64(double* A, int64_t n, int64_t lda, int* ipiv, int* 
                        A12 + o0 + ob, 1, lda, false, s));
     }
   }
-  // (a grid panel whose workgroups did not all arrive reports *d_info = -1: the caller calls lu_grid_disable() and
-  // repeats the factorisation from the original matrix, as for the single-launch Cholesky panel)
+  // (a grid panel whose workgroups did not all arrive reports *d_info = -1 and the later grid panels of this call return
+  // at once: A is then neither the input nor a factor.  The caller calls lu_grid_disable() and repeats the factorisation
+  // from the original matrix, as for the single-launch Cholesky panel)
   hipLaunchKernelGGL(unit_lower_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, A, n, lda);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
@@ -489,7 +531,8 @@ int32_t gss_dev_getrf_l(double* a, int64_t n, int64_t lda, void* stream) {
   GSS_HIP(hipStreamSynchronize(s));
   if (h < 0) {
     lu_grid_disable();
-    set_error("LU factorisation: the grid panel gave up waiting at a barrier; switched off for this process, call again");
+    set_error("LU factorisation: the grid panel gave up waiting at a barrier and is switched off for this process; the "
+              "matrix was overwritten in place -- restore the input, then call again");
     return GSS_ERR_HIP;
   }
   if (h != 0) {

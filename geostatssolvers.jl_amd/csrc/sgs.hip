@@ -1345,12 +1345,11 @@ static int32_t sgs_realize_block(gss_sgs_t* h, uint64_t seed, int64_t first_real
       sgs_team_strides(kp, &kn, &kw);
 #define GSS_SGS_TEAM_LAUNCH(W)                                                                                         \
   do {                                                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
+    static uint64_t attr_set = 0;                                                                                      \
+    if (first_on_this_device(attr_set)) {                                                                              \
       GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sgs_level_team_kernel<W>),                             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
                                   (int)(SGS_TEAM_STAGES * sizeof(SgsTeamStage))));                                     \
-      attr_set = true;                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((sgs_level_team_kernel<W>), dim3((unsigned)nteams), dim3(SGS_TEAM_THREADS),                     \
                        SGS_TEAM_STAGES * sizeof(SgsTeamStage), s, h->nb_sched.as<int>(), h->w_sched.as<double>(),      \

@@ -542,8 +542,19 @@ class HipEngine:
         d = np.where(valid, d, 0.0)
         with np.errstate(invalid="ignore", divide="ignore"):
             delta = d / d.max(axis=1, keepdims=True)             # lwr.jl:132
-        w = np.where(valid, np.asarray(weightfun(delta), dtype=np.float64), 0.0)   # lwr.jl:136
-        w = np.ascontiguousarray(np.nan_to_num(w, nan=0.0))
+        # lwr.jl:136 `weightfun.(deltas)`: elementwise, on the neighbours that exist only; a scalar-only callable
+        # (`lambda h: 1 - h if h < 1 else 0`) is mapped over them; a NaN weight (every distance zero: 0 / 0) stays NaN,
+        # so that the point is reported singular as the reference's NaN estimate would show
+        dv = delta[valid]
+        try:
+            wv = np.asarray(weightfun(dv), dtype=np.float64)
+            if wv.shape != dv.shape:
+                raise ValueError("weightfun did not map elementwise")
+        except (TypeError, ValueError):
+            wv = np.fromiter((float(weightfun(float(t))) for t in dv), dtype=np.float64, count=dv.size)
+        w = np.zeros_like(delta)
+        w[valid] = wv
+        w = np.ascontiguousarray(w)
         mean, var, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
         check(_lib.lib().gss_lwr_predict_weights(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k),
                                                  int(minneighbors), ptr(np.ascontiguousarray(idx)),

@@ -233,3 +233,57 @@ def test_getrf_unit_lower_matches_lapack(n):
     P, Lref, U = sla.lu(A)
     assert not np.array_equal(P, np.eye(n)) or n < 3
     assert np.max(np.abs(L - Lref)) < 1e-10 * max(1.0, np.max(np.abs(np.linalg.inv(U))) * 1e-3)
+
+
+def test_lu_grid_panel_gives_up_cleanly():
+    """GSS_LU_PANEL_FAIL=1 gives the first grid panel of the process no patience at its barriers, so its workgroups
+    really leave through the give-up path of `getrf_panel_grid_kernel` (lu.hip): the verdict must be "gave up" (-1), never
+    a spurious "exactly singular matrix" from candidate records that nobody wrote, the later panels of the call must not
+    wait again, and the message must say that the matrix was overwritten.  The second call of the process runs on the
+    single-workgroup panels and matches LAPACK; `gss_lugs_create(factorization = lu)` retries by itself."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, scipy.linalg as sla, gss\n"
+        "from gss import _lib\n"
+        "n = 2500\n"
+        "A = np.random.default_rng(3).normal(size=(n, n)) + 0.5 * np.eye(n)\n"
+        "dA = torch.as_tensor(np.ascontiguousarray(A.T), device='cuda')\n"
+        "t = time.time()\n"
+        "rc = _lib.lib().gss_dev_getrf_l(_lib.ptr(dA), n, n, _lib.current_stream())\n"
+        "assert rc == _lib.ERR_HIP, rc\n"
+        "msg = _lib.last_error()\n"
+        "assert 'gave up' in msg and 'restore the input' in msg and 'singular' not in msg, msg\n"
+        "assert time.time() - t < 20.0\n"
+        "dA = torch.as_tensor(np.ascontiguousarray(A.T), device='cuda')\n"
+        "_lib.check(_lib.lib().gss_dev_getrf_l(_lib.ptr(dA), n, n, _lib.current_stream()))\n"
+        "torch.cuda.synchronize()\n"
+        "P, Lref, U = sla.lu(A)\n"
+        "assert np.max(np.abs(dA.cpu().numpy().T - Lref)) < 1e-10\n"
+        "print('GETRF RECOVERED')\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSS_LU_PANEL_FAIL="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "GETRF RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    code2 = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, gss\n"
+        "from gss.engine import LUGSHandle\n"
+        "from oracle import lugs as OL\n"
+        "from oracle.variogram import Variogram\n"
+        "cent = gss.CartesianGrid(60, 50).centroids()\n"
+        "h = LUGSHandle(gss.SphericalVariogram(range=8.0, nugget=0.05), cent, np.zeros(0, np.int64), np.zeros(0),\n"
+        "               factorization='lu')\n"
+        "L22, d2 = h.factor()\n"
+        "pre = OL.preprocess(Variogram('spherical', range=8.0, nugget=0.05), cent, factorization='lu')\n"
+        "assert np.max(np.abs(L22 - pre.L22)) < 1e-9\n"
+        "print('LUGS LU RECOVERED')\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, GSS_LU_PANEL_FAIL="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "LUGS LU RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

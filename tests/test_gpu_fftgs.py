@@ -328,3 +328,144 @@ def test_rocfft_kernels_are_kept_for_later_processes():
     if os.environ.get("ROCFFT_RTC_CACHE_PATH") is None:          # not chosen by the user: the library's default
         assert path.decode().endswith(os.path.join("gss_hip", "rocfft_kernels.db"))
         assert os.path.exists(path.decode())
+
+
+# ---- 512-point y / z lines: ff_axis2_fast_kernel<MODE,3,512,9> and the slab order (the dominant kernels of configs[2]) ----
+
+LINE512_GRIDS = [(32, 512, 512), (64, 512, 512)]
+_LINE512_KW = dict(range=40.0, sill=1.4, nugget=0.05)
+_line512_cache = {}
+
+
+def _line512_oracle(dims):
+    """Oracle fields of one grid (fft.jl:62-198 through pocketfft), computed once per session: the spectrum, two
+    Philox realisations (seed 11, realisations 2 and 3) and one realisation from supplied noise."""
+    if dims not in _line512_cache:
+        N = int(np.prod(dims))
+        pre = O.preprocess(Variogram("exponential", **_LINE512_KW), dims, mean=0.3)
+        noise = np.random.default_rng(N + 7).uniform(size=N)
+        _line512_cache[dims] = dict(F=pre.F.ravel().copy(), z=O.realize(pre, 11, 2, 2), zn=O.solvesingle(pre, noise))
+    return _line512_cache[dims]
+
+
+_LINE512_CHILD = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gss
+from gss.engine import FFTGSHandle
+dims = %r
+N = int(np.prod(dims))
+h = FFTGSHandle(gss.ExponentialVariogram(**%r), dims, mean=0.3)
+noise = np.random.default_rng(N + 7).uniform(size=(1, N))
+np.savez(%r, F=h.spectrum(), z=h.realize(11, 2, 2), zn=h.realize(0, 0, 1, noise=noise)[0])
+h.close()
+"""
+
+
+@pytest.mark.parametrize("slab", ["0", "2"])
+@pytest.mark.parametrize("dims", LINE512_GRIDS)
+def test_fused_pipeline_on_512_point_lines_matches_oracle(dims, slab, tmp_path):
+    """fft.jl:163-170 at the line length the headline number is quoted on.  y and z lines of 512 points run the
+    pass-by-pass kernel `ff_axis2_fast_kernel<MODE,3,512,9>` (csrc/fftgs_fused.h) and, with GSS_FFTGS_SLAB != 0
+    (the default), the slab order over three streams; both are compared here with the oracle -- spectrum 1e-12 of
+    max F, Philox and supplied-noise realisations 1e-9 -- in a child process per setting because the switch is read
+    once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dev.npz")
+    code = _LINE512_CHILD % (root, os.path.join(root, "geostatssolvers.jl_amd"), dims, _LINE512_KW, out)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSS_FFTGS_SLAB=slab), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dev = np.load(out)
+    ref = _line512_oracle(dims)
+    assert dev["F"][0] == 0.0
+    assert np.max(np.abs(dev["F"] - ref["F"])) < 1e-12 * ref["F"].max()
+    assert np.max(np.abs(dev["z"] - ref["z"])) < 1e-9
+    assert np.max(np.abs(dev["zn"] - ref["zn"])) < 1e-9
+
+
+def _torch_restatement_512(e, rng_range, mean, U):
+    """fft.jl:96-103 and :163-170 written with torch's complex-to-complex FFT on the device: an implementation that
+    shares nothing with the library (its pipelines are real-to-complex; this one is the reference's literal C2C form)."""
+    import torch
+    ax = torch.arange(e, device="cuda", dtype=torch.float64) + 0.5
+    c = ax[e // 2 - 1]                                              # centre cell, fft.jl:69-70 (1-based e // 2)
+    d2 = ((ax - c) ** 2)
+    h = torch.sqrt(d2[:, None, None] + d2[None, :, None] + d2[None, None, :])
+    C = torch.exp(-3.0 * h / rng_range)                             # exponential model, sill 1, no nugget
+    del h
+    F = torch.sqrt(torch.abs(torch.fft.fftn(torch.fft.fftshift(C))))    # fft.jl:102
+    del C
+    F.view(-1)[0] = 0.0                                             # fft.jl:103
+    X = torch.fft.fftn(U.reshape(e, e, e))
+    P = F * torch.exp(1j * torch.angle(X))                          # fft.jl:163
+    del X
+    Z = torch.fft.ifftn(P).real                                     # fft.jl:166
+    del P
+    s2 = float((Z * Z).sum()) / (e ** 3 - 1)                        # fft.jl:169
+    return (Z * (1.0 / s2) ** 0.5 + mean).reshape(-1), F.reshape(-1)   # fft.jl:170
+
+
+def test_config3_full_size_realisation_against_two_other_implementations(monkeypatch):
+    """configs[2] at its full 512^3: one realisation of the fused pipeline against (i) a literal complex-to-complex
+    restatement of fft.jl:96-103,163-170 in torch on the same noise (1e-9, the tolerance of the oracle comparisons;
+    spectrum 1e-12 of max F) and (ii) the library's rocFFT pipeline (a different code path that is oracle-tested at
+    the smaller sizes; 1e-10)."""
+    import torch
+    import gss
+    from gss.engine import FFTGSHandle
+    e = 512
+    N = e ** 3
+    vg = gss.ExponentialVariogram(range=50.0)
+    h = FFTGSHandle(vg, (e, e, e), mean=1.0)
+    U = torch.rand(N, device="cuda", dtype=torch.float64, generator=torch.Generator("cuda").manual_seed(5))
+    zn = h.realize(0, 0, 1, noise=U.reshape(1, N), device=True)[0].clone()
+    zp = h.realize(4, 1, 1, device=True)[0].clone()
+    Fdev = torch.as_tensor(h.spectrum(), device="cuda")
+    h.close()
+    torch.cuda.synchronize()
+    ref, F = _torch_restatement_512(e, 50.0, 1.0, U)
+    assert float((Fdev - F).abs().max()) < 1e-12 * float(F.max())
+    assert float((zn - ref).abs().max()) < 1e-9
+    del ref, F, Fdev
+    monkeypatch.setenv("GSS_FFTGS_PATH", "rocfft")
+    h2 = FFTGSHandle(vg, (e, e, e), mean=1.0)
+    zn2 = h2.realize(0, 0, 1, noise=U.reshape(1, N), device=True)[0]
+    torch.cuda.synchronize()
+    assert float((zn2 - zn).abs().max()) < 1e-10 and not torch.equal(zn2, zn)
+    zp2 = h2.realize(4, 1, 1, device=True)[0]                       # Philox noise: the in-register generator of the
+    torch.cuda.synchronize()                                        # x pass against the stand-alone noise kernel
+    assert float((zp2 - zp).abs().max()) < 1e-10 and not torch.equal(zp2, zp)
+    h2.close()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("GSS_TEST_HOST_512") != "1",
+                    reason="minutes of host FFTs and 20 GiB of host memory: opt in with GSS_TEST_HOST_512=1")
+def test_config3_full_size_realisation_against_host_fft():
+    """configs[2] at full size against the host: fft.jl:163-170 through scipy's threaded pocketfft (complex-to-complex,
+    as the reference), the spectrum taken from the device handle (oracle-checked at 16 M cells above).  Run once per
+    round; the result is recorded in profiles/."""
+    import os
+    import scipy.fft
+    import gss
+    from gss.engine import FFTGSHandle
+    e = 512
+    N = e ** 3
+    w = os.cpu_count()
+    h = FFTGSHandle(gss.ExponentialVariogram(range=50.0), (e, e, e), mean=1.0)
+    U = np.random.default_rng(5).uniform(size=N)
+    z = h.realize(0, 0, 1, noise=U.reshape(1, N))[0]
+    F = h.spectrum().reshape(e, e, e)
+    h.close()
+    X = scipy.fft.fftn(U.reshape(e, e, e), workers=w)
+    X /= np.abs(X)                                                  # exp(i angle(X)), fft.jl:163
+    X *= F
+    Z = scipy.fft.ifftn(X, workers=w, overwrite_x=True).real        # fft.jl:166
+    Z *= np.sqrt(1.0 / (np.sum(Z * Z) / (N - 1)))                   # fft.jl:169-170
+    Z += 1.0
+    err = float(np.max(np.abs(z - Z.ravel())))
+    print("512^3 fused pipeline vs scipy.fft (complex-to-complex): max abs difference %.3e" % err)
+    assert err < 1e-9

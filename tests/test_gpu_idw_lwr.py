@@ -237,3 +237,26 @@ def test_lwr_with_an_arbitrary_weight_function(dim, k, ball):
         a = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=k, weightfun=E.default_weightfun))))
         b = gss.solve(prob, gss.LWRSolver(("z", dict(maxneighbors=k))))
         assert np.max(np.abs(a["z"] - b["z"])) < 1e-10 and np.max(np.abs(a["z_variance"] - b["z_variance"])) < 1e-10
+
+
+def test_lwr_weight_function_that_only_takes_scalars():
+    """lwr.jl:136 broadcasts `weightfun` over the neighbours' normalised distances, so a function written for one number
+    (a branch, `math.exp`) is a legal `weightfun`: the host maps it over the neighbours that exist -- never over padding
+    entries of a ball search -- and the result equals the vectorised form of the same function (1e-12)."""
+    import math
+    import gss
+    rng = np.random.default_rng(17)
+    x = rng.uniform(0, 60, (400, 2))
+    z = np.cos(x[:, 0] / 7.0) + 0.02 * x[:, 1]
+    c = rng.uniform(0, 60, (150, 2))
+    prob = gss.EstimationProblem(gss.georef({"z": z}, x), gss.PointSet(c), "z")
+    scalar = lambda h: math.exp(-3.0 * h * h) if h < 0.95 else 0.01          # noqa: E731
+    vector = lambda h: np.where(h < 0.95, np.exp(-3.0 * h * h), 0.01)        # noqa: E731
+    for kw in (dict(maxneighbors=15), dict(maxneighbors=25, neighborhood=gss.MetricBall(9.0))):
+        a = gss.solve(prob, gss.LWRSolver(("z", dict(weightfun=scalar, **kw))))
+        b = gss.solve(prob, gss.LWRSolver(("z", dict(weightfun=vector, **kw))))
+        assert np.array_equal(np.isnan(a["z"]), np.isnan(b["z"]))         # (math.exp and np.exp may differ in the last bit)
+        ok = np.isfinite(a["z"])
+        assert ok.sum() > 100
+        assert np.max(np.abs(a["z"][ok] - b["z"][ok])) < 1e-12
+        assert np.max(np.abs(a["z_variance"][ok] - b["z_variance"][ok])) < 1e-12

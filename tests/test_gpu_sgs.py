@@ -367,3 +367,15 @@ def test_short_levels_in_one_launch_are_bit_identical_to_both_other_sweeps():
     for a, b, c in zip(*outs):
         assert a.shape == b.shape == c.shape and np.isfinite(a).all()
         assert np.array_equal(a, b) and np.array_equal(a, c)
+    # the team kernel's own fields against the oracle (seq.jl:102-135), directly and not through the other sweeps:
+    # the reference's default of 10 neighbours and a list length that is not a multiple of four, row-by-row order
+    for case, (dims, k, R) in ((6, ((60, 45), 10, 5)), (7, ((50, 40), 7, 3))):
+        N = int(np.prod(dims))
+        rng = np.random.default_rng(N)
+        g = np.meshgrid(*[np.arange(d) + 0.5 for d in dims], indexing="ij")
+        cent = np.stack([a.ravel(order="F") for a in g], 1)
+        dl = np.sort(rng.choice(N, 25, replace=False))
+        zd = rng.normal(size=25)
+        ref = S.realize(Variogram("spherical", range=12.0, nugget=0.05), 0.3, cent, None, dl, zd, 7, 2, R, maxneighbors=k)
+        assert np.max(np.abs(outs[0][case] - ref)) < 1e-9
+        assert np.array_equal(outs[0][case][:, dl], np.broadcast_to(zd, (R, 25)))
