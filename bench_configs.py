@@ -161,6 +161,41 @@ def cfg4_local(a, gss, _lib):
                              "sample": "oracle.kriging.approxsolve (search + fit + predict per point as krig.jl:205-228), %d points in %.1f s" % (ns, cdt)}}
 
 
+def cfg4_full(a, gss, _lib):
+    """configs[4] at its FULL size on one GPU: UK degree 1, 5 000 3-D data, k = 64, Matern-3/2, 10^7 domain points in ONE
+    gss_krig_predict_knn call (the library walks them in chunks of 2^20: search, then systems, per chunk)."""
+    from gss.engine import KrigHandle, UK
+    from oracle import kriging as K
+    from oracle.variogram import Variogram
+    n = 5000
+    m = 1_000_000 if a.quick else 10_000_000
+    x = np.random.default_rng(6).uniform(0, 100, (n, 3))
+    z = 1.0 + 0.03 * x[:, 0] - 0.02 * x[:, 1] + 0.01 * x[:, 2] + np.random.default_rng(60).normal(size=n)
+    x0d = torch.rand((m, 3), dtype=torch.float64, device="cuda", generator=torch.Generator("cuda").manual_seed(7)) * 100.0
+    h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), UK, x, z, degree=1, factor=False)
+    h.predict_knn(x0d[:50000], 64)
+    sync()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    mu, var, st = h.predict_knn(x0d, 64)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    knn = _lib.profile_read("knn")
+    loc = _lib.profile_read("krig_local")
+    flop_pt = 68 ** 3 / 3 + 2 * 68 ** 2 + 8 * n
+    ns = 200
+    sel = torch.linspace(0, m - 1, ns, device="cuda").long()          # a sample across the whole call, last chunk included
+    rmu, rvar, _ = K.approxsolve(K.UK, Variogram("matern", range=30.0, nu=1.5), x, z, x0d[sel].cpu().numpy(), 64, degree=1)
+    err = float(np.max(np.abs(mu[sel].cpu().numpy() - rmu)))
+    return {"config": "configs[4] at full size: UK degree 1, 5000 3-D data, k=64, Matern-3/2, %d points in one call on one GPU" % m,
+            "metric": "kriged points/s", "value": round(m / dt, 1), "unit": "points/s", "seconds": round(dt, 4),
+            "roofline": {"bound": "fp64-valu", "achieved": round(flop_pt * m / dt / 1e12, 3), "peak": FP64_PEAK, "unit": "TFLOP/s",
+                         "frac": round(flop_pt * m / dt / 1e12 / FP64_PEAK, 4)},
+            "kernel_ms": {"knn": round(knn[0], 2), "krig_local": round(loc[0], 2), "launches": [knn[1], loc[1]]},
+            "missing": int(st.sum().item()), "parity_max_abs_err_%d_points_across_the_call" % ns: err}
+
+
 def cfg_bigk(a, gss, _lib):
     """Moving neighbourhoods with more than 64 neighbours (krig.jl:201-210, ui.jl:16-23 accept any count): UK degree 1,
     5 000 3-D data, Matern-3/2, k = 96 / 128 / 256.  One JSON object with a row per k."""
@@ -541,7 +576,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

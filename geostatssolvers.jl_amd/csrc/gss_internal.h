@@ -728,6 +728,25 @@ __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DI
   }
 }
 
+// four independent pairs (a[u], b[u]): the paired diagonal tiles of the moving-neighbourhood kernel, where the column
+// a lane works on depends on the row (krig_local.hip)
+template <int DIM, int KIND>
+__device__ __forceinline__ void cov_pairs4_k(const VgDev& v, const double (*a)[DIM], const double (*b)[DIM], double* out) {
+  if (KIND < 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = cov_pair<DIM>(v, a[u], b[u]);
+    return;
+  }
+  double d2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) d2[u] = sqdist_scaled<DIM>(a[u], b[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
+    out[u] = d2[u] <= 0.0 ? v.sill : v.cs * g;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dense FP64 toolkit (dense_la.hip, gemm_f64.hip)
 // ---------------------------------------------------------------------------------------------

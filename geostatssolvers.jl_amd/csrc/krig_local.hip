@@ -276,38 +276,6 @@ __device__ __forceinline__ void k5_block_step(d4_t (&T)[10], d4_t (&B)[4], const
   }
 }
 
-// The same step in two parts for the look-ahead order (GSS_K5_LOOKAHEAD, an experiment of round 3): the head produces
-// the next diagonal tile -- U_KK,KK+1 and A_KK+1,KK+1 -= U'U -- so that it can be handed to the factoring wave before
-// the rest of the step's products.
-template <int KK>
-__device__ __forceinline__ void k5_step_head(d4_t (&T)[10], const d4_t& V, int nt) {
-  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-  if constexpr (KK + 1 < 4) {
-    if (KK + 1 < nt) {
-      T[tile_id(KK, KK + 1)] = xty(V, T[tile_id(KK, KK + 1)], zero4);
-      T[tile_id(KK + 1, KK + 1)] = xty(-T[tile_id(KK, KK + 1)], T[tile_id(KK, KK + 1)], T[tile_id(KK + 1, KK + 1)]);
-    }
-  }
-}
-template <int KK>
-__device__ __forceinline__ void k5_step_rest(d4_t (&T)[10], d4_t (&B)[4], const d4_t& V, int nt) {
-  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int j = KK + 2; j < 4; ++j)
-    if (j < nt) T[tile_id(KK, j)] = xty(V, T[tile_id(KK, j)], zero4);
-  B[KK] = xty(V, B[KK], zero4);
-#pragma unroll
-  for (int i = KK + 1; i < 4; ++i) {
-    if (i < nt) {
-      const d4_t N = -T[tile_id(KK, i)];
-#pragma unroll
-      for (int j = i; j < 4; ++j)
-        if (j < nt && !(i == KK + 1 && j == KK + 1)) T[tile_id(i, j)] = xty(N, T[tile_id(KK, j)], T[tile_id(i, j)]);
-      B[i] = xty(N, B[KK], B[i]);
-    }
-  }
-}
-
 // Four domain points per workgroup, one per wave.  The waves only meet for the diagonal tiles: the row broadcasts of
 // the 16 x 16 factorisation are local to a 16-lane row (tile16.h), so ONE wave factors the four waves' diagonal tiles
 // in its four lane rows for the issue cost of one, and the duty rotates with the block step (wave kk does step kk)
@@ -417,8 +385,55 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
   __syncthreads();
   const int nt = (cnt + 15) >> 4;
 
-  // system matrix, upper block triangle, tile layout; the four rows a lane holds of a tile are evaluated together
+  // system matrix, upper block triangle, tile layout; the four rows a lane holds of a tile are evaluated together.
+  // Rows and columns beyond the neighbour count are padded with the identity; only the last tile row / column of a
+  // point can hold such entries, and none at all when the count is a multiple of 16 (the full neighbourhoods of a
+  // dense data set): the selects are behind a scalar branch.
+  const bool ragged = (cnt & 15) != 0;
   d4_t T[10];
+  // Diagonal tiles in PAIRS (round 4).  A diagonal tile is symmetric, and all the factorisation ever reads of it is one
+  // triangle: the hand-over below gives potrf16_inverse_x4 the lower triangle, which is all its lanes use.  So the
+  // registers of one tile evaluation serve two diagonal tiles: positions (a, b) with a <= b hold tile 2q's entry (a, b),
+  // positions a > b hold tile 2q + 1's entry (a, b) -- both tiles keep a copy, tile 2q is read through its upper
+  // triangle (handed over transposed), tile 2q + 1 through its lower triangle with its diagonal (the sill) put back.
+  // The trailing updates add symmetric matrices, so each copy's live triangle stays that tile's data.  Eight tile
+  // evaluations per point instead of ten at 64 neighbours (2 144 of the 2 560 covariances were ever needed).
+  if constexpr (NT >= 2) {
+#pragma unroll
+    for (int Q = 0; Q < NT / 2; ++Q) {
+      if (2 * Q < nt) {
+        double xr[4][DIM], xc[4][DIM], v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = g + 4 * r;
+          const int blk = 16 * (2 * Q + (a > c ? 1 : 0));
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) {
+            xr[r][d] = nxs[blk + a][d];
+            xc[r][d] = nxs[blk + c][d];
+          }
+        }
+        cov_pairs4_k<DIM, KIND>(vg, xr, xc, v);
+        d4_t t0, t1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t0[r] = v[r];
+          t1[r] = (g + 4 * r == c) ? vg.sill : v[r];
+        }
+        if (ragged && 2 * Q + 2 >= nt) {   // one of the two is the point's last tile (or lies beyond it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = g + 4 * r;
+            const double pad = a == c ? 1.0 : 0.0;
+            if (!(32 * Q + a < cnt && 32 * Q + c < cnt)) t0[r] = pad;
+            if (!(32 * Q + 16 + a < cnt && 32 * Q + 16 + c < cnt)) t1[r] = pad;
+          }
+        }
+        T[tile_id(2 * Q, 2 * Q)] = t0;
+        if (2 * Q + 1 < nt) T[tile_id(2 * Q + 1, 2 * Q + 1)] = t1;
+      }
+    }
+  }
 #pragma unroll
   for (int I = 0; I < NT; ++I) {
     if (I < nt) {
@@ -428,7 +443,7 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
 #pragma unroll
         for (int a = 0; a < DIM; ++a) xr[r][a] = nxs[16 * I + g + 4 * r][a];
 #pragma unroll
-      for (int J = I; J < NT; ++J) {
+      for (int J = (NT >= 2 ? I + 1 : I); J < NT; ++J) {
         if (J < nt) {
           const int col = 16 * J + c;
           double xcol[DIM], v[4];
@@ -436,9 +451,13 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
           for (int a = 0; a < DIM; ++a) xcol[a] = nxs[col][a];
           cov_pair4_k<DIM, KIND>(vg, xr, xcol, v);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + g + 4 * r;
-            T[tile_id(I, J)][r] = (row < cnt && col < cnt) ? v[r] : (row == col ? 1.0 : 0.0);
+          for (int r = 0; r < 4; ++r) T[tile_id(I, J)][r] = v[r];
+          if (ragged && J == nt - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * I + g + 4 * r;
+              if (!(row < cnt && col < cnt)) T[tile_id(I, J)][r] = row == col ? 1.0 : 0.0;
+            }
           }
         }
       }
@@ -462,39 +481,6 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
   }
   bool bad = false;
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-#ifdef GSS_K5_LOOKAHEAD
-  // look-ahead order (experiment, round 3; measured in DESIGN.md section 8): the diagonal tile of step kk + 1 is updated
-  // and handed over first, the wave on duty factors it while the others do the rest of step kk
-  {
-    double* mine0 = S4[0][wave];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mine0[(g + 4 * r) * 17 + c] = (0 < nt) ? T[tile_id(0, 0)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
-    __syncthreads();
-    if (wave == 0) potrf16_inverse_x4(&S4[0][0][0], lane, badflag[0]);
-    __syncthreads();
-  }
-  static_for<0, 4>([&](auto KKc) {
-    constexpr int kk = decltype(KKc)::value;
-    double* mine = S4[kk & 1][wave];
-    d4_t V;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) V[r] = mine[(g + 4 * r) * 17 + c];
-    if (kk < nt) {
-      bad = bad || (badflag[kk & 1][wave] != 0);
-      k5_step_head<kk>(T, V, nt);
-    }
-    if constexpr (kk + 1 < 4) {
-      double* next = S4[(kk + 1) & 1][wave];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        next[(g + 4 * r) * 17 + c] = (kk + 1 < nt) ? T[tile_id(kk + 1, kk + 1)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
-      __syncthreads();
-      if (wave == kk + 1) potrf16_inverse_x4(&S4[(kk + 1) & 1][0][0], lane, badflag[(kk + 1) & 1]);
-    }
-    if (kk < nt) k5_step_rest<kk>(T, B, V, nt);
-    if constexpr (kk + 1 < 4) __syncthreads();
-  });
-#else
   // fully unrolled block steps (a rolled loop around one copy of the diagonal factorisation, with switch-selected
   // per-step code, shrinks the kernel from 84 KB to 53 KB but measured 5 % slower)
   // block steps beyond ceil(maxneighbors / 16) have nothing to do for any point of the launch: skipped by the whole
@@ -505,9 +491,14 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
   for (int kk = 0; kk < NT; ++kk) {
     if (kk >= ntk) break;
     double* mine = S4[kk & 1][wave];
+    // (the factorisation reads the lower triangle: even tiles of a pair carry their data in the upper one and are
+    //  handed over transposed)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      mine[(g + 4 * r) * 17 + c] = (kk < nt) ? T[tile_id(kk, kk)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
+    for (int r = 0; r < 4; ++r) {
+      const double e = (kk < nt) ? T[tile_id(kk, kk)][r] : ((g + 4 * r) == c ? 1.0 : 0.0);
+      if (NT >= 2 && (kk & 1) == 0) mine[c * 17 + (g + 4 * r)] = e;
+      else mine[(g + 4 * r) * 17 + c] = e;
+    }
     __syncthreads();
     if (wave == kk) potrf16_inverse_x4(&S4[kk & 1][0][0], lane, badflag[kk & 1]);
     __syncthreads();
@@ -524,7 +515,6 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
       }
     }
   }
-#endif
   if (bad && live) {
     if (lane == 0) {
       mean_out[p] = NaN;
