@@ -25,6 +25,11 @@ struct EstSpec {
   double wa, wp;    // LWR weight parameters
   int metric;       // GSS_METRIC_* of the search (distances entering the weights use it too)
   double mparam;
+  // value columns that share the search and the weights (idw.jl:128-141 is generic over the value type: a composition's
+  // log-parts, several variables on one sample set): column c of the data at z + c * ldz, of the estimates at
+  // mean + c * ldm; distance / variance / status are per point
+  int nz;
+  int64_t ldz, ldm;
 };
 
 // ranking key of the search for a runtime metric
@@ -182,10 +187,9 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
   const int i = act ? idx[pc * k + gl] : 0;
 #pragma unroll
   for (int a = 0; a < DIM; ++a) c[a] = xdata[(int64_t)i * DIM + a];
-  const double zi = z[i];
   const double d2 = est_key<DIM>(sp.metric, c, qc, ir, aniso != 0);  // the key the search ranked by
   const double d = metric_dist(sp.metric, d2, sp.mparam);
-  double res_mean = NaN, res_aux = NaN;
+  double res_aux = NaN;
   int res_status = GSS_PT_MISSING;
 
   if (sp.method == 0) {
@@ -194,13 +198,16 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
     if (GW < 64) gz = (zb >> (grp * (GW & 63))) & ((1ull << (GW & 63)) - 1ull);
     const bool haszero = gz != 0ull;  // idw.jl:131-134: some distance is zero -> copy the first such sample
     const int jz = haszero ? __builtin_ctzll(gz) + grp * GW : lane;
-    const double zj = __shfl(zi, jz);
     const double w = (act && !haszero) ? idw_weight(d, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : d * d, sp.exponent) : 0.0;
     const double sw = grp_sum<GW>(w);
-    const double swz = grp_sum<GW>(w * zi);
     const double dmin = grp_min<GW>(act ? d : __builtin_huge_val());
+    for (int cz = 0; cz < sp.nz; ++cz) {   // one weight vector, every value column (idw.jl:138)
+      const double zi = z[(int64_t)cz * sp.ldz + i];
+      const double zj = __shfl(zi, jz);
+      const double swz = grp_sum<GW>(w * zi);
+      if (valid && gl == 0) mean_out[(int64_t)cz * sp.ldm + p] = missing ? NaN : (haszero ? zj : swz / sw);
+    }
     if (!missing) {
-      res_mean = haszero ? zj : swz / sw;
       res_aux = haszero ? 0.0 : dmin;  // idw.jl:139
       res_status = GSS_PT_OK;
     }
@@ -212,10 +219,9 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
     u[0] = 1.0;
 #pragma unroll
     for (int a = 0; a < DIM; ++a) u[a + 1] = c[a] - qc[a];
-    double S1[NT], S2[NT], b[NP];
+    double S1[NT], S2[NT];
 #pragma unroll
     for (int r = 0; r < NP; ++r) {
-      b[r] = grp_sum<GW>(w * u[r] * zi);
 #pragma unroll
       for (int q = 0; q <= r; ++q) {
         const double t = w * u[r] * u[q];
@@ -223,16 +229,23 @@ __global__ __launch_bounds__(256) void est_knn_kernel(EstSpec sp, const double* 
         S2[r * (r + 1) / 2 + q] = grp_sum<GW>(w * t);
       }
     }
-    double mu = 0.0, var = 0.0;
-    const bool ok = !missing && (dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
+    bool ok = !missing && (dmax > 0.0);
+    double var = 0.0;
+    for (int cz = 0; cz < sp.nz; ++cz) {   // the normal equations are the same for every value column
+      const double zi = z[(int64_t)cz * sp.ldz + i];
+      double b[NP];
+#pragma unroll
+      for (int r = 0; r < NP; ++r) b[r] = grp_sum<GW>(w * u[r] * zi);
+      double mu = 0.0;
+      ok = ok && lwr_solve<NP>(S1, S2, b, &mu, &var);
+      if (valid && gl == 0) mean_out[(int64_t)cz * sp.ldm + p] = ok ? mu : NaN;
+    }
     if (!missing) {
-      res_mean = ok ? mu : NaN;
       res_aux = ok ? var : NaN;
       res_status = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
     }
   }
   if (valid && gl == 0) {
-    mean_out[p] = res_mean;
     aux_out[p] = res_aux;
     status_out[p] = (uint8_t)res_status;
   }
@@ -308,7 +321,9 @@ __global__ __launch_bounds__(256) void idw_all_fast_kernel(const double* __restr
   status_out[p] = GSS_PT_OK;
 }
 
-template <int DIM>
+// ZC = value columns carried through one sweep (1, or up to 4 of a multi-column call: sp.nz columns are served in
+// chunks of ZC, each chunk sweeping the samples again -- the weights of a sweep are shared by its columns)
+template <int DIM, int ZC>
 __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* __restrict__ xdata,
                                                       const double* __restrict__ z, int n,
                                                       const double* __restrict__ x0, int64_t m, int minneighbors,
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
                                                       double ir2, double* __restrict__ mean_out,
                                                       double* __restrict__ aux_out, uint8_t* __restrict__ status_out) {
   __shared__ double sx[EST_TILE * DIM];
-  __shared__ double sz[EST_TILE];
+  __shared__ double sz[ZC][EST_TILE];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < m;
   const double ir[3] = {ir0, ir1, ir2};
@@ -326,16 +341,25 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
   for (int a = 0; a < DIM; ++a) qc[a] = live ? x0[p * DIM + a] : 0.0;
   constexpr int NP = DIM + 1, NT = NP * (NP + 1) / 2;
 
+  for (int c0 = 0; c0 < sp.nz; c0 += ZC) {
+  const int ncz = (sp.nz - c0) < ZC ? (sp.nz - c0) : ZC;
+  const double* zc = z + (int64_t)c0 * sp.ldz;
+  double* mo = mean_out + (int64_t)c0 * sp.ldm;
   int cnt = 0;
   double dmax2 = 0.0, dmin2 = __builtin_huge_val();
-  double sw = 0.0, swz = 0.0, zzero = 0.0;
+  double sw = 0.0, swz[ZC], zzero[ZC];
+#pragma unroll
+  for (int c = 0; c < ZC; ++c) swz[c] = zzero[c] = 0.0;
   bool haszero = false;
   // sweep 1: IDW sums (complete) / LWR farthest neighbour
   for (int t0 = 0; t0 < n; t0 += EST_TILE) {
     const int tn = (n - t0) < EST_TILE ? (n - t0) : EST_TILE;
     __syncthreads();
     for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
-    for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
+#pragma unroll
+    for (int c = 0; c < ZC; ++c)
+      if (c < ncz)
+        for (int e = threadIdx.x; e < tn; e += 256) sz[c][e] = zc[(int64_t)c * sp.ldz + t0 + e];
     __syncthreads();
     if (sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && (sp.exponent == 1.0 || sp.exponent == 2.0)) {
       // the reference's default (all samples, exponent 1) and its square: branch-free, 1 / d from v_rsq_f64 and
@@ -348,7 +372,8 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
         const bool zero = in && d2 == 0.0;
         cnt += in ? 1 : 0;
         dmin2 = (in && d2 < dmin2) ? d2 : dmin2;
-        zzero = (zero && !haszero) ? sz[j] : zzero;
+#pragma unroll
+        for (int c = 0; c < ZC; ++c) zzero[c] = (zero && !haszero && c < ncz) ? sz[c][j] : zzero[c];
         haszero = haszero || zero;
         double y;
         if (e1) {
@@ -363,7 +388,9 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
         }
         const double w = (in && !zero) ? y : 0.0;
         sw += w;
-        swz = fma(w, sz[j], swz);
+#pragma unroll
+        for (int c = 0; c < ZC; ++c)
+          if (c < ncz) swz[c] = fma(w, sz[c][j], swz[c]);
       }
       continue;
     }
@@ -385,47 +412,53 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
       dmin2 = d2 < dmin2 ? d2 : dmin2;
       if (sp.method == 0) {
         if (d2 == 0.0) {
-          if (!haszero) zzero = sz[j];
+          if (!haszero) {
+#pragma unroll
+            for (int c = 0; c < ZC; ++c)
+              if (c < ncz) zzero[c] = sz[c][j];
+          }
           haszero = true;
         } else {
           const double dd = metric_dist(sp.metric, d2, sp.mparam);
           const double w = idw_weight(dd, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : dd * dd, sp.exponent);
           sw += w;
-          swz += w * sz[j];
+#pragma unroll
+          for (int c = 0; c < ZC; ++c)
+            if (c < ncz) swz[c] += w * sz[c][j];
         }
       }
     }
   }
   const bool enough = cnt >= minneighbors && cnt >= 1;
   if (sp.method == 0) {
-    if (!live) return;
-    if (!enough) {
-      mean_out[p] = NaN;
-      aux_out[p] = NaN;
-      status_out[p] = GSS_PT_MISSING;
-    } else if (haszero) {
-      mean_out[p] = zzero;
-      aux_out[p] = 0.0;
-      status_out[p] = GSS_PT_OK;
-    } else {
-      mean_out[p] = swz / sw;
-      aux_out[p] = metric_dist(sp.metric, dmin2, sp.mparam);
-      status_out[p] = GSS_PT_OK;
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < ZC; ++c)
+        if (c < ncz) mo[(int64_t)c * sp.ldm + p] = !enough ? NaN : (haszero ? zzero[c] : swz[c] / sw);
+      if (c0 == 0) {
+        aux_out[p] = !enough ? NaN : (haszero ? 0.0 : metric_dist(sp.metric, dmin2, sp.mparam));
+        status_out[p] = enough ? GSS_PT_OK : GSS_PT_MISSING;
+      }
     }
-    return;
+    continue;
   }
   // sweep 2 (LWR): moments with delta = d / dmax
   const double dmax = metric_dist(sp.metric, dmax2, sp.mparam);
-  double S1[NT], S2[NT], b[NP];
+  double S1[NT], S2[NT], b[ZC][NP];
 #pragma unroll
   for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
 #pragma unroll
-  for (int e = 0; e < NP; ++e) b[e] = 0.0;
+  for (int c = 0; c < ZC; ++c)
+#pragma unroll
+    for (int e = 0; e < NP; ++e) b[c][e] = 0.0;
   for (int t0 = 0; t0 < n; t0 += EST_TILE) {
     const int tn = (n - t0) < EST_TILE ? (n - t0) : EST_TILE;
     __syncthreads();
     for (int e = threadIdx.x; e < tn * DIM; e += 256) sx[e] = xdata[(int64_t)t0 * DIM + e];
-    for (int e = threadIdx.x; e < tn; e += 256) sz[e] = z[t0 + e];
+#pragma unroll
+    for (int c = 0; c < ZC; ++c)
+      if (c < ncz)
+        for (int e = threadIdx.x; e < tn; e += 256) sz[c][e] = zc[(int64_t)c * sp.ldz + t0 + e];
     __syncthreads();
     const bool euclid = sp.metric == GSS_METRIC_EUCLIDEAN;
     const bool gauss_w = sp.wkind == GSS_WEIGHT_EXP && sp.wp == 2.0;  // exp(-a delta^2): no square root needed
@@ -442,11 +475,12 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
       u[0] = 1.0;
 #pragma unroll
       for (int a = 0; a < DIM; ++a) u[a + 1] = sx[j * DIM + a] - qc[a];
-      const double zj = sz[j];
 #pragma unroll
       for (int r = 0; r < NP; ++r) {
         const double wu = w * u[r];
-        b[r] += wu * zj;
+#pragma unroll
+        for (int c = 0; c < ZC; ++c)
+          if (c < ncz) b[c][r] += wu * sz[c][j];
 #pragma unroll
         for (int q = 0; q <= r; ++q) {
           const double t = wu * u[q];
@@ -456,18 +490,23 @@ __global__ __launch_bounds__(256) void est_all_kernel(EstSpec sp, const double* 
       }
     }
   }
-  if (!live) return;
-  if (!enough) {
-    mean_out[p] = NaN;
-    aux_out[p] = NaN;
-    status_out[p] = GSS_PT_MISSING;
-    return;
+  if (live) {
+    bool ok = enough && (sp.wsup != nullptr || dmax > 0.0);
+    double var = 0.0;
+#pragma unroll
+    for (int c = 0; c < ZC; ++c) {
+      if (c < ncz) {
+        double mu = 0.0;
+        ok = ok && lwr_solve<NP>(S1, S2, b[c], &mu, &var);
+        mo[(int64_t)c * sp.ldm + p] = ok ? mu : NaN;
+      }
+    }
+    if (c0 == 0) {
+      aux_out[p] = ok ? var : NaN;
+      status_out[p] = !enough ? GSS_PT_MISSING : (ok ? GSS_PT_OK : GSS_PT_SINGULAR);
+    }
   }
-  double mu, var;
-  const bool ok = (sp.wsup != nullptr || dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
-  mean_out[p] = ok ? mu : NaN;
-  aux_out[p] = ok ? var : NaN;
-  status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+  }
 }
 
 // The reference's default LWR -- every sample a neighbour (lwr.jl:96), Euclidean distance, no ball, weight
@@ -540,7 +579,7 @@ __global__ __launch_bounds__(256) void lwr_all_fast_kernel(double wa, const doub
 // 64 < k < n: one thread per estimation point walks its neighbour list (m x k, ascending key, written by the
 // passes of the search).  Same sums, in the same (ascending-distance) order, as est_knn_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
+template <int DIM, int ZC>
 __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double* __restrict__ xdata,
                                                        const double* __restrict__ z, const double* __restrict__ x0,
                                                        int64_t m, int k, int minneighbors, const int* __restrict__ idx,
@@ -558,93 +597,111 @@ __global__ __launch_bounds__(256) void est_list_kernel(EstSpec sp, const double*
   for (int a = 0; a < DIM; ++a) qc[a] = x0[p * DIM + a];
   int cnt = count[p];
   const int* nb = idx + p * k;
+  bool bad = false;
   if (ncheck > 0) {   // lists that come from the caller (gss_lwr_predict_weights): never gather through a bad entry
     cnt = cnt > k ? k : cnt;
-    bool bad = false;
     for (int j = 0; j < cnt; ++j) bad |= (unsigned)nb[j] >= (unsigned)ncheck;
-    if (bad) {
-      mean_out[p] = NaN;
-      aux_out[p] = NaN;
-      status_out[p] = GSS_PT_SINGULAR;
-      return;
-    }
   }
-  if (cnt < minneighbors || cnt < 1) {
-    mean_out[p] = NaN;
+  if (bad || cnt < minneighbors || cnt < 1) {
+    for (int c = 0; c < sp.nz; ++c) mean_out[(int64_t)c * sp.ldm + p] = NaN;
     aux_out[p] = NaN;
-    status_out[p] = GSS_PT_MISSING;
+    status_out[p] = bad ? GSS_PT_SINGULAR : GSS_PT_MISSING;
     return;
   }
-  if (sp.method == 0) {
-    double sw = 0.0, swz = 0.0, dmin2 = __builtin_huge_val();
+  for (int c0 = 0; c0 < sp.nz; c0 += ZC) {   // the columns of a chunk share one walk along the list and its weights
+    const int ncz = (sp.nz - c0) < ZC ? (sp.nz - c0) : ZC;
+    const double* zc = z + (int64_t)c0 * sp.ldz;
+    double* mo = mean_out + (int64_t)c0 * sp.ldm;
+    if (sp.method == 0) {
+      double sw = 0.0, swz[ZC], dmin2 = __builtin_huge_val();
+#pragma unroll
+      for (int c = 0; c < ZC; ++c) swz[c] = 0.0;
+      int jz = -1;
+      for (int j = 0; j < cnt; ++j) {
+        const int nj = nb[j];
+        double xj[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
+        const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
+        if (d2 == 0.0) {  // neighbours are sorted: the first zero distance is the first neighbour (idw.jl:131-134)
+          jz = nj;
+          break;
+        }
+        dmin2 = d2 < dmin2 ? d2 : dmin2;
+        const double dd = metric_dist(sp.metric, d2, sp.mparam);
+        const double w = idw_weight(dd, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : dd * dd, sp.exponent);
+        sw += w;
+#pragma unroll
+        for (int c = 0; c < ZC; ++c)
+          if (c < ncz) swz[c] += w * zc[(int64_t)c * sp.ldz + nj];
+      }
+#pragma unroll
+      for (int c = 0; c < ZC; ++c)
+        if (c < ncz) mo[(int64_t)c * sp.ldm + p] = jz >= 0 ? zc[(int64_t)c * sp.ldz + jz] : swz[c] / sw;
+      if (c0 == 0) {
+        aux_out[p] = jz >= 0 ? 0.0 : metric_dist(sp.metric, dmin2, sp.mparam);
+        status_out[p] = GSS_PT_OK;
+      }
+      continue;
+    }
+    // LWR: delta = d / d_max with d_max the distance of the last (farthest) neighbour (lwr.jl:132)
+    double dmax2 = 0.0;
+    {
+      const int nl = nb[cnt - 1];
+      double xl[DIM];
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) xl[a] = xdata[(int64_t)nl * DIM + a];
+      dmax2 = est_key<DIM>(sp.metric, xl, qc, ir, aniso != 0);
+    }
+    const double dmax = metric_dist(sp.metric, dmax2, sp.mparam);
+    double S1[NT], S2[NT], b[ZC][NP];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
+#pragma unroll
+    for (int c = 0; c < ZC; ++c)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) b[c][e] = 0.0;
     for (int j = 0; j < cnt; ++j) {
       const int nj = nb[j];
       double xj[DIM];
 #pragma unroll
       for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
       const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
-      if (d2 == 0.0) {  // neighbours are sorted: the first zero distance is the first neighbour (idw.jl:131-134)
-        mean_out[p] = z[nj];
-        aux_out[p] = 0.0;
-        status_out[p] = GSS_PT_OK;
-        return;
-      }
-      dmin2 = d2 < dmin2 ? d2 : dmin2;
-      const double dd = metric_dist(sp.metric, d2, sp.mparam);
-      const double w = idw_weight(dd, sp.metric == GSS_METRIC_EUCLIDEAN ? d2 : dd * dd, sp.exponent);
-      sw += w;
-      swz += w * z[nj];
-    }
-    mean_out[p] = swz / sw;
-    aux_out[p] = metric_dist(sp.metric, dmin2, sp.mparam);
-    status_out[p] = GSS_PT_OK;
-    return;
-  }
-  // LWR: delta = d / d_max with d_max the distance of the last (farthest) neighbour (lwr.jl:132)
-  double dmax2 = 0.0;
-  {
-    const int nl = nb[cnt - 1];
-    double xl[DIM];
+      const double w = sp.wsup ? sp.wsup[p * k + j]
+                               : lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
+      double u[NP];
+      u[0] = 1.0;
 #pragma unroll
-    for (int a = 0; a < DIM; ++a) xl[a] = xdata[(int64_t)nl * DIM + a];
-    dmax2 = est_key<DIM>(sp.metric, xl, qc, ir, aniso != 0);
-  }
-  const double dmax = metric_dist(sp.metric, dmax2, sp.mparam);
-  double S1[NT], S2[NT], b[NP];
+      for (int a = 0; a < DIM; ++a) u[a + 1] = xj[a] - qc[a];
 #pragma unroll
-  for (int e = 0; e < NT; ++e) S1[e] = S2[e] = 0.0;
+      for (int r = 0; r < NP; ++r) {
+        const double wu = w * u[r];
 #pragma unroll
-  for (int e = 0; e < NP; ++e) b[e] = 0.0;
-  for (int j = 0; j < cnt; ++j) {
-    const int nj = nb[j];
-    double xj[DIM];
+        for (int c = 0; c < ZC; ++c)
+          if (c < ncz) b[c][r] += wu * zc[(int64_t)c * sp.ldz + nj];
 #pragma unroll
-    for (int a = 0; a < DIM; ++a) xj[a] = xdata[(int64_t)nj * DIM + a];
-    const double d2 = est_key<DIM>(sp.metric, xj, qc, ir, aniso != 0);
-    const double w = sp.wsup ? sp.wsup[p * k + j]
-                             : lwr_weight(sp.wkind, sp.wa, sp.wp, metric_dist(sp.metric, d2, sp.mparam) / dmax);
-    double u[NP];
-    u[0] = 1.0;
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) u[a + 1] = xj[a] - qc[a];
-    const double zj = z[nj];
-#pragma unroll
-    for (int r = 0; r < NP; ++r) {
-      const double wu = w * u[r];
-      b[r] += wu * zj;
-#pragma unroll
-      for (int q = 0; q <= r; ++q) {
-        const double t = wu * u[q];
-        S1[r * (r + 1) / 2 + q] += t;
-        S2[r * (r + 1) / 2 + q] += w * t;
+        for (int q = 0; q <= r; ++q) {
+          const double t = wu * u[q];
+          S1[r * (r + 1) / 2 + q] += t;
+          S2[r * (r + 1) / 2 + q] += w * t;
+        }
       }
     }
+    bool ok = sp.wsup != nullptr || dmax > 0.0;
+    double var = 0.0;
+#pragma unroll
+    for (int c = 0; c < ZC; ++c) {
+      if (c < ncz) {
+        double mu = 0.0;
+        ok = ok && lwr_solve<NP>(S1, S2, b[c], &mu, &var);
+        mo[(int64_t)c * sp.ldm + p] = ok ? mu : NaN;
+      }
+    }
+    if (c0 == 0) {
+      aux_out[p] = ok ? var : NaN;
+      status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
+    }
   }
-  double mu, var;
-  const bool ok = (sp.wsup != nullptr || dmax > 0.0) && lwr_solve<NP>(S1, S2, b, &mu, &var);
-  mean_out[p] = ok ? mu : NaN;
-  aux_out[p] = ok ? var : NaN;
-  status_out[p] = ok ? GSS_PT_OK : GSS_PT_SINGULAR;
 }
 
 static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int dim,
@@ -684,11 +741,15 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
       const dim3 grid((unsigned)((mv + 255) / 256));
 #define GSS_EST_LIST_ARGS sp, xdata, z, x0 + off * dim, mv, k, minneighbors, idx_s.as<int>(), cnt_s.as<int>(), aniso, \
                           ir[0], ir[1], ir[2], mean + off, aux + off, status + off, 0
+#define GSS_EST_LIST(D)                                                                                      \
+  if (sp.nz > 1) hipLaunchKernelGGL((est_list_kernel<D, 4>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS);      \
+  else hipLaunchKernelGGL((est_list_kernel<D, 1>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS)
       switch (dim) {
-        case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
-        case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
-        default: hipLaunchKernelGGL((est_list_kernel<3>), grid, dim3(256), 0, s, GSS_EST_LIST_ARGS); break;
+        case 1: GSS_EST_LIST(1); break;
+        case 2: GSS_EST_LIST(2); break;
+        default: GSS_EST_LIST(3); break;
       }
+#undef GSS_EST_LIST
 #undef GSS_EST_LIST_ARGS
       GSS_HIP(hipGetLastError());
     }
@@ -698,8 +759,9 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   if (k > 64) {
     ProfScope ps(pname, s);
     dim3 grid((unsigned)((m + 255) / 256));
-    if (sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && (sp.exponent == 1.0 || sp.exponent == 2.0) &&
-        minneighbors <= n) {
+    // (the two dedicated kernels carry one value column; several columns share the sweeps of the general kernel)
+    if (sp.nz == 1 && sp.method == 0 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball &&
+        (sp.exponent == 1.0 || sp.exponent == 2.0) && minneighbors <= n) {
 #define GSS_IDW_FAST(D)                                                                                               \
   if (sp.exponent == 1.0)                                                                                            \
     hipLaunchKernelGGL((idw_all_fast_kernel<D, true>), grid, dim3(256), 0, s, xdata, z, (int)n, x0, m, mean, aux,     \
@@ -716,8 +778,8 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
       GSS_HIP(hipGetLastError());
       return GSS_OK;
     }
-    if (sp.method == 1 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && sp.wkind == GSS_WEIGHT_EXP && sp.wp == 2.0 &&
-        minneighbors <= n) {
+    if (sp.nz == 1 && sp.method == 1 && sp.metric == GSS_METRIC_EUCLIDEAN && !use_ball && sp.wkind == GSS_WEIGHT_EXP &&
+        sp.wp == 2.0 && minneighbors <= n) {
       switch (dim) {
         case 1: hipLaunchKernelGGL((lwr_all_fast_kernel<1>), grid, dim3(256), 0, s, sp.wa, xdata, z, (int)n, x0, m, mean, aux, status); break;
         case 2: hipLaunchKernelGGL((lwr_all_fast_kernel<2>), grid, dim3(256), 0, s, sp.wa, xdata, z, (int)n, x0, m, mean, aux, status); break;
@@ -728,11 +790,15 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
     }
 #define GSS_EST_ALL_ARGS sp, xdata, z, (int)n, x0, m, minneighbors, r2, use_ball, aniso, ir[0], ir[1], ir[2], mean, \
                          aux, status
+#define GSS_EST_ALL(D)                                                                                     \
+  if (sp.nz > 1) hipLaunchKernelGGL((est_all_kernel<D, 4>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS);      \
+  else hipLaunchKernelGGL((est_all_kernel<D, 1>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS)
     switch (dim) {
-      case 1: hipLaunchKernelGGL((est_all_kernel<1>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
-      case 2: hipLaunchKernelGGL((est_all_kernel<2>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
-      default: hipLaunchKernelGGL((est_all_kernel<3>), grid, dim3(256), 0, s, GSS_EST_ALL_ARGS); break;
+      case 1: GSS_EST_ALL(1); break;
+      case 2: GSS_EST_ALL(2); break;
+      default: GSS_EST_ALL(3); break;
     }
+#undef GSS_EST_ALL
 #undef GSS_EST_ALL_ARGS
     GSS_HIP(hipGetLastError());
     return GSS_OK;
@@ -785,10 +851,14 @@ static int32_t est_local_dev(const EstSpec& sp, const double* xdata, const doubl
   return GSS_OK;
 }
 
-static int32_t est_predict(const EstSpec& sp, const double* xdata, const double* z, int64_t n, int32_t dim,
+static int32_t est_predict(EstSpec sp, const double* xdata, const double* z, int64_t n, int32_t dim, int32_t nz,
                            const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
                            const double* inv_radii, double* mean, double* aux, uint8_t* status, int32_t mem,
                            void* stream) {
+  GSS_REQUIRE(nz >= 1 && nz <= 4096, "%d value columns: 1 .. 4096", nz);
+  sp.nz = nz;
+  sp.ldz = n;
+  sp.ldm = m;
   GSS_REQUIRE(n >= 1 && n < INT_MAX, "estimation requires data");  // idw.jl:95
   GSS_REQUIRE(dim >= 1 && dim <= 3, "dim = %d outside 1..3", dim);
   GSS_REQUIRE(k >= 1 && k <= n, "maxneighbors %d outside 1..%lld (searcher_ui clamps it, ui.jl:18-20)", k,
@@ -800,12 +870,12 @@ static int32_t est_predict(const EstSpec& sp, const double* xdata, const double*
   hipStream_t s = to_stream(stream);
   Staged sxd, sz, sx, smean, saux, sstat;
   GSS_TRY(sxd.in(xdata, sizeof(double) * n * dim, mem, s));
-  GSS_TRY(sz.in(z, sizeof(double) * n, mem, s));
-  HostPipe pipe;   // host arrays of the domain: in and out piece by piece beside the computation (k <= 64)
-  GSS_TRY(pipe.begin(k <= 64 ? mem : GSS_MEM_DEVICE, m, s));
+  GSS_TRY(sz.in(z, sizeof(double) * n * nz, mem, s));
+  HostPipe pipe;   // host arrays of the domain: in and out piece by piece beside the computation (k <= 64, one column)
+  GSS_TRY(pipe.begin(k <= 64 && nz == 1 ? mem : GSS_MEM_DEVICE, m, s));
   if (pipe.on) GSS_TRY(sx.out(const_cast<double*>(xdom), sizeof(double) * m * dim, mem));   // device scratch only
   else GSS_TRY(sx.in(xdom, sizeof(double) * m * dim, mem, s));
-  GSS_TRY(smean.out(mean, sizeof(double) * m, mem));
+  GSS_TRY(smean.out(mean, sizeof(double) * m * nz, mem));
   GSS_TRY(saux.out(aux, sizeof(double) * m, mem));
   DevBuf st_own;
   uint8_t* st = nullptr;
@@ -825,7 +895,7 @@ static int32_t est_predict(const EstSpec& sp, const double* xdata, const double*
   GSS_TRY(est_local_dev(sp, sxd.as<double>(), sz.as<double>(), n, dim, sx.as<double>(), m, k, minneighbors, radius,
                         inv_radii, smean.as<double>(), saux.as<double>(), st, s, &pipe));
   if (pipe.on) return GSS_OK;   // everything is home (est_local_dev ends with pipe.finish and a synchronisation)
-  GSS_TRY(smean.back(mean, sizeof(double) * m, mem, s));
+  GSS_TRY(smean.back(mean, sizeof(double) * m * nz, mem, s));
   GSS_TRY(saux.back(aux, sizeof(double) * m, mem, s));
   if (status) GSS_TRY(sstat.back(status, (size_t)m, mem, s));
   if (!status) GSS_HIP(hipStreamSynchronize(s));  // st_own is released on return
@@ -838,10 +908,10 @@ using namespace gss;
 
 extern "C" {
 
-int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
-                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
-                        double metric_param, double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
-                        void* stream) {
+int32_t gss_idw_predict_cols(const double* xdata, const double* z, int64_t n, int32_t dim, int32_t nz,
+                             const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
+                             const double* inv_radii, int32_t metric, double metric_param, double exponent, double* mean,
+                             double* dist, uint8_t* status, int32_t mem, void* stream) {
   GSS_ENTRY();
   GSS_REQUIRE(exponent > 0.0, "exponent must be positive");  // idw.jl:96
   EstSpec sp;
@@ -850,8 +920,16 @@ int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t
   sp.exponent = exponent;
   sp.metric = metric;
   sp.mparam = metric_param;
-  return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, dist, status, mem,
+  return est_predict(sp, xdata, z, n, dim, nz, xdom, m, k, minneighbors, radius, inv_radii, mean, dist, status, mem,
                      stream);
+}
+
+int32_t gss_idw_predict(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
+                        int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
+                        double metric_param, double exponent, double* mean, double* dist, uint8_t* status, int32_t mem,
+                        void* stream) {
+  return gss_idw_predict_cols(xdata, z, n, dim, 1, xdom, m, k, minneighbors, radius, inv_radii, metric, metric_param,
+                              exponent, mean, dist, status, mem, stream);
 }
 
 int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
@@ -885,13 +963,16 @@ int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n,
   std::memset(&sp, 0, sizeof(sp));
   sp.method = 1;
   sp.wsup = sw.as<double>();
+  sp.nz = 1;
+  sp.ldz = n;
+  sp.ldm = m;
   const dim3 grid((unsigned)((m + 255) / 256));
 #define GSS_LWRW_ARGS sp, sxd.as<double>(), sz.as<double>(), sx.as<double>(), m, (int)k, (int)minneighbors, si.as<int>(), \
                       sc.as<int>(), 0, 1.0, 1.0, 1.0, smean.as<double>(), svar.as<double>(), st, (int)n
   switch (dim) {
-    case 1: hipLaunchKernelGGL((est_list_kernel<1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
-    case 2: hipLaunchKernelGGL((est_list_kernel<2>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
-    default: hipLaunchKernelGGL((est_list_kernel<3>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+    case 1: hipLaunchKernelGGL((est_list_kernel<1, 1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+    case 2: hipLaunchKernelGGL((est_list_kernel<2, 1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
+    default: hipLaunchKernelGGL((est_list_kernel<3, 1>), grid, dim3(256), 0, s, GSS_LWRW_ARGS); break;
   }
 #undef GSS_LWRW_ARGS
   GSS_HIP(hipGetLastError());
@@ -906,6 +987,15 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
                         int32_t k, int32_t minneighbors, double radius, const double* inv_radii, int32_t metric,
                         double metric_param, int32_t weight_kind, double weight_a, double weight_p, double* mean,
                         double* var, uint8_t* status, int32_t mem, void* stream) {
+  return gss_lwr_predict_cols(xdata, z, n, dim, 1, xdom, m, k, minneighbors, radius, inv_radii, metric, metric_param,
+                              weight_kind, weight_a, weight_p, mean, var, status, mem, stream);
+}
+
+int32_t gss_lwr_predict_cols(const double* xdata, const double* z, int64_t n, int32_t dim, int32_t nz,
+                             const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
+                             const double* inv_radii, int32_t metric, double metric_param, int32_t weight_kind,
+                             double weight_a, double weight_p, double* mean, double* var, uint8_t* status, int32_t mem,
+                             void* stream) {
   GSS_ENTRY();
   GSS_REQUIRE(weight_kind == GSS_WEIGHT_EXP || weight_kind == GSS_WEIGHT_TRICUBE, "unknown weight function %d",
               weight_kind);
@@ -918,7 +1008,7 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
   sp.wp = weight_p;
   sp.metric = metric;
   sp.mparam = metric_param;
-  return est_predict(sp, xdata, z, n, dim, xdom, m, k, minneighbors, radius, inv_radii, mean, var, status, mem,
+  return est_predict(sp, xdata, z, n, dim, nz, xdom, m, k, minneighbors, radius, inv_radii, mean, var, status, mem,
                      stream);
 }
 

@@ -4,8 +4,8 @@ The package holds only what the hot path needs: the ctypes binding of the C-ABI 
 array-level engine (`engine`), the minimal geospatial containers the solvers read (`geo`), and the
 solver front-ends (`solvers`) that mirror the reference's `solve(problem, solver)` API.
 """
-from .geo import (CartesianGrid, DomainView, Ensemble, GeoTable, PointSet, asarray, domain, georef, parent,
-                  parentindices, view)
+from .geo import (CartesianGrid, Composition, DomainView, Ensemble, GeoTable, PointSet, aitchison, asarray, domain,
+                  georef, parent, parentindices, view)
 from .problems import EstimationProblem, SimulationProblem
 from .solvers import (FFTGS, LUGS, SGS, ExpWeight, IDWSolver, KrigingSolver, LWRSolver, TricubeWeight, kriging_ui,
                       searcher_ui, simulate_with_generic_loop, solve)

@@ -88,6 +88,9 @@ SIGNATURES = {
     "gss_idw_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _f64, _p, _p, _p, _i32, _p],
     "gss_lwr_predict": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _i32, _f64, _f64, _p, _p, _p, _i32,
                         _p],
+    "gss_idw_predict_cols": [_p, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _f64, _p, _p, _p, _i32, _p],
+    "gss_lwr_predict_cols": [_p, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _f64, _p, _i32, _f64, _i32, _f64, _f64, _p, _p, _p,
+                             _i32, _p],
     "gss_lwr_predict_weights": [_p, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "gss_sgs_create": [C.POINTER(_p), _VG, _f64, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _f64, _p, _i32, _p],
     "gss_sgs_create_paths": [C.POINTER(_p), _VG, _f64, _p, _i64, _i32, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _f64, _p,

@@ -466,7 +466,9 @@ class HipEngine:
 
     @staticmethod
     def _estimate(fn_name, extra, xdata, z, xdom, k, minneighbors, radius, radii, distance=None):
-        """Host arrays in -> host arrays out; if `xdom` is a CUDA tensor everything stays in HBM."""
+        """Host arrays in -> host arrays out; if `xdom` is a CUDA tensor everything stays in HBM.  `z` of shape (n,) is
+        one value column; (nz, n) is nz columns that share the search and the weights (gss_*_predict_cols: the mean
+        comes back as (nz, m), distance / variance / status per point)."""
         l = _lib.lib()
         dev = is_torch(xdom) and xdom.is_cuda
         if dev:
@@ -476,7 +478,8 @@ class HipEngine:
             zz = _prep_in(z if is_torch(z) else torch.as_tensor(np.asarray(z, dtype=np.float64), device="cuda"))
             c = _prep_in(xdom.reshape(-1, x.shape[1]))
             m = c.shape[0]
-            mean = torch.empty(m, dtype=torch.float64, device="cuda")
+            mshape = (m,) if zz.ndim == 1 else (zz.shape[0], m)
+            mean = torch.empty(mshape, dtype=torch.float64, device="cuda")
             aux = torch.empty(m, dtype=torch.float64, device="cuda")
             st = torch.empty(m, dtype=torch.uint8, device="cuda")
         else:
@@ -486,13 +489,21 @@ class HipEngine:
             zz = np.ascontiguousarray(z, dtype=np.float64)
             c = np.ascontiguousarray(xdom, dtype=np.float64).reshape(-1, x.shape[1])
             m = c.shape[0]
-            mean, aux, st = np.empty(m), np.empty(m), np.empty(m, dtype=np.uint8)
+            mean = np.empty((m,) if zz.ndim == 1 else (zz.shape[0], m))
+            aux, st = np.empty(m), np.empty(m, dtype=np.uint8)
+        if zz.ndim not in (1, 2) or zz.shape[-1] != x.shape[0]:
+            raise ValueError("z must have shape (n,) or (nz, n)")
         ir = None if radii is None else np.ascontiguousarray(1.0 / np.asarray(radii, dtype=np.float64))
         r = -1.0 if radius is None and radii is None else (1.0 if radii is not None else float(radius))
         met, mpar = _lib.metric_spec(distance)
-        check(getattr(l, fn_name)(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k), int(minneighbors), r,
-                                  ptr(ir), met, mpar, *extra, ptr(mean), ptr(aux), ptr(st), MEM_DEVICE if dev else MEM_HOST,
-                                  current_stream()))
+        if zz.ndim == 1:
+            check(getattr(l, fn_name)(ptr(x), ptr(zz), x.shape[0], x.shape[1], ptr(c), m, int(k), int(minneighbors), r,
+                                      ptr(ir), met, mpar, *extra, ptr(mean), ptr(aux), ptr(st),
+                                      MEM_DEVICE if dev else MEM_HOST, current_stream()))
+        else:
+            check(getattr(l, fn_name + "_cols")(ptr(x), ptr(zz), x.shape[0], x.shape[1], int(zz.shape[0]), ptr(c), m, int(k),
+                                                int(minneighbors), r, ptr(ir), met, mpar, *extra, ptr(mean), ptr(aux),
+                                                ptr(st), MEM_DEVICE if dev else MEM_HOST, current_stream()))
         return mean, aux, st
 
     @staticmethod

@@ -119,6 +119,48 @@ def parentindices(domain: Domain) -> Optional[np.ndarray]:
     return domain.inds if isinstance(domain, DomainView) else None
 
 
+class Composition:
+    """CoDa.jl's `Composition(parts...)` as far as the estimation loops use it (idw.jl:128-141 is generic over the value
+    type; test/estimation/idw.jl:47-65 runs it on compositions): `w * c` is powering (parts .^ w), `c1 + c2` is
+    perturbation (parts .* parts) and nothing is closed on the way -- a composition is an equivalence class under
+    positive scaling, which `aitchison` respects ([RECALL] of CoDa's definitions; the package is not in the tree).
+    Both operations are linear in the log-parts, which is how the device estimates them (one value column per part,
+    one search and one weight vector: gss_idw_predict_cols)."""
+
+    __slots__ = ("parts",)
+
+    def __init__(self, *parts):
+        if len(parts) == 1 and np.ndim(parts[0]) == 1:
+            parts = tuple(parts[0])
+        self.parts = np.asarray(parts, dtype=np.float64)
+
+    def __rmul__(self, w):
+        return Composition(self.parts ** float(w))
+
+    __mul__ = __rmul__
+
+    def __add__(self, other):
+        return Composition(self.parts * other.parts)
+
+    def __radd__(self, other):                  # sum(...) starts from 0
+        return self if isinstance(other, (int, float)) and other == 0 else NotImplemented
+
+    def closure(self):
+        return Composition(self.parts / self.parts.sum())
+
+    def clr(self):
+        lg = np.log(self.parts)
+        return lg - lg.mean()
+
+    def __repr__(self):
+        return "Composition(" + ", ".join("%.6g" % v for v in self.parts) + ")"
+
+
+def aitchison(c1: Composition, c2: Composition) -> float:
+    """Aitchison distance: the Euclidean norm of the difference of the centred log-ratio coordinates."""
+    return float(np.linalg.norm(c1.clr() - c2.clr()))
+
+
 class GeoTable:
     """Table + domain (`georef`).  Columns are accessed as attributes or items."""
 
@@ -145,7 +187,11 @@ def georef(table, domain) -> GeoTable:
         domain = PointSet(np.asarray(domain, dtype=np.float64))
     cols = {}
     for k, v in dict(table).items():
-        a = np.asarray([np.nan if x is None else x for x in v] if isinstance(v, (list, tuple)) else v)
+        if len(v) and any(isinstance(x, Composition) for x in v):
+            a = np.empty(len(v), dtype=object)          # a column of compositions (None = missing)
+            a[:] = list(v)
+        else:
+            a = np.asarray([np.nan if x is None else x for x in v] if isinstance(v, (list, tuple)) else v)
         cols[k] = a
         if a.shape[0] != domain.nelements():
             raise ValueError(f"column {k} has {a.shape[0]} rows for {domain.nelements()} elements")

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import parallel
 from .engine import EDK, OK, SK, UK, default_engine
-from .geo import Ensemble, GeoTable, PointSet, georef, parent, parentindices
+from .geo import Composition, Ensemble, GeoTable, PointSet, georef, parent, parentindices
 from .problems import EstimationProblem, SimulationProblem
 from .variograms import GaussianVariogram, MetricBall
 
@@ -425,8 +425,19 @@ class _NeighborEstimator(_Solver):
         cols, aux = {}, {}
         for var in problem.variables:
             p = self.params(var)
-            zall = np.asarray(problem.data[var], dtype=np.float64)
-            inds = np.flatnonzero(~np.isnan(zall))                       # idw.jl:77, lwr.jl:80
+            col = problem.data[var]
+            # a column of compositions (test/estimation/idw.jl:47-65): the loop is generic over the value type
+            # (idw.jl:138 `sum(ws[i] * vs[i])` = perturbation of powers), and both operations are linear in the
+            # log-parts -- one device value column per part, ONE search and ONE weight vector for all of them
+            comp = getattr(col, "dtype", None) == object and any(isinstance(v, Composition) for v in col)
+            if comp:
+                keep = np.array([isinstance(v, Composition) and bool(np.all(np.isfinite(v.parts)) and np.all(v.parts > 0))
+                                 for v in col])
+                inds = np.flatnonzero(keep)
+                zall = None
+            else:
+                zall = np.asarray(col, dtype=np.float64)
+                inds = np.flatnonzero(~np.isnan(zall))                   # idw.jl:77, lwr.jl:80
             n = inds.size
             assert n > 0, "estimation requires data"                      # idw.jl:95
             _distance(p)
@@ -438,17 +449,29 @@ class _NeighborEstimator(_Solver):
             vdom = PointSet(coords[inds])
             _, k = searcher_ui(vdom, p["maxneighbors"], p["distance"], p["neighborhood"])   # idw.jl:100
             radius, radii = _ball(p["neighborhood"])
-            if hi > lo:
-                mu, ax, st = self._estimate(p, vdom.coords, zall[inds], xdom, k, nmin, radius, radii)
+            if comp:
+                zin = np.log(np.stack([col[i].parts for i in inds], axis=1))     # (parts, n): log-parts as value columns
             else:
-                mu, ax, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
+                zin = zall[inds]
+            if hi > lo:
+                mu, ax, st = self._estimate(p, vdom.coords, zin, xdom, k, nmin, radius, radii)
+            else:
+                mu = np.empty((zin.shape[0], 0)) if comp else np.empty(0)
+                ax, st = np.empty(0), np.empty(0, dtype=np.uint8)
             mu = np.where(st == 0, mu, np.nan)                            # `missing`
             ax = np.where(st == 0, ax, np.nan)
             if gather and ws > 1:
-                mu = parallel.all_gather_concat(mu, m)
+                mu = (np.stack([parallel.all_gather_concat(r, m) for r in mu]) if comp
+                      else parallel.all_gather_concat(mu, m))
                 ax = parallel.all_gather_concat(ax, m)
             if order is not None and (gather or ws == 1):              # results in traversal order, idw.jl:112-113
-                mu, ax = mu[order], ax[order]
+                mu, ax = mu[..., order], ax[order]
+            if comp:                                                    # back from the log-parts; `missing` stays None
+                parts = np.exp(mu)
+                out = np.empty(parts.shape[1], dtype=object)
+                for j in range(parts.shape[1]):
+                    out[j] = Composition(parts[:, j]) if np.all(np.isfinite(parts[:, j])) else None
+                mu = out
             cols[var] = mu
             aux[f"{var}_{self.AUX}"] = ax
         cols.update(aux)                                                  # (; mus..., sigmas...) idw.jl:152

@@ -35,6 +35,7 @@ using Random
 using Unitful
 using LinearAlgebra: cholesky, lu      # values of LUGS' `factorization` parameter (lu.jl:70)
 using Distances: evaluate              # the search metric applied to a pair of points (closure weights of LWR)
+using CoDa: Composition, components    # compositional value columns (test/estimation/idw.jl:47-65); [RECALL] accessor names
 using Distributed: myid, remotecall_fetch
 
 import GeoStatsBase: solve, preprocess, solvesingle
@@ -352,7 +353,7 @@ end
   @param path = LinearPath()
 end
 
-function neighbor_estimate(problem, solver, auxname, auxunit, call)
+function neighbor_estimate(problem, solver, auxname, auxunit, call, callcols)
   pdata = data(problem)
   pdomain = domain(problem)
   dtable = values(pdata)
@@ -365,7 +366,8 @@ function neighbor_estimate(problem, solver, auxname, auxunit, call)
     inds = findall(!ismissing, zcol)                                     # idw.jl:77, lwr.jl:80
     n = length(inds)
     @assert n > 0 "estimation requires data"
-    z, u = stripunits(zcol)                                              # uadjust, idw.jl:109, lwr.jl:112
+    iscomp = nonmissingtype(eltype(zcol)) <: Composition
+    z, u = iscomp ? (Float64[], NoUnits) : stripunits(zcol)              # uadjust, idw.jl:109, lwr.jl:112
     X = coordmatrix(view(domain(pdata), inds))
     nmax = isnothing(p.maxneighbors) ? n : min(p.maxneighbors, n)        # idw.jl:93
     @assert p.minneighbors ≤ nmax "invalid min/max number of neighbors"
@@ -379,7 +381,22 @@ function neighbor_estimate(problem, solver, auxname, auxunit, call)
       rs = ustrip.(radii(p.neighborhood))
       length(rs) == 1 ? (radius = Float64(rs[1])) : (radius = 1.0; ir = Float64[1 / r for r in rs])
     end
-    μ = Vector{Float64}(undef, m); aux = similar(μ); status = Vector{UInt8}(undef, m)
+    aux = Vector{Float64}(undef, m); status = Vector{UInt8}(undef, m)
+    if iscomp
+      # compositional data (test/estimation/idw.jl:47-65): the loop is generic over the value type -- idw.jl:138
+      # `sum(ws[i] * vs[i])` is a perturbation of powers -- and both operations are linear in the log-parts, which travel
+      # as value columns of ONE call: one search and one weight vector per estimation point (gss_*_predict_cols)
+      L = log.(permutedims(reduce(hcat, [collect(Float64, components(zcol[i])) for i in inds])))   # n x D, a part per column
+      D = size(L, 2)
+      M = Matrix{Float64}(undef, m, D)
+      GC.@preserve X L X0 ir M aux status check(callcols(p, X, L, n, d, Int32(D), X0, m, Int32(k), radius, ir, M, aux, status))
+      miss = status .!= 0
+      tinds = collect(traverse(pdomain, p.path))
+      push!(μs, var => [miss[i] ? missing : Composition(exp.(view(M, i, :))...) for i in tinds])
+      push!(σs, Symbol(var, auxname) => [miss[i] ? missing : aux[i] for i in tinds])
+      continue
+    end
+    μ = Vector{Float64}(undef, m)
     GC.@preserve X z X0 ir μ aux status check(call(p, X, z, n, d, X0, m, Int32(k), radius, ir, μ, aux, status))
     miss = status .!= 0                                                  # idw.jl:123-124
     inds = collect(traverse(pdomain, p.path))                            # results in traversal order, idw.jl:112-113
@@ -397,6 +414,14 @@ solve(problem::EstimationProblem, solver::IDWSolverHIP) =
           (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
            Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
           X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, Float64(p.exponent), μ, aux,
+          status, GSS_MEM_HOST, C_NULL)
+  end, (p, X, L, n, d, D, X0, m, k, radius, ir, M, aux, status) -> begin
+    @assert p.exponent > 0 "exponent must be positive"
+    met, mpar = searchmetric(p)
+    ccall((:gss_idw_predict_cols, libgss), Int32,
+          (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
+           Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, L, n, Int32(d), D, X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, Float64(p.exponent), M, aux,
           status, GSS_MEM_HOST, C_NULL)
   end)
 
@@ -433,6 +458,16 @@ solve(problem::EstimationProblem, solver::LWRSolverHIP) =
           (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
            Int32, Float64, Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
           X, z, n, Int32(d), X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, wk, wa, wp, μ, aux, status,
+          GSS_MEM_HOST, C_NULL)
+  end, (p, X, L, n, d, D, X0, m, k, radius, ir, M, aux, status) -> begin
+    p.weightfun isa Union{ExpWeight,TricubeWeight} ||
+      throw(ArgumentError("compositional data with a `weightfun` closure: use ExpWeight / TricubeWeight"))
+    wk, wa, wp = weightspec(p.weightfun)
+    met, mpar = searchmetric(p)
+    ccall((:gss_lwr_predict_cols, libgss), Int32,
+          (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Float64}, Int64, Int32, Int32, Float64, Ptr{Float64},
+           Int32, Float64, Int32, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Int32, Ptr{Cvoid}),
+          X, L, n, Int32(d), D, X0, m, k, Int32(p.minneighbors), radius, ir, met, mpar, wk, wa, wp, M, aux, status,
           GSS_MEM_HOST, C_NULL)
   end)
 

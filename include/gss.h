@@ -282,10 +282,25 @@ int32_t gss_lwr_predict(const double* xdata, const double* z, int64_t n, int32_t
                         int64_t m, int32_t k, int32_t minneighbors, double radius, const double* inv_radii,
                         int32_t metric, double metric_param, int32_t weight_kind, double weight_a,
                         double weight_p, double* mean, double* var, uint8_t* status, int32_t mem, void* stream);
+/* Several value columns on ONE search and ONE weight vector per point.  The reference's estimation loop is generic over
+ * the value type (idw.jl:128-141: `mu = sum(ws[i] * vs[i])`, exercised with CoDa compositions in
+ * test/estimation/idw.jl:47-65, whose arithmetic is linear in the log-parts) and several variables measured on the same
+ * samples share everything but the values.  z: nz columns of n (column c at z + c * n); mean: nz columns of m (column c
+ * at mean + c * m); dist / var / status: one per point, as in the single-column calls (which are these with nz = 1). */
+int32_t gss_idw_predict_cols(const double* xdata, const double* z, int64_t n, int32_t dim, int32_t nz,
+                             const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
+                             const double* inv_radii, int32_t metric, double metric_param, double exponent,
+                             double* mean, double* dist, uint8_t* status, int32_t mem, void* stream);
+int32_t gss_lwr_predict_cols(const double* xdata, const double* z, int64_t n, int32_t dim, int32_t nz,
+                             const double* xdom, int64_t m, int32_t k, int32_t minneighbors, double radius,
+                             const double* inv_radii, int32_t metric, double metric_param, int32_t weight_kind,
+                             double weight_a, double weight_p, double* mean, double* var, uint8_t* status,
+                             int32_t mem, void* stream);
 /* LWR with the neighbours' weights supplied by the caller, for weight functions that cannot cross the ABI -- an arbitrary
  * `weightfun` closure (lwr.jl:58,136): the host searches (gss_knn_search), evaluates delta = d / max d and w = f(delta)
  * itself and hands over idx (m x k, 0-based, as the search wrote it), count (m) and weights (m x k); the rest of
- * lwr.jl:137-145 (normal equations about the estimation point, norm(r)) runs here. */
+ * lwr.jl:137-145 (normal equations about the estimation point, norm(r)) runs here.  The lists are the caller's: a count
+ * above k is clamped and a point whose list holds an index outside 0 .. n-1 is reported GSS_PT_SINGULAR, never gathered. */
 int32_t gss_lwr_predict_weights(const double* xdata, const double* z, int64_t n, int32_t dim, const double* xdom, int64_t m,
                                 int32_t k, int32_t minneighbors, const int32_t* idx, const int32_t* count,
                                 const double* weights, double* mean, double* var, uint8_t* status, int32_t mem,

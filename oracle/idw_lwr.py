@@ -70,6 +70,43 @@ def idw(x: np.ndarray, z: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[i
     return mu, sd, st
 
 
+def idw_compositional(x: np.ndarray, parts: np.ndarray, xdom: np.ndarray, maxneighbors: Optional[int] = None,
+                      minneighbors: int = 1, exponent: float = 1.0, radius: Optional[float] = None,
+                      radii: Optional[Sequence[float]] = None, distance=None):
+    """idw.jl:111-142 on a column of compositions (`test/estimation/idw.jl:47-65`), written with the compositions' own
+    operations instead of logarithms: `ws[i] * vs[i]` is powering (parts .^ w), `sum` perturbation (parts .* parts), no
+    closure ([RECALL] CoDa.jl; the package is not in the tree).  `parts`: (n, D) positive.  Returns (mu (m, D), dist,
+    status)."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    parts = np.asarray(parts, dtype=np.float64)
+    xdom = np.atleast_2d(np.asarray(xdom, dtype=np.float64))
+    n = x.shape[0]
+    nmax = n if maxneighbors is None else min(int(maxneighbors), n)
+    m = xdom.shape[0]
+    mu = np.full((m, parts.shape[1]), np.nan)
+    sd = np.full(m, np.nan)
+    st = np.zeros(m, dtype=np.uint8)
+    for p in range(m):
+        is_, ds = _neighbours(x, xdom[p], nmax, radius, radii, distance)
+        if is_.size < minneighbors:                                       # idw.jl:123-124
+            st[p] = 1
+            continue
+        with np.errstate(divide="ignore"):
+            ws = 1.0 / ds ** exponent                                     # idw.jl:128
+        sw = ws.sum()
+        if np.isinf(sw):                                                  # idw.jl:131-134
+            mu[p] = parts[is_[int(np.flatnonzero(ds == 0.0)[0])]]
+            sd[p] = 0.0
+        else:
+            ws = ws / sw                                                  # idw.jl:136
+            acc = np.ones(parts.shape[1])
+            for w, v in zip(ws, parts[is_]):                              # idw.jl:138: perturbation of the powers
+                acc = acc * v ** w
+            mu[p] = acc
+            sd[p] = float(ds.min())
+    return mu, sd, st
+
+
 def default_weightfun(h):
     """lwr.jl:58: h -> exp(-3 h^2)."""
     return np.exp(-3.0 * h * h)

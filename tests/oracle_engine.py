@@ -140,6 +140,10 @@ class OracleEngine:
     @staticmethod
     def idw(xdata, z, xdom, k, minneighbors=1, exponent=1.0, radius=None, radii=None, distance=None):
         from oracle import idw_lwr
+        z = np.asarray(z, dtype=np.float64)
+        if z.ndim == 2:                                   # value columns (nz, n) that share the search: column by column
+            res = [idw_lwr.idw(xdata, zc, xdom, k, minneighbors, exponent, radius, radii, distance) for zc in z]
+            return np.stack([r[0] for r in res]), res[0][1], res[0][2]
         return idw_lwr.idw(xdata, z, xdom, k, minneighbors, exponent, radius, radii, distance)
 
     @staticmethod
@@ -147,4 +151,8 @@ class OracleEngine:
         from oracle import idw_lwr
         kind, a, p = weight
         wf = idw_lwr.tricube if kind == 1 else idw_lwr.exp_weight(a, p)
+        z = np.asarray(z, dtype=np.float64)
+        if z.ndim == 2:
+            res = [idw_lwr.lwr(xdata, zc, xdom, k, minneighbors, wf, radius, radii, distance) for zc in z]
+            return np.stack([r[0] for r in res]), res[0][1], res[0][2]
         return idw_lwr.lwr(xdata, z, xdom, k, minneighbors, wf, radius, radii, distance)

@@ -260,3 +260,75 @@ def test_lwr_weight_function_that_only_takes_scalars():
         assert ok.sum() > 100
         assert np.max(np.abs(a["z"][ok] - b["z"][ok])) < 1e-12
         assert np.max(np.abs(a["z_variance"][ok] - b["z_variance"][ok])) < 1e-12
+
+
+def test_compositional_idw_on_the_device_replays_the_reference_assertions():
+    """test/estimation/idw.jl:47-65 through `gss.solve` on the device: the three `aitchison(...) < 1e-2` assertions, and
+    the whole field against the oracle's restatement in the compositions' own arithmetic (1e-12 relative).  The log-parts
+    travel as value columns of ONE gss_idw_predict_cols call: one search, one weight vector per cell."""
+    import gss
+    data = [gss.Composition(0.1, 0.2), gss.Composition(0.3, 0.4), gss.Composition(0.5, 0.6)]
+    coord = [(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)]
+    grid = gss.CartesianGrid(100, 100)
+    problem = gss.EstimationProblem(gss.georef({"z": data}, coord), grid, "z")
+    sol = gss.solve(problem, gss.IDWSolver())
+    S = sol["z"]
+    lin = lambda i, j: (i - 1) + 100 * (j - 1)                      # noqa: E731  LinearIndices(size(grid))[i, j]
+    assert gss.aitchison(S[lin(25, 25)], data[0]) < 1e-2
+    assert gss.aitchison(S[lin(50, 75)], data[1]) < 1e-2
+    assert gss.aitchison(S[lin(75, 50)], data[2]) < 1e-2
+    mu, sd, st = E.idw_compositional(np.array(coord), np.array([c.parts for c in data]), grid.centroids())
+    got = np.array([c.parts for c in S])
+    assert np.max(np.abs(got / mu - 1.0)) < 1e-12 and np.max(np.abs(sol["z_distance"] - sd)) < 1e-12
+    # a larger case with a neighbourhood, missing data and points without neighbours
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 50, (300, 2))
+    parts = rng.uniform(0.1, 1.0, (300, 4))
+    cs = [gss.Composition(p) for p in parts]
+    cs[7] = None
+    dom = gss.PointSet(rng.uniform(0, 50, (500, 2)))
+    prob = gss.EstimationProblem(gss.georef({"c": cs}, x), dom, "c")
+    sol = gss.solve(prob, gss.IDWSolver(("c", dict(maxneighbors=9, neighborhood=gss.MetricBall(3.0), exponent=2))))
+    keep = np.arange(300) != 7
+    mu, sd, st = E.idw_compositional(x[keep], parts[keep], dom.centroids(), maxneighbors=9, exponent=2.0, radius=3.0)
+    assert st.any() and not st.all()
+    for j, c in enumerate(sol["c"]):
+        assert (c is None) == bool(st[j])
+        if c is not None:
+            assert np.max(np.abs(c.parts / mu[j] - 1.0)) < 1e-12
+
+
+@pytest.mark.parametrize("k,n", [(7, 400), (40, 400), (90, 400), (400, 400), (64, 64)])
+def test_value_columns_share_one_search_and_one_weight_vector(k, n):
+    """gss_idw_predict_cols / gss_lwr_predict_cols: nz value columns on one search.  Every kernel family -- sixteen and
+    sixty-four lanes per point, neighbour lists beyond 64, every sample a neighbour -- must give, column by column, what
+    the single-column call gives (bit for bit where the same kernel serves both, 1e-9 where the single column runs on
+    an instantiation of its own: the compiler contracts the sums differently), with a ball, duplicates of estimation points among the samples (zero distances)
+    and device-resident arrays."""
+    import torch
+    from gss.engine import HipEngine
+    rng = np.random.default_rng(k + n)
+    x = rng.uniform(0, 40, (n, 3))
+    Z = rng.normal(size=(5, n))
+    c = np.concatenate([rng.uniform(0, 40, (700, 3)), x[:20]])
+    for ball in (None, 9.0):
+        same_kernel = k <= 64                       # the wave-per-point kernel serves one column and many alike; the
+                                                    # list / all-samples kernels are instantiated per column count
+        for fn, kw in ((HipEngine.idw, dict(exponent=2.0)), (HipEngine.idw, dict(exponent=1.5)),
+                       (HipEngine.lwr, dict(weight=(0, 3.0, 2.0))), (HipEngine.lwr, dict(weight=(1, 0.0, 0.0)))):
+            nmin = 2 if fn is HipEngine.idw else min(10, k)     # (a plane through four or five points is barely determined)
+            mu, ax, st = fn(x, Z, c, k, nmin, radius=ball, **kw)
+            assert mu.shape == (5, 720) and ax.shape == (720,)
+            for col in range(5):
+                m1, a1, s1 = fn(x, Z[col], c, k, nmin, radius=ball, **kw)
+                assert np.array_equal(st, s1)
+                ok = st == 0
+                if same_kernel:
+                    assert np.array_equal(mu[col][ok], m1[ok]) and np.array_equal(ax[ok], a1[ok])
+                else:
+                    # (rounding differences, amplified where a ball leaves an LWR fit nearly singular)
+                    assert np.max(np.abs(mu[col][ok] - m1[ok])) < 1e-9
+                    assert np.max(np.abs(ax[ok] - a1[ok]) / (1.0 + np.abs(a1[ok]))) < 1e-8
+            md, ad, sd = fn(torch.as_tensor(x, device="cuda"), torch.as_tensor(Z, device="cuda"),
+                            torch.as_tensor(c, device="cuda"), k, nmin, radius=ball, **kw)
+            assert np.array_equal(md.cpu().numpy(), mu, equal_nan=True) and np.array_equal(sd.cpu().numpy(), st)

@@ -159,3 +159,64 @@ def test_search_distances_of_the_reference_tests():
     ref = E.lwr(np.array([(50.0, -30.0), (100.0, 30.0), (200.0, 10.0)]), np.array([4.0, -1.0, 3.0]), dom.centroids(), 3,
                 radius=500.0)
     assert np.allclose(sol2["z"], ref[0], equal_nan=True)
+
+
+def test_compositional_idw_replays_the_reference_assertions_and_known_answers():
+    """test/estimation/idw.jl:47-65 -- the one numerical assertion the reference holds on IDW: three `Composition` data,
+    `IDWSolver()` on a 100 x 100 grid, `aitchison(S[cell], datum) < 1e-2` at the three data cells.  The oracle follows
+    idw.jl:128-141 with the compositions' own operations (powering, perturbation: `idw_compositional`); the twin maps
+    the parts to logarithms, estimates them as value columns that share one search and one weight vector, and maps
+    back -- the two agree to rounding because both operations are linear in the log-parts."""
+    data = [gss.Composition(0.1, 0.2), gss.Composition(0.3, 0.4), gss.Composition(0.5, 0.6)]
+    coord = [(25.0, 25.0), (50.0, 75.0), (75.0, 50.0)]
+    grid = gss.CartesianGrid(100, 100)
+    problem = gss.EstimationProblem(gss.georef({"z": data}, coord), grid, "z")
+    sol = gss.solve(problem, gss.IDWSolver(engine=OracleEngine))
+    S = sol["z"]
+    lin = lambda i, j: (i - 1) + 100 * (j - 1)                      # LinearIndices(size(grid))[i, j], 1-based
+    assert gss.aitchison(S[lin(25, 25)], data[0]) < 1e-2
+    assert gss.aitchison(S[lin(50, 75)], data[1]) < 1e-2
+    assert gss.aitchison(S[lin(75, 50)], data[2]) < 1e-2
+    # the restatement with the compositions' own arithmetic
+    parts = np.array([c.parts for c in data])
+    mu, sd, st = E.idw_compositional(np.array(coord), parts, grid.centroids())
+    got = np.array([c.parts for c in S])
+    assert np.max(np.abs(got / mu - 1.0)) < 1e-13 and not st.any()
+    assert np.allclose(sol["z_distance"], sd)
+    # known answers: (i) the clr coordinates of the estimate are the weighted means of the data's clr coordinates with
+    # weights that sum to one (the estimate stays in the simplex's linear structure); (ii) midway between two data the
+    # estimate is their geometric mean; (iii) a datum is reproduced at its own location (idw.jl:131-134)
+    x2 = np.array([[0.0], [2.0]])
+    p2 = np.array([[0.2, 0.3, 0.5], [0.6, 0.3, 0.1]])
+    m2, _, _ = E.idw_compositional(x2, p2, np.array([[1.0], [0.0], [0.5]]))
+    assert np.allclose(m2[0], np.sqrt(p2[0] * p2[1]), rtol=1e-15)
+    assert np.array_equal(m2[1], p2[0])
+    w = np.array([1 / 0.5, 1 / 1.5]) / (1 / 0.5 + 1 / 1.5)
+    clr = lambda v: np.log(v) - np.log(v).mean()
+    assert np.allclose(clr(m2[2]), w[0] * clr(p2[0]) + w[1] * clr(p2[1]), atol=1e-15)
+    # Composition arithmetic itself (CoDa's definitions, [RECALL]): perturbation, powering, scale invariance
+    a, b = gss.Composition(1.0, 2.0, 4.0), gss.Composition(2.0, 2.0, 1.0)
+    assert np.allclose((a + b).parts, [2.0, 4.0, 4.0]) and np.allclose((0.5 * a).parts, [1.0, np.sqrt(2.0), 2.0])
+    assert gss.aitchison(a, gss.Composition(3.0, 6.0, 12.0)) < 1e-15
+    assert np.isclose(gss.aitchison(gss.Composition(0.1, 0.2), gss.Composition(0.2, 0.1)), np.sqrt(2.0) * np.log(2.0))
+
+
+def test_compositions_with_missing_values_and_a_neighbourhood():
+    """Missing compositions are dropped like missing numbers (idw.jl:77); estimation points without enough neighbours
+    come back as `missing` (None) -- idw.jl:123-124."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 50, (30, 2))
+    parts = rng.uniform(0.1, 1.0, (30, 3))
+    data = [gss.Composition(p) for p in parts]
+    data[4] = None
+    dom = gss.PointSet(rng.uniform(0, 50, (40, 2)))
+    prob = gss.EstimationProblem(gss.georef({"c": data}, x), dom, "c")
+    sol = gss.solve(prob, gss.IDWSolver(("c", dict(maxneighbors=6, neighborhood=gss.MetricBall(12.0), exponent=2)),
+                                        engine=OracleEngine))
+    keep = np.arange(30) != 4
+    mu, sd, st = E.idw_compositional(x[keep], parts[keep], dom.centroids(), maxneighbors=6, exponent=2.0, radius=12.0)
+    assert st.any() and not st.all()
+    for j, c in enumerate(sol["c"]):
+        assert (c is None) == bool(st[j])
+        if c is not None:
+            assert np.allclose(c.parts, mu[j], rtol=1e-13)
