@@ -196,6 +196,73 @@ def cfg4_full(a, gss, _lib):
             "missing": int(st.sum().item()), "parity_max_abs_err_%d_points_across_the_call" % ns: err}
 
 
+def cfg_api(a, gss, _lib):
+    """The two headline workloads through the FRONT-END the reference's users call -- `solve(problem, solver)`
+    (krig.jl:130, fft.jl:62/145 under GeoStatsBase's loop) -- beside the handle-level numbers of bench.py, so that the
+    cost of the API layer (problem objects, missing-value handling, host tables in and out) is a number:
+    configs[1] `solve(EstimationProblem(1 000 data, PointSet of 10^6), KrigingSolver(z => (variogram = Matern-3/2)))`
+    and configs[2] `solve(SimulationProblem(CartesianGrid(512^3), z, 8), FFTGS(...))`, results in host memory as the
+    reference returns them."""
+    from gss.engine import KrigHandle, FFTGSHandle, OK
+    n, m = 1000, (100_000 if a.quick else 1_000_000)
+    x = np.random.default_rng(2).uniform(0.0, 100.0, (n, 3))
+    z = np.random.default_rng(1002).normal(size=n)
+    x0 = np.random.default_rng(3).uniform(0.0, 100.0, (m, 3))
+    vg = gss.MaternVariogram(range=30.0, order=1.5)
+    prob = gss.EstimationProblem(gss.georef({"z": z}, x), gss.PointSet(x0), "z")
+    solver = gss.KrigingSolver(("z", dict(variogram=vg)))
+    sol = gss.solve(prob, solver)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        sol = gss.solve(prob, solver)
+    dt_api = (time.perf_counter() - t0) / 3
+
+    def step():
+        h = KrigHandle(vg, OK, x, z)
+        out = h.predict_global(x0)
+        sync()
+        h.close()
+        return out
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        mu, var, st = step()
+    dt_handle = (time.perf_counter() - t0) / 3
+    same = bool(np.array_equal(np.asarray(sol["z"]), mu))
+    krig = {"workload": "configs[1]: solve(EstimationProblem(1000 3-D data, PointSet(%d)), KrigingSolver(Matern-3/2))" % m,
+            "solve_ms": round(dt_api * 1e3, 2), "handle_level_ms_same_host_arrays": round(dt_handle * 1e3, 2),
+            "points_per_s_through_solve": round(m / dt_api, 1), "api_overhead_ms": round((dt_api - dt_handle) * 1e3, 2),
+            "same_estimates": same}
+    e = 128 if a.quick else 512
+    R = 8
+    N = e ** 3
+    grid = gss.CartesianGrid((e, e, e))
+    fsolver = gss.FFTGS(("z", dict(variogram=gss.ExponentialVariogram(range=50.0 * e / 512))), rng=4)
+    fprob = gss.SimulationProblem(grid, ("z", float), R)
+    ens = gss.solve(fprob, fsolver)
+    del ens
+    t0 = time.perf_counter()
+    ens = gss.solve(fprob, fsolver)
+    dt_fapi = time.perf_counter() - t0
+    r0 = np.array(ens["z"][0][:1000])
+    del ens
+    f = FFTGSHandle(gss.ExponentialVariogram(range=50.0 * e / 512), (e, e, e))
+    out = np.empty((R, N))
+    out.fill(0.0)
+    f.realize(4, 0, R, out=out)
+    t0 = time.perf_counter()
+    f.realize(4, 0, R, out=out)
+    dt_fh = time.perf_counter() - t0
+    f.close()
+    fft = {"workload": "configs[2]: solve(SimulationProblem(CartesianGrid(%d^3), z, %d), FFTGS(exponential)), host vectors out" % (e, R),
+           "solve_s": round(dt_fapi, 3), "realisations_per_s_through_solve": round(R / dt_fapi, 2),
+           "handle_level_s_same_destination_kind": round(dt_fh, 3), "handle_level_realisations_per_s": round(R / dt_fh, 2),
+           "same_first_values": bool(np.array_equal(r0, out[0][:1000]))}
+    return {"config": "front-end rows: the headline workloads through gss.solve(problem, solver)", "metric": "kriged points/s through solve",
+            "value": krig["points_per_s_through_solve"], "unit": "points/s", "kriging": krig, "fftgs": fft}
+
+
 def cfg_bigk(a, gss, _lib):
     """Moving neighbourhoods with more than 64 neighbours (krig.jl:201-210, ui.jl:16-23 accept any count): UK degree 1,
     5 000 3-D data, Matern-3/2, k = 96 / 128 / 256.  One JSON object with a row per k."""
@@ -576,7 +643,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "api": cfg_api, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

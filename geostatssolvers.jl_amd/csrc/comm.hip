@@ -91,12 +91,63 @@ static int32_t adopt(int32_t kind, void* handle, void* stream) {
   }
 }
 
+static int g_last_ipc_route = -1;   // of the last gss_state_ipc_import (gss_stat "ipc_route": tests)
+int comm_last_ipc_route() { return g_last_ipc_route; }
+
 struct IpcToken {            // what gss_state_ipc_export writes (GSS_IPC_TOKEN_BYTES)
   hipIpcMemHandle_t mem;     // 64 bytes: the allocation that holds the state
   int64_t offset;            // of the state inside that allocation
   int64_t bytes;
+  int32_t pci_domain, pci_bus, pci_device;   // the owner's device: the importer decides between "my own device",
+  int32_t reserved;                          // "a peer I can reach" and "a device I cannot reach" before it maps anything
 };
 static_assert(sizeof(IpcToken) == GSS_IPC_TOKEN_BYTES, "token layout");
+
+static int32_t pci_of(int dev, int32_t* dom, int32_t* bus, int32_t* devid) {
+  int a = 0, b = 0, c = 0;
+  GSS_HIP(hipDeviceGetAttribute(&a, hipDeviceAttributePciDomainID, dev));
+  GSS_HIP(hipDeviceGetAttribute(&b, hipDeviceAttributePciBusId, dev));
+  GSS_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributePciDeviceId, dev));
+  *dom = a;
+  *bus = b;
+  *devid = c;
+  return GSS_OK;
+}
+
+// How the importing process reaches the owner's device.  GSS_IPC_SAME: it is this process's current device (two ranks on
+// one GPU, the one-GPU tests); GSS_IPC_PEER: another visible device with peer access -- enabled here, the copy then runs
+// over the direct xGMI link; GSS_IPC_HIDDEN: not among the visible devices (one process per GPU behind
+// HIP_VISIBLE_DEVICES): the IPC mapping itself is the test, with hipIpcMemLazyEnablePeerAccess; GSS_IPC_NOPEER: visible
+// but not reachable -- refused with a message instead of a failing copy.
+enum { GSS_IPC_SAME = 0, GSS_IPC_PEER = 1, GSS_IPC_HIDDEN = 2, GSS_IPC_NOPEER = 3 };
+static int32_t ipc_route(const IpcToken& t, int* route, int* owner_dev) {
+  int cur = 0, ndev = 0;
+  GSS_HIP(hipGetDevice(&cur));
+  GSS_HIP(hipGetDeviceCount(&ndev));
+  *route = GSS_IPC_HIDDEN;
+  *owner_dev = -1;
+  for (int d = 0; d < ndev; ++d) {
+    int32_t dom, bus, dv;
+    GSS_TRY(pci_of(d, &dom, &bus, &dv));
+    if (dom == t.pci_domain && bus == t.pci_bus && dv == t.pci_device) {
+      *owner_dev = d;
+      break;
+    }
+  }
+  if (*owner_dev == cur) *route = GSS_IPC_SAME;
+  else if (*owner_dev >= 0) {
+    int can = 0;
+    GSS_HIP(hipDeviceCanAccessPeer(&can, cur, *owner_dev));
+    *route = can ? GSS_IPC_PEER : GSS_IPC_NOPEER;
+  }
+  // test hook (one-GPU box): GSS_IPC_FORCE_ROUTE=peer|hidden|nopeer overrides the decision above
+  if (const char* f = std::getenv("GSS_IPC_FORCE_ROUTE")) {
+    if (!std::strcmp(f, "peer")) *route = GSS_IPC_PEER;
+    else if (!std::strcmp(f, "hidden")) *route = GSS_IPC_HIDDEN;
+    else if (!std::strcmp(f, "nopeer")) *route = GSS_IPC_NOPEER;
+  }
+  return GSS_OK;
+}
 
 }  // namespace gss
 
@@ -176,6 +227,9 @@ int32_t gss_state_ipc_export(int32_t kind, void* handle, uint8_t* token) {
   GSS_HIP(hipIpcGetMemHandle(&t.mem, base));
   t.offset = (int64_t)(static_cast<char*>(p) - static_cast<char*>(base));
   t.bytes = bytes;
+  int cur = 0;
+  GSS_HIP(hipGetDevice(&cur));
+  GSS_TRY(pci_of(cur, &t.pci_domain, &t.pci_bus, &t.pci_device));
   std::memcpy(token, &t, sizeof(t));
   return GSS_OK;
 }
@@ -191,8 +245,33 @@ int32_t gss_state_ipc_import(int32_t kind, void* handle, const uint8_t* token, v
   GSS_REQUIRE(t.bytes == bytes, "state sizes differ: the owner exports %lld bytes, this handle holds %lld (same grid / "
               "data on both sides?)", (long long)t.bytes, (long long)bytes);
   hipStream_t s = to_stream(stream);
+  int route = GSS_IPC_HIDDEN, owner = -1;
+  GSS_TRY(ipc_route(t, &route, &owner));
+  g_last_ipc_route = route;
+  if (route == GSS_IPC_NOPEER) {
+    set_error("gss_state_ipc_import: the owner's device (PCI %04x:%02x:%02x) is visible to this process but not peer-accessible "
+              "from its current device; use gss_state_bcast (RCCL) or recompute the state on this rank",
+              (unsigned)t.pci_domain, (unsigned)t.pci_bus, (unsigned)t.pci_device);
+    return GSS_ERR_UNSUPPORTED;
+  }
+  if (route == GSS_IPC_PEER && owner >= 0) {
+    const hipError_t pe = hipDeviceEnablePeerAccess(owner, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+      set_error("gss_state_ipc_import: enabling peer access to device %d failed: %s", owner, hipGetErrorString(pe));
+      return GSS_ERR_HIP;
+    }
+    (void)hipGetLastError();   // (hipErrorPeerAccessAlreadyEnabled is sticky otherwise)
+  }
   void* src = nullptr;
-  GSS_HIP(hipIpcOpenMemHandle(&src, t.mem, hipIpcMemLazyEnablePeerAccess));
+  {
+    const hipError_t oe = hipIpcOpenMemHandle(&src, t.mem, hipIpcMemLazyEnablePeerAccess);
+    if (oe != hipSuccess) {
+      set_error("gss_state_ipc_import: mapping the owner's buffer (device PCI %04x:%02x:%02x, %s) failed: %s",
+                (unsigned)t.pci_domain, (unsigned)t.pci_bus, (unsigned)t.pci_device,
+                route == GSS_IPC_HIDDEN ? "not visible to this process" : "visible", hipGetErrorString(oe));
+      return GSS_ERR_HIP;
+    }
+  }
   const hipError_t e = hipMemcpyAsync(p, static_cast<char*>(src) + t.offset, (size_t)bytes, hipMemcpyDeviceToDevice, s);
   const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(s) : e;
   (void)hipIpcCloseMemHandle(src);

@@ -766,6 +766,10 @@ int32_t gss_stat(const char* name, int64_t* value) {
     *value = g_stat_ring_bytes.load();
   } else if (!std::strcmp(name, "out_chunks")) {
     *value = g_stat_chunks.load();
+  } else if (!std::strcmp(name, "panel_giveups")) {
+    *value = panel_giveups();
+  } else if (!std::strcmp(name, "ipc_route")) {
+    *value = comm_last_ipc_route();   // of the last gss_state_ipc_import: 0 same device, 1 peer, 2 not visible, 3 refused
   } else {
     set_error("gss_stat: unknown counter '%s'", name);
     return GSS_ERR_INVALID;

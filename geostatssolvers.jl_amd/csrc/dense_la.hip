@@ -1161,7 +1161,12 @@ static int panel_workgroups() {
 // set when a launch reported -1 (its workgroups were not all resident within the bounded spin, e.g. many such
 // kernels at once): the process goes back to the launch-per-block recursion from then on
 static std::atomic<bool> g_panel_off{false};
-void potrf_panel_disable() { g_panel_off.store(true); }
+static std::atomic<int> g_panel_giveups{0};   // gss_stat "panel_giveups"
+void potrf_panel_disable() {
+  g_panel_off.store(true);
+  g_panel_giveups.fetch_add(1);
+}
+int panel_giveups() { return g_panel_giveups.load(); }
 static bool use_panel(int64_t n) { return !g_panel_off.load() && n >= PANEL_MIN && n <= panel_max_rows(); }
 constexpr int64_t PANEL_MAX_LD = (int64_t)1 << 20;  // 32-bit element offsets inside the kernel
 

@@ -781,6 +781,8 @@ inline bool first_on_this_device(uint64_t& mask) {
   mask |= bit;
   return true;
 }
+int comm_last_ipc_route();   // comm.hip
+int panel_giveups();          // dense_la.hip: times a single-launch factorisation gave up at a grid barrier
 void lu_grid_disable();   // lu.hip: 32-column LU panels on one workgroup instead of the grid
 // padded16: the caller guarantees that rows and columns n .. 16 ceil(n / 16) - 1 of A and W exist in memory and are
 // zero (they stay zero): a size that is not a multiple of 16 then still runs on the single-launch panel kernel.

@@ -247,7 +247,7 @@ def metric_spec(distance):
 
 
 STATE_KRIG, STATE_FFTGS, STATE_LUGS = 0, 1, 2
-COMM_ID_BYTES, IPC_TOKEN_BYTES = 128, 80
+COMM_ID_BYTES, IPC_TOKEN_BYTES = 128, 96
 
 
 def comm_unique_id() -> bytes:
@@ -286,13 +286,13 @@ def state_ipc_export(kind: int, handle) -> bytes:
 
 def state_ipc_import(kind: int, handle, token: bytes):
     if len(token) != IPC_TOKEN_BYTES:
-        raise ValueError("IPC token must have 80 bytes")
+        raise ValueError("IPC token must have %d bytes" % IPC_TOKEN_BYTES)
     buf = C.create_string_buffer(token, IPC_TOKEN_BYTES)
     check(lib().gss_state_ipc_import(int(kind), handle, C.cast(buf, C.c_void_p), current_stream()))
 
 
 def stat(name: str) -> int:
-    """A library counter: "pool_bytes", "out_ring_bytes", "out_chunks" (gss.h, gss_stat)."""
+    """A library counter: "pool_bytes", "out_ring_bytes", "out_chunks", "panel_giveups", "ipc_route" (gss.h, gss_stat)."""
     v = C.c_int64()
     check(load().gss_stat(name.encode(), C.byref(v)))
     return v.value

@@ -51,7 +51,7 @@ const GSS_FFTGS_NO_SPECTRUM = Int32(1)
 const GSS_LUGS_NO_FACTOR = Int32(1)
 const GSS_STATE_FFTGS = Int32(1)
 const GSS_STATE_LUGS = Int32(2)
-const GSS_IPC_TOKEN_BYTES = 80
+const GSS_IPC_TOKEN_BYTES = 96
 const GSS_KRIG_NO_FACTOR = Int32(1)
 const GSS_KRIG_ASYNC_FIT = Int32(2)     # fit beside the first assembly; status at the first global prediction
 const GSS_LUGS_FACT_LU = Int32(2)

@@ -134,7 +134,10 @@ int32_t gss_dev_to_host(void* dst, const void* src_dev, int64_t bytes, void* str
  * program whose own allocator (torch, RCCL, rocFFT) has just failed.  Synchronises the device. */
 int32_t gss_trim_pool(void);
 /* Counters for tests and diagnostics: "pool_bytes" (device bytes in the block cache), "out_ring_bytes" (HBM staged for
- * the host outputs of the last simulation call), "out_chunks" (chunks that call moved). */
+ * the host outputs of the last simulation call), "out_chunks" (chunks that call moved), "panel_giveups" (times a
+ * single-launch factorisation left through its bounded wait and was repeated on the launch-per-block path),
+ * "ipc_route" (how the last gss_state_ipc_import reached the owner's device: 0 same device, 1 visible peer, 2 not among
+ * the visible devices, 3 refused -- visible but not peer-accessible). */
 int32_t gss_stat(const char* name, int64_t* value);
 
 /* ---- multi-GPU: one process per GPU, the preprocess state of rank 0 replicated to the peers -----------------
@@ -151,10 +154,12 @@ int32_t gss_stat(const char* name, int64_t* value);
  *      HIP IPC (no communicator, works between processes that share one device as well): the owner writes a token with
  *      gss_state_ipc_export, the host carries its GSS_IPC_TOKEN_BYTES bytes, a peer calls gss_state_ipc_import: it maps
  *      the owner's buffer, pulls it with one device-to-device copy over its own xGMI link and adopts.  The owner keeps
- *      its handle alive until the peers have imported.                                                              */
+ *      its handle alive until the peers have imported.  The token names the owner's device (PCI domain / bus / device):
+ *      the importer enables peer access when that device is another visible one, and refuses -- GSS_ERR_UNSUPPORTED, the
+ *      message names gss_state_bcast and recomputation -- when it is visible but not peer-accessible.             */
 enum { GSS_STATE_KRIG = 0, GSS_STATE_FFTGS = 1, GSS_STATE_LUGS = 2 };   /* which create call `handle` came from */
 #define GSS_COMM_ID_BYTES 128
-#define GSS_IPC_TOKEN_BYTES 80
+#define GSS_IPC_TOKEN_BYTES 96
 int32_t gss_comm_unique_id(uint8_t* id);                               /* id[GSS_COMM_ID_BYTES], root only */
 int32_t gss_comm_init(const uint8_t* id, int32_t rank, int32_t nranks);
 int32_t gss_comm_info(int32_t* rank, int32_t* nranks);                 /* -1, 0 without a communicator */

@@ -287,3 +287,53 @@ def test_lu_grid_panel_gives_up_cleanly():
     r = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, GSS_LU_PANEL_FAIL="1"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and "LUGS LU RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_single_launch_panel_beside_a_callers_own_kernels():
+    """The single-launch factor-and-inverse kernel needs its 64 workgroups resident together, a whole CU each.  The
+    library's own launch order guarantees that; a CALLER's kernels on another stream (here: a chain of large FP64
+    matrix products from torch, LDS-heavy workgroups that keep every CU busy) can delay their arrival.  Whatever happens
+    -- the panel squeezes in, or its bounded wait ends and the fit repeats on the launch-per-block path -- the
+    estimates must be the usual ones and the call must return; the child prints what happened and what it cost
+    (recorded in profiles/)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, gss\n"
+        "from gss import _lib\n"
+        "from gss.engine import KrigHandle, OK\n"
+        "from oracle import kriging as K\n"
+        "from oracle.variogram import Variogram\n"
+        "rng = np.random.default_rng(0)\n"
+        "x = rng.uniform(0, 100, (1000, 3)); z = rng.normal(size=1000); x0 = rng.uniform(0, 100, (400, 3))\n"
+        "ref = K.predict(K.fit(K.OK, Variogram('matern', range=30.0, nu=1.5), x, z), x0)\n"
+        "vg = gss.MaternVariogram(range=30.0, order=1.5)\n"
+        "def fit_predict():\n"
+        "    t0 = time.perf_counter()\n"
+        "    h = KrigHandle(vg, OK, x, z)\n"
+        "    mu, var, st = h.predict_global(x0)\n"
+        "    torch.cuda.synchronize()\n"
+        "    dt = time.perf_counter() - t0\n"
+        "    h.close()\n"
+        "    assert np.max(np.abs(mu - ref[0])) < 1e-9 and np.max(np.abs(var - ref[1])) < 1e-9\n"
+        "    return dt\n"
+        "fit_predict()\n"
+        "alone = min(fit_predict() for _ in range(3))\n"
+        "a = torch.randn(6144, 6144, dtype=torch.float64, device='cuda')\n"
+        "side = torch.cuda.Stream()\n"
+        "beside = []\n"
+        "for trial in range(6):\n"
+        "    with torch.cuda.stream(side):\n"
+        "        for _ in range(8):\n"
+        "            b = a @ a\n"
+        "    beside.append(fit_predict())\n"
+        "    torch.cuda.synchronize()\n"
+        "print('FOREIGN alone %%.2f ms, beside the products %%s ms, give-ups %%d' %% (alone * 1e3, ' '.join('%%.2f' %% (t * 1e3) for t in beside), _lib.stat('panel_giveups')))\n"
+    ) % (root, os.path.join(root, "geostatssolvers.jl_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FOREIGN alone" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    print([l for l in r.stdout.splitlines() if l.startswith("FOREIGN")][0])
