@@ -218,8 +218,42 @@ metricspec(d::Haversine) = (Int32(3), Float64(d.radius))
 metricspec(d) = throw(ArgumentError("search distance $d is not available on the device"))
 searchmetric(p) = isnothing(p.neighborhood) ? metricspec(p.distance) : (Int32(0), 0.0)
 
-# point-major coordinates: a d x n Julia matrix is already in the layout the C-ABI wants
-coordmatrix(dom) = reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(dom, i)))) for i in 1:nelements(dom)])
+# Point-major coordinates: a d x n Julia matrix is already in the layout the C-ABI wants.  Three methods, because for
+# 10^6 - 10^7 elements the generic one -- a `centroid` call and a small vector per element -- would be the `solve` time:
+#   * CartesianGrid: the centroids are origin + (index - 1/2) * spacing per axis, first axis fastest (the order of the
+#     grid's elements and of every realisation vector): d ranges and one pass over the matrix, nothing per element;
+#   * PointSet of Float64 points: the coordinate vectors ARE the columns -- one `reinterpret`, no copy of the data
+#     beyond the final `Matrix` (the C side wants contiguous memory that stays put during the call);
+#   * views of either (`view(domain, inds)`, `parentindices`): the parent's matrix, then the selected columns;
+#   * anything else: element by element.
+function coordmatrix(g::CartesianGrid)
+  dims = size(g)
+  d = length(dims)
+  o = Float64[ustrip.(coordinates(minimum(g)))...]
+  sp = Float64[ustrip.(spacing(g))...]
+  axes = [o[a] .+ ((1:dims[a]) .- 0.5) .* sp[a] for a in 1:d]
+  X = Matrix{Float64}(undef, d, prod(dims))
+  j = 0
+  for I in CartesianIndices(dims)          # first index fastest = the linear order of the grid's elements
+    j += 1
+    for a in 1:d
+      X[a, j] = axes[a][I[a]]
+    end
+  end
+  X
+end
+function coordmatrix(ps::PointSet)
+  n = nelements(ps)
+  n == 0 && return Matrix{Float64}(undef, embeddim(ps), 0)
+  v = [ustrip.(coordinates(ps[i])) for i in 1:n]                  # Vector of static coordinate vectors
+  eltype(eltype(v)) === Float64 ? Matrix(reinterpret(reshape, Float64, v)) : Float64.(reduce(hcat, v))
+end
+function coordmatrix(dom)
+  if parent(dom) !== dom && (parent(dom) isa CartesianGrid || parent(dom) isa PointSet)
+    return coordmatrix(parent(dom))[:, collect(parentindices(dom))]
+  end
+  reduce(hcat, [collect(Float64, ustrip.(coordinates(centroid(dom, i)))) for i in 1:nelements(dom)])
+end
 
 # ---- KrigingSolver ------------------------------------------------------------------------
 @estimsolver KrigingSolverHIP begin

@@ -120,15 +120,18 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.timeout(300)
-def test_two_ranks_reproduce_single_process_results():
+@pytest.mark.timeout(420)
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_reproduce_single_process_results(world):
+    """world = 2, and world = 8 -- the node the driver launches: more ranks than realisations (5 FFTGS, 3 LUGS / SGS), so
+    several ranks hold EMPTY shards and still take part in the broadcasts and gathers."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=240) for _ in range(2))
+    results = dict(q.get(timeout=360) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -155,7 +158,7 @@ def test_two_ranks_reproduce_single_process_results():
     rs = gss.solve(gss.SimulationProblem(S, gss.CartesianGrid(24), "z", 3),
                    gss.SGS(("z", dict(variogram=gss.SphericalVariogram(range=6.0), maxneighbors=5)), rng=9,
                            engine=OracleEngine))
-    for rank in (0, 1):
+    for rank in range(world):
         out = results[rank]
         assert np.array_equal(out["idw"], np.c_[ri["z"], ri["z_distance"]])
         assert np.array_equal(out["lwr"], np.c_[rl["z"], rl["z_variance"]])
