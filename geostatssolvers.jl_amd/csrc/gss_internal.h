@@ -331,6 +331,29 @@ __device__ __forceinline__ double gss_exp_poly(double x) {
   return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// gss_exp_poly for arguments that are finite and <= 0 (minus a distance): the clamp at -800 only protects the integer
+// conversion of n, which saturates by itself, and ldexp of a huge negative exponent is the 0 that exp underflows to.
+__device__ __forceinline__ double gss_exp_poly_neg(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double gss_sqrt(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double s = x * y;
@@ -636,9 +659,9 @@ __device__ __forceinline__ double vg_shape_k(double d2, double inv_range, double
   return vg_shape(KIND, d2, inv_range, mscale, pw);
 }
 
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT>
 __device__ __forceinline__ double cov_pair_k(const VgDev& v, const double* a, const double* b);
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT>
 __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DIM], const double* b, double* out);
 
 // out[u] = C(a_u, b) for four points a_u and one point b
@@ -668,29 +691,47 @@ __device__ __forceinline__ void cov_pair4(const VgDev& v, const double (*a)[DIM]
 // scales each point once, krig_local.hip), so a pair costs three differences and one fused sum of squares instead of
 // a multiply and a select per coordinate; the square root runs on max(d2, 1e-300) without its zero guard (a zero lag
 // is replaced by the total sill afterwards anyway).  KIND < 0: any model, coordinates as they are.
+// UNIT: the caller has also multiplied the coordinates by the model's own scale (kpos_scale below), so the scaled
+// distance IS the argument of the shape -- two multiplications fewer per pair (the moving-neighbourhood kernel scales its
+// 64 neighbours once and evaluates 2 048 pairs).
 template <int KIND>
+__device__ __forceinline__ double kpos_scale(const VgDev& v) {
+  if (KIND == GSS_VG_GAUSSIAN) return 1.7320508075688772 * v.inv_range;   // exp(-3 (h / r)^2) = exp(-|sqrt(3) h / r|^2)
+  if (KIND == GSS_VG_EXPONENTIAL) return 3.0 * v.inv_range;
+  if (KIND == GSS_VG_SPHERICAL) return v.inv_range;
+  return v.mscale * v.inv_range;                                           // Matern 1/2, 3/2, 5/2
+}
+template <int KIND, bool UNIT = false>
 __device__ __forceinline__ double vg_shape_kpos(double d2, double inv_range, double mscale, double pw) {
-  if (KIND == GSS_VG_GAUSSIAN) return gss_exp_poly(-3.0 * (d2 * inv_range * inv_range));
+  if (KIND == GSS_VG_GAUSSIAN) return gss_exp_poly_neg(UNIT ? -d2 : -3.0 * (d2 * inv_range * inv_range));
   const double y = __builtin_amdgcn_rsq(d2);  // gss_sqrt without the zero guard
   double sq = d2 * y;
   const double hy = 0.5 * y;
   sq = fma(fma(-sq, sq, d2), hy, sq);
   sq = fma(fma(-sq, sq, d2), hy, sq);
-  if (KIND == GSS_VG_EXPONENTIAL) return gss_exp_poly(-3.0 * (sq * inv_range));
-  if (KIND == VG_MATERN12) return gss_exp_poly(-(mscale * (sq * inv_range)));
+  if (KIND == GSS_VG_EXPONENTIAL) return gss_exp_poly_neg(UNIT ? -sq : -3.0 * (sq * inv_range));
+  if (KIND == VG_MATERN12) return gss_exp_poly_neg(UNIT ? -sq : -(mscale * (sq * inv_range)));
   if (KIND == VG_MATERN32) {
-    const double d = mscale * (sq * inv_range);
-    return (1.0 + d) * gss_exp_poly(-d);
+    const double d = UNIT ? sq : mscale * (sq * inv_range);
+    return (1.0 + d) * gss_exp_poly_neg(-d);
   }
   if (KIND == VG_MATERN52) {
-    const double d = mscale * (sq * inv_range);
-    return (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp_poly(-d);
+    const double d = UNIT ? sq : mscale * (sq * inv_range);
+    return (1.0 + d + d * d * (1.0 / 3.0)) * gss_exp_poly_neg(-d);
   }
   if (KIND == GSS_VG_SPHERICAL) {
-    const double x = sq * inv_range;
+    const double x = UNIT ? sq : sq * inv_range;
     return x < 1.0 ? 1.0 - (1.5 * x - 0.5 * x * x * x) : 0.0;
   }
   return vg_shape(KIND, d2, inv_range, mscale, pw);
+}
+
+// a * b rounded once and never fused into a following addition: the scaled coordinates of a sample and of an estimation
+// point that coincide must be the SAME doubles, so that their distance is exactly zero (C(0) = sill, not sill - nugget)
+__device__ __forceinline__ double mul_rounded(double a, double b) {
+#pragma clang fp contract(off)
+  const double r = a * b;
+  return r;
 }
 
 template <int DIM>
@@ -704,15 +745,15 @@ __device__ __forceinline__ double sqdist_scaled(const double* a, const double* b
   return acc;
 }
 
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT = false>
 __device__ __forceinline__ double cov_pair_k(const VgDev& v, const double* a, const double* b) {
   if (KIND < 0) return cov_pair<DIM>(v, a, b);
   const double d2 = sqdist_scaled<DIM>(a, b);
-  const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2, 1e-300), v.inv_range, v.mscale, v.pw);
+  const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND), UNIT>(fmax(d2, 1e-300), v.inv_range, v.mscale, v.pw);
   return d2 <= 0.0 ? v.sill : v.cs * g;
 }
 
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT = false>
 __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DIM], const double* b, double* out) {
   if (KIND < 0) {
     cov_pair4<DIM>(v, a, b, out);
@@ -722,15 +763,19 @@ __device__ __forceinline__ void cov_pair4_k(const VgDev& v, const double (*a)[DI
 #pragma unroll
   for (int u = 0; u < 4; ++u) d2[u] = sqdist_scaled<DIM>(a[u], b);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
-    out[u] = d2[u] <= 0.0 ? v.sill : v.cs * g;
+  for (int u = 0; u < 4; ++u)
+    out[u] = v.cs * vg_shape_kpos<(KIND < 0 ? 0 : KIND), UNIT>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
+  // C(0) = sill.  At a zero lag the shape evaluated at 1e-300 is exactly 1 for every one of these models, i.e. the value
+  // above is cs = sill - nugget: only a model WITH a nugget needs the select (wave-uniform: a scalar branch)
+  if (v.cs != v.sill) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = d2[u] <= 0.0 ? v.sill : out[u];
   }
 }
 
 // four independent pairs (a[u], b[u]): the paired diagonal tiles of the moving-neighbourhood kernel, where the column
 // a lane works on depends on the row (krig_local.hip)
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT = false>
 __device__ __forceinline__ void cov_pairs4_k(const VgDev& v, const double (*a)[DIM], const double (*b)[DIM], double* out) {
   if (KIND < 0) {
 #pragma unroll
@@ -741,9 +786,11 @@ __device__ __forceinline__ void cov_pairs4_k(const VgDev& v, const double (*a)[D
 #pragma unroll
   for (int u = 0; u < 4; ++u) d2[u] = sqdist_scaled<DIM>(a[u], b[u]);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const double g = vg_shape_kpos<(KIND < 0 ? 0 : KIND)>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
-    out[u] = d2[u] <= 0.0 ? v.sill : v.cs * g;
+  for (int u = 0; u < 4; ++u)
+    out[u] = v.cs * vg_shape_kpos<(KIND < 0 ? 0 : KIND), UNIT>(fmax(d2[u], 1e-300), v.inv_range, v.mscale, v.pw);
+  if (v.cs != v.sill) {   // (see cov_pair4_k)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = d2[u] <= 0.0 ? v.sill : out[u];
   }
 }
 

@@ -26,12 +26,13 @@ struct LocalSpec {
 };
 
 // c0 entry of one neighbour.  xs: the neighbour (already divided by the radii of the model's ball when KIND >= 0 and the
-// model is anisotropic), c: the estimation point as given, cs: the same scaled like xs.  Point support: one covariance;
+// model is anisotropic, and -- UNIT -- multiplied by the model's own scale, kpos_scale), c: the estimation point as given,
+// cs: the same scaled like xs, sca: the per-axis factor xs and cs carry (UNIT only).  Point support: one covariance;
 // block support: the mean over the sub-cell centres, first axis slowest as in the oracle.
-template <int DIM, int KIND>
+template <int DIM, int KIND, bool UNIT = false>
 __device__ __forceinline__ double c0_entry(const VgDev& vg, const LocalSpec& sp, const double* xs, const double* c,
-                                           const double* cs) {
-  if (sp.bsub <= 0) return cov_pair_k<DIM, KIND>(vg, xs, cs);
+                                           const double* cs, const double* sca = nullptr) {
+  if (sp.bsub <= 0) return cov_pair_k<DIM, KIND, UNIT>(vg, xs, cs);
   const int nsub = sp.bsub;
   const int ns = DIM == 1 ? nsub : (DIM == 2 ? nsub * nsub : nsub * nsub * nsub);
   double acc = 0.0;
@@ -43,9 +44,9 @@ __device__ __forceinline__ double c0_entry(const VgDev& vg, const LocalSpec& sp,
       const int ia = q % nsub;
       q /= nsub;
       const double v = c[a] + (((double)ia + 0.5) / (double)nsub - 0.5) * sp.bcell[a];
-      pt[a] = (KIND >= 0 && vg.aniso) ? v * vg.ir[a] : v;
+      pt[a] = UNIT ? mul_rounded(v, sca[a]) : ((KIND >= 0 && vg.aniso) ? mul_rounded(v, vg.ir[a]) : v);
     }
-    acc += cov_pair_k<DIM, KIND>(vg, xs, pt);
+    acc += cov_pair_k<DIM, KIND, UNIT>(vg, xs, pt);
   }
   return acc / (double)ns;
 }

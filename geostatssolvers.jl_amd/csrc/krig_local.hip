@@ -337,11 +337,16 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
   }
   const int nc = sp.nc;
   const int g = lane >> 4, c = lane & 15;
-  double c0[DIM], c0s[DIM];
+  // (single-structure instantiations: the coordinates carry the radii of the model's ball AND the model's own scale, so
+  //  that the scaled distance is the argument of the shape -- kpos_scale, gss_internal.h)
+  constexpr bool UNIT = KIND >= 0;
+  double c0[DIM], c0s[DIM], sca[DIM];
 #pragma unroll
   for (int a = 0; a < DIM; ++a) {
+    sca[a] = UNIT ? (vg.aniso ? vg.ir[a] : 1.0) * kpos_scale<(KIND < 0 ? 0 : KIND)>(vg) : 1.0;
     c0[a] = x0[p * DIM + a];
-    c0s[a] = (KIND >= 0 && vg.aniso) ? c0[a] * vg.ir[a] : c0[a];
+    c0s[a] = UNIT ? mul_rounded(c0[a], sca[a]) : c0[a];   // (rounded products: a contraction with the difference below
+                                                          //  would make a coincident sample's distance nonzero)
   }
   {
     const bool act = lane < cnt;
@@ -350,12 +355,12 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
       xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
-      xjs[a] = (KIND >= 0 && vg.aniso) ? xj[a] * vg.ir[a] : xj[a];
+      xjs[a] = UNIT ? mul_rounded(xj[a], sca[a]) : xj[a];
       nxs[lane][a] = xjs[a];
     }
     double zz = act ? z[nj] : 0.0;
     if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-    rhs_col(0)[lane] = act ? c0_entry<DIM, KIND>(vg, sp, xjs, c0, c0s) : 0.0;
+    rhs_col(0)[lane] = act ? c0_entry<DIM, KIND, UNIT>(vg, sp, xjs, c0, c0s, sca) : 0.0;
     rhs_col(1)[lane] = act ? zz : 0.0;
     // drift columns: monomials about the estimation point (uniform exponents), external drifts, or the constant
     double um[DIM];
@@ -413,7 +418,7 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
             xc[r][d] = nxs[blk + c][d];
           }
         }
-        cov_pairs4_k<DIM, KIND>(vg, xr, xc, v);
+        cov_pairs4_k<DIM, KIND, UNIT>(vg, xr, xc, v);
         d4_t t0, t1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -449,7 +454,7 @@ void krig_local_mfma_kernel(VgDev vg, LocalSpec sp, const double* __restrict__ x
           double xcol[DIM], v[4];
 #pragma unroll
           for (int a = 0; a < DIM; ++a) xcol[a] = nxs[col][a];
-          cov_pair4_k<DIM, KIND>(vg, xr, xcol, v);
+          cov_pair4_k<DIM, KIND, UNIT>(vg, xr, xcol, v);
 #pragma unroll
           for (int r = 0; r < 4; ++r) T[tile_id(I, J)][r] = v[r];
           if (ragged && J == nt - 1) {

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
       c0[a] = x0[p * DIM + a];
-      c0s[a] = (KIND >= 0 && vg.aniso) ? c0[a] * vg.ir[a] : c0[a];
+      c0s[a] = (KIND >= 0 && vg.aniso) ? mul_rounded(c0[a], vg.ir[a]) : c0[a];   // rounded, never contracted with the
+                                                                                  // difference: a coincident sample stays at distance 0
     }
     if (tid == 0) s_bad = 0;
     // neighbour coordinates and the right-hand-side columns (lane = neighbour), staged where the pivot row will live
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
 #pragma unroll
       for (int a = 0; a < DIM; ++a) {
         xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
-        xjs[a] = (KIND >= 0 && vg.aniso) ? xj[a] * vg.ir[a] : xj[a];
+        xjs[a] = (KIND >= 0 && vg.aniso) ? mul_rounded(xj[a], vg.ir[a]) : xj[a];
         nx[j * 3 + a] = xjs[a];
       }
       double zz = act ? z[nj] : 0.0;

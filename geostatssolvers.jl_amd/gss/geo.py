@@ -187,7 +187,8 @@ def georef(table, domain) -> GeoTable:
         domain = PointSet(np.asarray(domain, dtype=np.float64))
     cols = {}
     for k, v in dict(table).items():
-        if len(v) and any(isinstance(x, Composition) for x in v):
+        numeric = isinstance(v, np.ndarray) and v.dtype != object     # (never walk a million floats looking for objects)
+        if not numeric and len(v) and any(isinstance(x, Composition) for x in v):
             a = np.empty(len(v), dtype=object)          # a column of compositions (None = missing)
             a[:] = list(v)
         else:

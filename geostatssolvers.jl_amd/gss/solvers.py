@@ -250,6 +250,15 @@ def _path_order(path, n, domain=None):
     return order
 
 
+def _mask_missing(a, st):
+    """`missing` (krig.jl:213-214, idw.jl:123-124) as NaN, in place: the arrays are the call's own outputs, and a pass of
+    `np.where` over 10^6 - 10^7 estimates that almost never hold a missing value costs more than the device call."""
+    bad = st != 0
+    if bad.any():
+        a[..., bad] = np.nan
+    return a
+
+
 def _ball(neighborhood):
     if neighborhood is None:
         return None, None
@@ -366,8 +375,8 @@ class KrigingSolver(_Solver):
                     mu, var_, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
             finally:
                 h.close()
-            mu = np.where(st == 0, mu, np.nan)                         # `missing` krig.jl:213-214
-            var_ = np.where(st == 0, var_, np.nan)
+            mu = _mask_missing(mu, st)                                 # `missing` krig.jl:213-214
+            var_ = _mask_missing(var_, st)
             if gather and ws > 1:
                 mu = parallel.all_gather_concat(mu, m)
                 var_ = parallel.all_gather_concat(var_, m)
@@ -458,8 +467,8 @@ class _NeighborEstimator(_Solver):
             else:
                 mu = np.empty((zin.shape[0], 0)) if comp else np.empty(0)
                 ax, st = np.empty(0), np.empty(0, dtype=np.uint8)
-            mu = np.where(st == 0, mu, np.nan)                            # `missing`
-            ax = np.where(st == 0, ax, np.nan)
+            mu = _mask_missing(mu, st)                                    # `missing`
+            ax = _mask_missing(ax, st)
             if gather and ws > 1:
                 mu = (np.stack([parallel.all_gather_concat(r, m) for r in mu]) if comp
                       else parallel.all_gather_concat(mu, m))
