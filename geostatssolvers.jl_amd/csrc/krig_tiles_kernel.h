@@ -80,12 +80,15 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
     const int nt = (cnt + 15) >> 4;
     // KIND >= 0 (one structure fixed at compile time): coordinates are divided by the radii of the model's ball once,
     // as in the 64-neighbour kernel, and every pair is three differences and a fused sum of squares
-    double c0[DIM], c0s[DIM];
+    // (and, round 4, multiplied by the model's own scale -- kpos_scale -- so that the scaled distance is the argument of
+    //  the shape; products rounded once and never contracted with the difference: a coincident sample stays at distance 0)
+    constexpr bool UNIT = KIND >= 0;
+    double c0[DIM], c0s[DIM], sca[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
+      sca[a] = UNIT ? (vg.aniso ? vg.ir[a] : 1.0) * kpos_scale<(KIND < 0 ? 0 : KIND)>(vg) : 1.0;
       c0[a] = x0[p * DIM + a];
-      c0s[a] = (KIND >= 0 && vg.aniso) ? mul_rounded(c0[a], vg.ir[a]) : c0[a];   // rounded, never contracted with the
-                                                                                  // difference: a coincident sample stays at distance 0
+      c0s[a] = UNIT ? mul_rounded(c0[a], sca[a]) : c0[a];
     }
     if (tid == 0) s_bad = 0;
     // neighbour coordinates and the right-hand-side columns (lane = neighbour), staged where the pivot row will live
@@ -99,12 +102,12 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
 #pragma unroll
       for (int a = 0; a < DIM; ++a) {
         xj[a] = act ? xdata[(int64_t)nj * DIM + a] : 0.0;
-        xjs[a] = (KIND >= 0 && vg.aniso) ? mul_rounded(xj[a], vg.ir[a]) : xj[a];
+        xjs[a] = UNIT ? mul_rounded(xj[a], sca[a]) : xj[a];
         nx[j * 3 + a] = xjs[a];
       }
       double zz = act ? z[nj] : 0.0;
       if (sp.variant == GSS_KRIG_SIMPLE) zz -= sp.sk_mean;
-      rhs[0 * KMAX + j] = act ? c0_entry<DIM, KIND>(vg, sp, xjs, c0, c0s) : 0.0;
+      rhs[0 * KMAX + j] = act ? c0_entry<DIM, KIND, UNIT>(vg, sp, xjs, c0, c0s, sca) : 0.0;
       rhs[1 * KMAX + j] = act ? zz : 0.0;
       for (int t = 0; t < nc; ++t) {
         double f = 1.0;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_til
       const int cj = 16 * col + c;
 #pragma unroll
       for (int a = 0; a < DIM; ++a) xc[a] = nx[cj * 3 + a];
-      cov_pair4_k<DIM, KIND>(vg, xr, xc, v);
+      cov_pair4_k<DIM, KIND, UNIT>(vg, xr, xc, v);
       d4_t t;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -191,11 +191,16 @@ __device__ __forceinline__ void potrf16_full(const d4_t& t, double* S, double* S
 // One tile, only what a right-looking block step needs from it: v = U^-1 in tile layout (t = U'U) and the first column
 // whose pivot was not positive (-1 if none).  potrf16_full without the U / V' outputs: 16 x 17 doubles of LDS (S), the
 // calling wave alone when WAVE_LOCAL (the other waves of the workgroup wait at a barrier of their own).
-template <bool WAVE_LOCAL = false>
+// TRANSPOSED: the tile is stored transposed, i.e. the factorisation sees t' -- for a symmetric tile that is only valid in
+// its upper triangle (the paired diagonal tiles of the moving-neighbourhood kernels): the sweep reads the lower triangle.
+template <bool WAVE_LOCAL = false, bool TRANSPOSED = false>
 __device__ __forceinline__ void potrf16_inv(const d4_t& t, double* S, int lane, d4_t* v, int* bad_col) {
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) S[(g + 4 * r) * 17 + c] = t[r];
+  for (int r = 0; r < 4; ++r) {
+    if (TRANSPOSED) S[c * 17 + (g + 4 * r)] = t[r];
+    else S[(g + 4 * r) * 17 + c] = t[r];
+  }
   tile_sync<WAVE_LOCAL>();
   const int i = c;
   double row[16];
