@@ -263,6 +263,49 @@ def cfg_api(a, gss, _lib):
             "value": krig["points_per_s_through_solve"], "unit": "points/s", "kriging": krig, "fftgs": fft}
 
 
+def cfg_fftgs_generic(a, gss, _lib):
+    """FFTGS on grids outside the power-of-two 3-D pipeline -- the reference's own test grids are 100 x 100
+    (test/simulation/fft.jl:4,11,26) -- on the library's generic Stockham passes (sizes 2^a 3^b 5^c, fftgs_generic.h)
+    and, beside it, on the rocFFT pipeline of the same library (GSS_FFTGS_PATH=rocfft, read at handle creation)."""
+    from gss.engine import FFTGSHandle
+    rows = []
+    shapes = ((100, 100), (1000, 1000), (200, 200, 200), (300, 300, 300)) if a.quick else \
+        ((100, 100), (1000, 1000), (4096, 1024), (200, 200, 200), (300, 300, 300), (500, 500, 500))
+    for dims in shapes:
+        N = int(np.prod(dims))
+        R = 16 if N < 5e7 else 4
+        res = {}
+        for path in ("generic", "rocfft"):
+            if path == "rocfft":
+                os.environ["GSS_FFTGS_PATH"] = "rocfft"
+            else:
+                os.environ.pop("GSS_FFTGS_PATH", None)
+            vg = gss.ExponentialVariogram(range=dims[0] / 10.0)
+            FFTGSHandle(vg, dims).close()                      # plans / kernels of this size exist
+            sync(); t0 = time.perf_counter()
+            h = FFTGSHandle(vg, dims)
+            sync(); t1 = time.perf_counter()
+            out = torch.empty((R, N), dtype=torch.float64, device="cuda")
+            h.realize(1, 0, R, out=out)
+            sync(); t2 = time.perf_counter()
+            h.realize(1, 0, R, out=out)
+            sync(); t3 = time.perf_counter()
+            res[path] = dict(ms=(t3 - t2) / R * 1e3, create_ms=(t1 - t0) * 1e3, first=out[0].clone())
+            h.close()
+            del out
+        os.environ.pop("GSS_FFTGS_PATH", None)
+        g, r = res["generic"], res["rocfft"]
+        rows.append({"grid": "x".join(map(str, dims)), "ms_per_realisation": round(g["ms"], 4),
+                     "rocfft_pipeline_ms": round(r["ms"], 4), "speedup": round(r["ms"] / g["ms"], 2),
+                     "create_ms_warm": round(g["create_ms"], 2), "rocfft_create_ms_warm": round(r["create_ms"], 2),
+                     "max_abs_difference_between_the_two": float((g["first"] - r["first"]).abs().max()),
+                     "roofline": {"bound": "hbm", "achieved": round(32.0 * N / (g["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK,
+                                  "unit": "GB/s", "frac": round(32.0 * N / (g["ms"] * 1e-3) / 1e9 / HBM_PEAK, 4),
+                                  "algorithmic_bytes": 32.0 * N}})
+    return {"config": "FFTGS on 2-D grids and on sizes 2^a 3^b 5^c: the library's generic passes against its rocFFT pipeline",
+            "metric": "ms per realisation", "rows": rows}
+
+
 def cfg_bigk(a, gss, _lib):
     """Moving neighbourhoods with more than 64 neighbours (krig.jl:201-210, ui.jl:16-23 accept any count): UK degree 1,
     5 000 3-D data, Matern-3/2, k = 96 / 128 / 256.  One JSON object with a row per k."""
@@ -643,7 +686,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "api": cfg_api, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "api": cfg_api, "fftgs_gen": cfg_fftgs_generic, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 

@@ -17,6 +17,7 @@
 // the algorithmic floor is 32 N bytes.
 #include "gss_internal.h"
 #include "fftgs_fused.h"
+#include "fftgs_generic.h"
 
 #include <sys/stat.h>
 #include <cerrno>
@@ -204,6 +205,13 @@ struct gss_fftgs {
   DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
   int x_rows = 8;               // x lines per workgroup of the Stockham x passes (rows * M / 8 <= 256)
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes
+  // generic pipeline (2-D grids, sizes 2^a 3^b 5^c: fftgs_generic.h): Stockham plans per axis and their twiddle tables;
+  // the half-spectrum buffer is X, the amplitudes are read from the state in their natural layout
+  bool generic = false;
+  GenGrid gg;
+  GenPlan gp[3];
+  DevBuf gtab[3];
+  int g_rows = 1, g_txlog[3] = {3, 3, 3};
   // slab order of the strided passes: slab i runs on stream i mod ns (0 = the caller's, the others are helper streams
   // of the process, slab_stream()); the events that fence them belong to the handle
   static constexpr int SLAB_MAX_STREAMS = 4;
@@ -470,6 +478,160 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   return GSS_OK;
 }
 
+// ---- generic pipeline (fftgs_generic.h) ---------------------------------------------------------------------------------
+static bool gen_plan(int L, GenPlan* pl) {
+  std::memset(pl, 0, sizeof(*pl));
+  pl->L = L;
+  int n = L, np = 0;
+  while (n % 5 == 0) { pl->radix[np++] = 5; n /= 5; if (np >= GEN_MAX_PASSES - 4) break; }
+  while (n % 3 == 0 && np < GEN_MAX_PASSES - 4) { pl->radix[np++] = 3; n /= 3; }
+  int e = 0;
+  while (n % 2 == 0) { ++e; n /= 2; }
+  if (n != 1 || L < 2) return false;
+  while (e >= 3 && np < GEN_MAX_PASSES) { pl->radix[np++] = 8; e -= 3; }
+  if (e == 2 && np < GEN_MAX_PASSES) { pl->radix[np++] = 4; e = 0; }
+  if (e == 1 && np < GEN_MAX_PASSES) { pl->radix[np++] = 2; e = 0; }
+  if (e != 0) return false;
+  pl->npass = np;
+  int off = 0, Ns = 1;
+  for (int p = 0; p < np; ++p) {
+    pl->toff[p] = off;
+    off += (pl->radix[p] - 1) * Ns;
+    Ns *= pl->radix[p];
+  }
+  pl->tlen = off;
+  return Ns == L;
+}
+
+static int32_t gen_upload_table(DevBuf& buf, const GenPlan& pl, hipStream_t s) {
+  std::vector<double> t((size_t)2 * (pl.tlen > 0 ? pl.tlen : 1), 0.0);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  int Ns = 1;
+  for (int p = 0; p < pl.npass; ++p) {
+    const int R = pl.radix[p];
+    for (int r = 1; r < R; ++r)
+      for (int k = 0; k < Ns; ++k) {
+        const long double a = two_pi * (long double)r * (long double)k / ((long double)Ns * (long double)R);
+        const size_t e = (size_t)(pl.toff[p] + (r - 1) * Ns + k);
+        t[2 * e] = (double)cosl(a);
+        t[2 * e + 1] = (double)(-sinl(a));
+      }
+    Ns *= R;
+  }
+  GSS_TRY(buf.alloc(sizeof(double) * t.size()));
+  GSS_HIP(hipMemcpyAsync(buf.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s));
+  GSS_HIP(hipStreamSynchronize(s));
+  return GSS_OK;
+}
+
+static size_t gen_x_lds(const GenPlan& pl, int rows) { return sizeof(double2) * (size_t)(pl.L + pl.tlen + rows * pl.L); }
+static size_t gen_axis_lds(const GenPlan& pl, int txlog) { return sizeof(double2) * (size_t)(pl.tlen + (pl.L << txlog)); }
+
+// 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c: n1 even with n1 / 2 <= 2 048,
+// the other axes <= 1 024.  Everything else stays on rocFFT.
+static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
+  const char* e = std::getenv("GSS_FFTGS_PATH");
+  if (e && std::strcmp(e, "rocfft") == 0) return GSS_OK;
+  const GridSpec& g = h->g;
+  if (h->fused || h->ndim < 2 || (g.n1 & 1) || g.n1 / 2 > 2048 || g.n1 < 4 || g.n2 > 1024 || g.n3 > 1024) return GSS_OK;
+  GenPlan p1, p2, p3;
+  if (!gen_plan((int)(g.n1 / 2), &p1) || !gen_plan((int)g.n2, &p2)) return GSS_OK;
+  if (h->ndim == 3 && !gen_plan((int)g.n3, &p3)) return GSS_OK;
+  if (h->ndim == 2) std::memset(&p3, 0, sizeof(p3));
+  h->gp[0] = p1; h->gp[1] = p2; h->gp[2] = p3;
+  GenGrid& gg = h->gg;
+  gg.n1 = (int)g.n1; gg.n2 = (int)g.n2; gg.n3 = (int)g.n3;
+  gg.nh = (int)g.nh;
+  gg.nhp = (gg.nh + 7) / 8 * 8;
+  gg.ndim = h->ndim;
+  gg.c1 = (int)g.c1; gg.c2 = (int)g.c2; gg.c3 = (int)g.c3;
+  gg.s1 = g.s1; gg.s2 = g.s2; gg.s3 = g.s3;
+  h->g_rows = (int)(2048 / p1.L);
+  if (h->g_rows > 16) h->g_rows = 16;
+  if (h->g_rows < 1) h->g_rows = 1;
+  h->g_txlog[1] = p2.L <= 512 ? 3 : 2;
+  h->g_txlog[2] = (h->ndim == 3 && p3.L > 512) ? 2 : 3;
+  GSS_TRY(upload_twiddles(h->tw1, gg.n1, s));
+  GSS_TRY(gen_upload_table(h->gtab[0], p1, s));
+  GSS_TRY(gen_upload_table(h->gtab[1], p2, s));
+  if (h->ndim == 3) GSS_TRY(gen_upload_table(h->gtab[2], p3, s));
+  GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)gg.nhp * gg.n2 * gg.n3));
+  GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));   // the padding columns stay zero
+  const int lx = 104 * 1024;   // (one fixed bound for every handle: the attribute belongs to the function, not to the launch)
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_PHILOX>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_ARRAY>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_COV>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  const int la = 96 * 1024;
+#define GSS_GEN_ATTR(MODE, TXL) \
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_axis_kernel<MODE, TXL>), hipFuncAttributeMaxDynamicSharedMemorySize, la))
+  GSS_GEN_ATTR(0, 3); GSS_GEN_ATTR(1, 3); GSS_GEN_ATTR(2, 3); GSS_GEN_ATTR(0, 2); GSS_GEN_ATTR(1, 2); GSS_GEN_ATTR(2, 2);
+#undef GSS_GEN_ATTR
+  h->generic = true;
+  return GSS_OK;
+}
+
+template <int SRC>
+static void gen_launch_p1(gss_fftgs* h, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
+  const GenGrid& g = h->gg;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
+  hipLaunchKernelGGL((gen_x_fwd_kernel<SRC>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows), s, g, h->gp[0],
+                     h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
+}
+static void gen_launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
+  const GenGrid& g = h->gg;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
+  hipLaunchKernelGGL(gen_x_inv_kernel, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows), s, g, h->gp[0], h->g_rows,
+                     h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
+}
+// strided pass `MODE` along y (axis 1) or z (axis 2)
+template <int MODE>
+static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s) {
+  const GenGrid& g = h->gg;
+  const GenPlan& pl = h->gp[axis];
+  const int txlog = h->g_txlog[axis];
+  const int nouter = axis == 1 ? g.n3 : g.n2;
+  const int64_t ostride = axis == 1 ? (int64_t)g.n2 * g.nhp : (int64_t)g.nhp;
+  const int64_t lstride = axis == 1 ? (int64_t)g.nhp : (int64_t)g.n2 * g.nhp;
+  const unsigned blocks = (unsigned)(nouter * (g.nhp >> txlog));
+  const size_t lds = gen_axis_lds(pl, txlog);
+  if (txlog == 3)
+    hipLaunchKernelGGL((gen_axis_kernel<MODE, 3>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
+                       ostride, lstride, h->X.as<double2>(), h->Fh(), h->mean);
+  else
+    hipLaunchKernelGGL((gen_axis_kernel<MODE, 2>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
+                       ostride, lstride, h->X.as<double2>(), h->Fh(), h->mean);
+}
+
+// fft.jl:96-103 on the generic passes
+static int32_t fftgs_spectrum_generic(gss_fftgs* h, double* partial, hipStream_t s) {
+  gen_launch_p1<FF_SRC_COV>(h, 0, 0, nullptr, s);
+  gen_launch_axis<0>(h, 1, s);
+  if (h->ndim == 3) gen_launch_axis<0>(h, 2, s);
+  hipLaunchKernelGGL(gen_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->gg, h->X.as<double2>(), h->Fh(), partial);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
+// one realisation (fft.jl:163-170): five passes on 3-D grids, three on 2-D grids
+static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z, hipStream_t s) {
+  ProfScope ps("fftgs_generic", s);
+  if (noise) gen_launch_p1<FF_SRC_ARRAY>(h, seed, (uint32_t)real, noise, s);
+  else gen_launch_p1<FF_SRC_PHILOX>(h, seed, (uint32_t)real, nullptr, s);
+  if (h->ndim == 3) {
+    gen_launch_axis<0>(h, 1, s);
+    gen_launch_axis<2>(h, 2, s);
+    gen_launch_axis<1>(h, 1, s);
+  } else {
+    gen_launch_axis<2>(h, 1, s);
+  }
+  gen_launch_p5(h, z, s);
+  GSS_HIP(hipGetLastError());
+  return GSS_OK;
+}
+
 // launches of the forward passes shared by the realisations and the spectrum build
 template <int SRC>
 static void launch_p1_src(gss_fftgs* h, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
@@ -690,6 +852,7 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
 
   GSS_TRY(h->state.alloc(sizeof(double) * (size_t)(h->NH + 2)));
   GSS_TRY(fftgs_setup_fused(h, s));  // decides the pipeline; allocates its buffers (no rocFFT plan on that path)
+  GSS_TRY(fftgs_setup_generic(h, s));
   if (flags & GSS_FFTGS_NO_SPECTRUM) {  // the state arrives by broadcast (gss_fftgs_adopt_state)
     GSS_HIP(hipStreamSynchronize(s));
     guard.h = nullptr;
@@ -702,6 +865,8 @@ int32_t gss_fftgs_create(gss_fftgs_t** out, const gss_variogram_t* vg, int32_t n
   GSS_TRY(partial.alloc(sizeof(double) * RED_BLOCKS));
   if (h->fused) {
     GSS_TRY(fftgs_spectrum_fused(h, partial.as<double>(), s));
+  } else if (h->generic) {
+    GSS_TRY(fftgs_spectrum_generic(h, partial.as<double>(), s));
   } else {
     GSS_TRY(ensure_rocfft(h));
     hipLaunchKernelGGL(fftgs_cov_kernel, dim3(grid_blocks(h->N)), dim3(256), 0, s, h->vg, h->g, h->U.as<double>());
@@ -761,7 +926,7 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
   GSS_REQUIRE(h->ready, "handle has no spectrum");
   if (nreals == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
-  if (!h->fused) GSS_TRY(ensure_rocfft(h));
+  if (!h->fused && !h->generic) GSS_TRY(ensure_rocfft(h));
   const int64_t N = h->N;
   const int64_t npts = inds ? ninds : N;
   // Host arrays: the realisations leave chunk by chunk through a ring of at most three chunks (OutStream: the
@@ -811,6 +976,17 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
         GSS_TRY(fftgs_fused_p1(h, seed, first_real + r, nz, s));
         GSS_TRY(fftgs_fused_rest(h, zf, s));
       }
+      if (inds) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
+                           ninds, dst);
+        GSS_HIP(hipGetLastError());
+      }
+      GSS_TRY(os.done(r, s));
+      continue;
+    }
+    if (h->generic) {
+      double* zf = inds ? h->Z.as<double>() : dst;
+      GSS_TRY(fftgs_generic_realize(h, seed, first_real + r, nz, zf, s));
       if (inds) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
                            ninds, dst);

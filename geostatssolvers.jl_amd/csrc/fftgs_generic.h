@@ -1,0 +1,330 @@
+// FFTGS on the library's own passes for grids the power-of-two pipeline (fftgs_fused.h) does not take: 2-D grids and
+// 3-D grids whose sizes are products of 2, 3 and 5 -- the reference's own test grids are 100 x 100
+// (/root/reference/test/simulation/fft.jl:4,11,26), and 200^3 / 300^3 / 500^3 are the round numbers users pick.
+//
+// Same mathematics and the same pass structure as the fused pipeline (fft.jl:96-103 for the spectrum, :163-170 for a
+// realisation):
+//   GP1  x lines : noise (Philox in registers / supplied) or covariance rows -> packed half-length complex FFT ->
+//                  real-FFT post-processing -> half spectrum                               (8N B written)
+//   GP2  y lines : forward, tiles of TX columns (3-D only)                                 (8N r + 8N w)
+//   GP3  last axis (z, or y of a 2-D grid): forward -> phase X <- Fh X / |X| -> inverse    (8N + 4N r, 8N w)
+//   GP4  y lines : inverse (3-D only)
+//   GP5  x lines : real-inverse pre-processing -> half-length inverse FFT -> realisation   (8N r + 8N w)
+// i.e. five passes (three on 2-D grids) against the eight full-volume passes of noise kernel + rocFFT R2C + phase kernel
+// + rocFFT C2R.  What differs from the power-of-two passes is the transform inside a pass: Stockham autosort passes of
+// radix 2, 3, 4, 5 or 8 chosen at run time from the factorisation of the line length, natural order in and out on every
+// axis (so the amplitudes Fh are read in their natural layout -- the state buffer of the handle -- and no permuted copy
+// exists), every pass in place in LDS with the items of a thread held in registers between the read and the write of
+// the tile.  A line is at most 2 048 complex elements (x: n1 / 2) or 1 024 (y, z); everything else stays on rocFFT.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fftgs_fused.h"
+#include "gss_internal.h"
+#include "philox.h"
+
+namespace gss {
+
+constexpr int GEN_MAX_PASSES = 12;
+struct GenPlan {          // one axis: radices of the Stockham passes and where each pass's twiddles start in its table
+  int L;                  // line length (x: n1 / 2)
+  int npass;
+  int radix[GEN_MAX_PASSES];
+  int toff[GEN_MAX_PASSES];
+  int tlen;               // complex entries of the table: sum over the passes of (R - 1) * Ns
+};
+struct GenGrid {
+  int n1, n2, n3;         // n1 fastest; n3 = 1 on 2-D grids
+  int nh, nhp;            // n1 / 2 + 1 and the row pitch of the half-spectrum buffer (a multiple of 8)
+  int ndim;
+  int c1, c2, c3;         // centre cell (covariance source)
+  double s1, s2, s3;
+};
+
+// ---- in-register DFTs ------------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void g_dft3(double2 (&v)[3]) {
+  const double s = 0.86602540378443864676;   // sin(2 pi / 3)
+  const double2 t1 = make_double2(v[1].x + v[2].x, v[1].y + v[2].y);
+  const double2 t2 = make_double2(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
+  const double2 d = make_double2((v[1].x - v[2].x) * s, (v[1].y - v[2].y) * s);
+  const double2 r = mul_mi<INV>(d);          // forward: -i d, inverse: +i d
+  v[0] = make_double2(v[0].x + t1.x, v[0].y + t1.y);
+  v[1] = make_double2(t2.x + r.x, t2.y + r.y);
+  v[2] = make_double2(t2.x - r.x, t2.y - r.y);
+}
+template <bool INV>
+__device__ __forceinline__ void g_dft5(double2 (&v)[5]) {
+  const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi / 5), cos(4 pi / 5)
+  const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi / 5), sin(4 pi / 5)
+  const double2 t1 = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), t2 = make_double2(v[2].x + v[3].x, v[2].y + v[3].y);
+  const double2 t3 = make_double2(v[1].x - v[4].x, v[1].y - v[4].y), t4 = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
+  const double2 a1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+  const double2 a2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+  const double2 b1 = mul_mi<INV>(make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+  const double2 b2 = mul_mi<INV>(make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+  v[0] = make_double2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+  v[1] = make_double2(a1.x + b1.x, a1.y + b1.y);
+  v[4] = make_double2(a1.x - b1.x, a1.y - b1.y);
+  v[2] = make_double2(a2.x + b2.x, a2.y + b2.y);
+  v[3] = make_double2(a2.x - b2.x, a2.y - b2.y);
+}
+template <int R, bool INV>
+__device__ __forceinline__ void g_dft(double2 (&v)[R]) {
+  if constexpr (R == 2) x_dft<1, INV>(v);
+  else if constexpr (R == 4) x_dft<2, INV>(v);
+  else if constexpr (R == 8) x_dft<3, INV>(v);
+  else if constexpr (R == 3) g_dft3<INV>(v);
+  else g_dft5<INV>(v);
+}
+
+// One Stockham pass of radix R over `nlines` lines of length L, in place: element n of line l at
+// buf[l * lstr + n * nstr].  Item (l, jj), jj < L / R: inputs n = jj + r L / R, twiddles T[(r - 1) Ns + jj mod Ns]
+// (conjugated for the inverse), outputs n = (jj div Ns) Ns R + jj mod Ns + r Ns.  A thread keeps its items (at most
+// MAXI: the tile holds at most 4 096 elements for 512 threads, 2 048 for 256) in registers across the barrier that
+// separates the reads of the tile from its writes.
+template <int R, bool INV, int NT>
+__device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int nstr, int L, const double2* T, int Ns, int tid) {
+  constexpr int MAXI = (8 + R - 1) / R;      // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256))
+  const int LR = L / R;
+  const int nitems = nlines * LR;
+  double2 v[MAXI][R];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int it = tid + i * NT;
+    if (it < nitems) {
+      const int l = it % nlines, jj = it / nlines;
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[i][r] = buf[l * lstr + (jj + r * LR) * nstr];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int it = tid + i * NT;
+    if (it < nitems) {
+      const int l = it % nlines, jj = it / nlines;
+      const int k = jj % Ns;
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        double2 w = T[(r - 1) * Ns + k];
+        if (INV) w.y = -w.y;
+        v[i][r] = cmul(v[i][r], w);
+      }
+      g_dft<R, INV>(v[i]);
+      const int j0 = (jj - k) * R + k;
+#pragma unroll
+      for (int r = 0; r < R; ++r) buf[l * lstr + (j0 + r * Ns) * nstr] = v[i][r];
+    }
+  }
+  __syncthreads();
+}
+
+template <bool INV, int NT>
+__device__ __forceinline__ void g_transform(double2* buf, int nlines, int lstr, int nstr, const GenPlan& pl, const double2* T,
+                                            int tid) {
+  int Ns = 1;
+  for (int p = 0; p < pl.npass; ++p) {
+    const int R = pl.radix[p];
+    const double2* Tp = T + pl.toff[p];
+    switch (R) {
+      case 2: g_pass<2, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+      case 3: g_pass<3, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+      case 4: g_pass<4, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+      case 5: g_pass<5, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+      default: g_pass<8, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+    }
+    Ns *= R;
+  }
+}
+
+constexpr int GEN_XNT = 256;     // x passes: rows * M <= 2 048
+constexpr int GEN_ANT = 512;     // strided passes: TX * L <= 4 096
+
+// ---- GP1.  LDS: tw[M] | T[tlen] | buf[rows * M] ------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
+                                                            const double2* __restrict__ xtw, uint64_t seed, uint32_t real,
+                                                            const double* __restrict__ noise, double2* __restrict__ X,
+                                                            VgDev vg) {
+  extern __shared__ __attribute__((aligned(16))) double2 gsm[];
+  const int M = pl.L;
+  double2* tw = gsm;
+  double2* T = gsm + M;
+  double2* buf = T + pl.tlen;
+  const int tid = threadIdx.x;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const int64_t row0 = (int64_t)blockIdx.x * rows;
+  for (int k = tid; k < M; k += GEN_XNT) tw[k] = tw1[k];
+  for (int k = tid; k < pl.tlen; k += GEN_XNT) T[k] = xtw[k];
+  for (int e = tid; e < rows * M; e += GEN_XNT) {
+    const int row = e / M, n = e - row * M;
+    const int64_t grow = row0 + row;
+    double2 x = make_double2(0.0, 0.0);
+    if (grow < nrows) {
+      const int64_t blk = grow * M + n;   // elements 2 blk, 2 blk + 1 of the realisation
+      if (SRC == FF_SRC_ARRAY) {
+        x = reinterpret_cast<const double2*>(noise)[blk];
+      } else if (SRC == FF_SRC_COV) {
+        const int i2 = (int)(grow % g.n2), i3 = (int)(grow / g.n2);
+        const double zero[3] = {0.0, 0.0, 0.0};
+        double a[3] = {(double)(2 * n - g.c1) * g.s1, (double)(i2 - g.c2) * g.s2, (double)(i3 - g.c3) * g.s3};
+        x.x = cov_pair<3>(vg, a, zero);
+        a[0] = (double)(2 * n + 1 - g.c1) * g.s1;
+        x.y = cov_pair<3>(vg, a, zero);
+      } else {
+        philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)blk, x.x, x.y);
+      }
+    }
+    buf[e] = x;
+  }
+  __syncthreads();
+  g_transform<false, GEN_XNT>(buf, rows, M, 1, pl, T, tid);
+  // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2 for k = 0 .. M, the pair (k, M - k) together
+  const int half = M / 2;
+  for (int t = tid; t < rows * (half + 1); t += GEN_XNT) {
+    const int row = t / (half + 1), k = t - row * (half + 1);
+    const int64_t grow = row0 + row;
+    if (grow >= nrows) continue;
+    const double2* z = buf + row * M;
+    const double2 a = z[k];
+    const double2 b = cconj(z[k == 0 ? 0 : M - k]);
+    const double2 w = tw[k];
+    const double2 sm2 = make_double2(a.x + b.x, a.y + b.y);
+    const double2 pp = cmul(make_double2(a.x - b.x, a.y - b.y), w);
+    double2* xr = X + grow * g.nhp;
+    xr[k] = make_double2(0.5 * (sm2.x + pp.y), 0.5 * (sm2.y - pp.x));
+    if (k != M - k) xr[M - k] = make_double2(0.5 * (sm2.x - pp.y), 0.5 * (-sm2.y - pp.x));
+  }
+}
+
+// ---- GP5.  LDS: tw[M] | T[tlen] | buf[rows * M] ------------------------------------------------------------------------
+__global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
+                                                            const double2* __restrict__ xtw, const double2* __restrict__ X,
+                                                            double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double2 gsm[];
+  const int M = pl.L;
+  double2* tw = gsm;
+  double2* T = gsm + M;
+  double2* buf = T + pl.tlen;
+  const int tid = threadIdx.x;
+  const int64_t nrows = (int64_t)g.n2 * g.n3;
+  const int64_t row0 = (int64_t)blockIdx.x * rows;
+  for (int k = tid; k < M; k += GEN_XNT) tw[k] = tw1[k];
+  for (int k = tid; k < pl.tlen; k += GEN_XNT) T[k] = xtw[k];
+  __syncthreads();
+  // Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})), k = 0 .. M - 1
+  for (int e = tid; e < rows * M; e += GEN_XNT) {
+    const int row = e / M, k = e - row * M;
+    const int64_t grow = row0 + row;
+    double2 v = make_double2(0.0, 0.0);
+    if (grow < nrows) {
+      const double2* xr = X + grow * g.nhp;
+      const double2 a = xr[k];
+      const double2 bb = cconj(xr[M - k]);
+      const double2 d = cmul(make_double2(a.x - bb.x, a.y - bb.y), cconj(tw[k]));   // i * d = (-d.y, d.x)
+      v = make_double2(a.x + bb.x - d.y, a.y + bb.y + d.x);
+    }
+    buf[e] = v;
+  }
+  __syncthreads();
+  g_transform<true, GEN_XNT>(buf, rows, M, 1, pl, T, tid);
+  double2* o2 = reinterpret_cast<double2*>(out);
+  for (int e = tid; e < rows * M; e += GEN_XNT) {
+    const int row = e / M, n = e - row * M;
+    const int64_t grow = row0 + row;
+    if (grow < nrows) o2[grow * M + n] = buf[e];
+  }
+}
+
+// ---- strided passes.  MODE 0: forward, 1: inverse, 2: forward, phase with Fh, inverse.  Tile (o, t): TX columns
+// t TX .. of line o of the axis; element j of the line at X + o * ostride + j * lstride.  LDS: T[tlen] | buf[L * TX],
+// element (j, c) at j * TX + c.
+template <int MODE, int TXLOG>
+__global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl, int axis, const double2* __restrict__ atw,
+                                                           int64_t ostride, int64_t lstride, double2* __restrict__ X,
+                                                           const double* __restrict__ Fh, double mean) {
+  extern __shared__ __attribute__((aligned(16))) double2 gsm[];
+  constexpr int TX = 1 << TXLOG;
+  const int L = pl.L;
+  double2* T = gsm;
+  double2* buf = gsm + pl.tlen;
+  const int tid = threadIdx.x;
+  const int ntx = g.nhp >> TXLOG;
+  const int t = blockIdx.x % ntx, o = blockIdx.x / ntx;
+  double2* gbase = X + (int64_t)o * ostride + (int64_t)t * TX;
+  for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
+  for (int e = tid; e < L * TX; e += GEN_ANT) {
+    const int c = e & (TX - 1), j = e >> TXLOG;
+    buf[e] = gbase[(int64_t)j * lstride + c];
+  }
+  __syncthreads();
+  if (MODE == 1) {
+    g_transform<true, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+  } else {
+    g_transform<false, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+    if (MODE == 2) {
+      // fft.jl:163: P = F exp(i angle(X)); the amplitudes in their natural layout Fh[(kz n2 + ky) nh + kx]
+      for (int e = tid; e < L * TX; e += GEN_ANT) {
+        const int c = e & (TX - 1), j = e >> TXLOG;
+        const int kx = t * TX + c;
+        if (kx < g.nh) {
+          const int ky = axis == 1 ? j : o, kz = axis == 1 ? 0 : j;
+          const double f = Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx];
+          const double2 x = buf[e];
+          const double mag2 = x.x * x.x + x.y * x.y;
+          double2 pz;
+          if (mag2 > 0.0) {
+            double y = __builtin_amdgcn_rsq(mag2);
+            double er = fma(-(mag2 * y), y, 1.0);
+            y = fma(0.5 * y, er, y);
+            er = fma(-(mag2 * y), y, 1.0);
+            y = fma(0.5 * y, er, y);
+            const double inv = f * y;
+            pz = make_double2(x.x * inv, x.y * inv);
+          } else {
+            pz = make_double2(f, 0.0);   // angle(0) = 0
+          }
+          if (kx == 0 && ky == 0 && kz == 0) pz = make_double2(mean, 0.0);   // DC <- mean
+          buf[e] = pz;
+        }
+      }
+      __syncthreads();
+      g_transform<true, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+    }
+  }
+  for (int e = tid; e < L * TX; e += GEN_ANT) {
+    const int c = e & (TX - 1), j = e >> TXLOG;
+    gbase[(int64_t)j * lstride + c] = buf[e];
+  }
+}
+
+// spectrum build: Fh[idx] = sqrt(|X|) from the padded buffer (natural order), DC = 0 (fft.jl:102-103); partial sums of
+// F^2 over the FULL spectrum as in fftgs_amp_kernel
+__global__ __launch_bounds__(256) void gen_amp_kernel(GenGrid g, const double2* __restrict__ X, double* __restrict__ Fh,
+                                                      double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int64_t NH = (int64_t)g.nh * g.n2 * g.n3;
+  double acc = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
+    const int kx = (int)(idx % g.nh);
+    const int64_t r = idx / g.nh;
+    const double2 x = X[r * g.nhp + kx];
+    double f = sqrt(sqrt(x.x * x.x + x.y * x.y));
+    if (idx == 0) f = 0.0;
+    Fh[idx] = f;
+    const bool self = (kx == 0) || (2 * kx == g.n1);
+    acc += (self ? 1.0 : 2.0) * f * f;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+}  // namespace gss

@@ -469,3 +469,69 @@ def test_config3_full_size_realisation_against_host_fft():
     err = float(np.max(np.abs(z - Z.ravel())))
     print("512^3 fused pipeline vs scipy.fft (complex-to-complex): max abs difference %.3e" % err)
     assert err < 1e-9
+
+
+# ---- generic pipeline (fftgs_generic.h): 2-D grids and sizes 2^a 3^b 5^c on the library's own Stockham passes ----------
+
+GENERIC_GRIDS = [(100, 100), (60, 50), (50, 64), (64, 64), (1000, 36), (36, 1000), (4096, 16), (250, 250),
+                 (48, 36, 30), (100, 100, 100), (20, 18, 10), (64, 48, 40), (30, 625, 8)]
+
+
+@pytest.mark.parametrize("dims", GENERIC_GRIDS)
+def test_generic_pipeline_matches_oracle_and_rocfft_path(dims, monkeypatch):
+    """Grids the power-of-two pipeline does not take but whose sizes factor into 2, 3 and 5 -- the reference's own test
+    grids are 100 x 100 (test/simulation/fft.jl:4,11,26) -- run on the library's own Stockham passes of radix 2 / 3 / 4 /
+    5 / 8 (three passes in 2-D, five in 3-D) instead of noise kernel + rocFFT R2C + phase kernel + rocFFT C2R.  Spectrum
+    1e-12 of max F, realisations from Philox and from supplied noise 1e-9 against the oracle; 1e-10 against the rocFFT
+    pipeline of the same library, which is a different code path (and must differ in the last bits)."""
+    from gss import _lib
+    N = int(np.prod(dims))
+    kw = dict(range=0.2 * dims[0], sill=1.4, nugget=0.05)
+    pre = O.preprocess(Variogram("exponential", **kw), dims, mean=0.3)
+    h = _handle("exponential", dims, mean=0.3, **kw)
+    F = h.spectrum()
+    assert F[0] == 0.0 and np.max(np.abs(F - pre.F.ravel())) < 1e-12 * pre.F.max()
+    _lib.profile_reset(); _lib.profile_enable(True)
+    z = h.realize(11, 2, 3)
+    _lib.profile_enable(False)
+    assert _lib.profile_read("fftgs_generic")[1] == 3, "the realisations did not run on the generic passes"
+    ref = O.realize(pre, 11, 2, 3)
+    assert np.max(np.abs(z - ref)) < 1e-9
+    noise = np.random.default_rng(N).uniform(size=(2, N))
+    zn = h.realize(0, 0, 2, noise=noise)
+    for r in range(2):
+        assert np.max(np.abs(zn[r] - O.solvesingle(pre, noise[r]))) < 1e-9
+    inds = np.arange(0, N, 7)
+    assert np.array_equal(h.realize(11, 2, 1, inds=inds)[0], z[0][inds])
+    h.close()
+    monkeypatch.setenv("GSS_FFTGS_PATH", "rocfft")
+    h2 = _handle("exponential", dims, mean=0.3, **kw)
+    z2 = h2.realize(11, 2, 3)
+    assert np.max(np.abs(z2 - z)) < 1e-10 and not np.array_equal(z2, z)
+    h2.close()
+
+
+def test_generic_pipeline_with_anisotropy_spacing_and_state_adoption():
+    """The reference's anisotropic case (`GaussianVariogram(MetricBall((20., 5.)))` on 100 x 100, test/simulation/fft.jl:
+    8-12) and a grid with unequal spacing on the generic passes (Gaussian model: 1e-6, module docstring), and a handle
+    that adopts another handle's state."""
+    import gss
+    from gss.engine import FFTGSHandle
+    dims = (100, 100)
+    h = _handle("gaussian", dims, radii=(20.0, 5.0))
+    pre = O.preprocess(Variogram("gaussian", radii=(20.0, 5.0)), dims)
+    assert np.max(np.abs(h.spectrum() - pre.F.ravel())) < 1e-6 * np.max(pre.F)
+    assert np.max(np.abs(h.realize(2022, 0, 3) - O.realize(pre, 2022, 0, 3))) < 1e-6
+    h.close()
+    dims = (60, 45, 20)
+    kw = dict(range=9.0, sill=2.0, nugget=0.1)
+    a = _handle("spherical", dims, (1.0, 2.0, 0.5), mean=-0.5, **kw)
+    pre = O.preprocess(Variogram("spherical", **kw), dims, spacing=(1.0, 2.0, 0.5), mean=-0.5)
+    za = a.realize(5, 0, 2)
+    assert np.max(np.abs(za - O.realize(pre, 5, 0, 2))) < 1e-9
+    b = FFTGSHandle(gss.SphericalVariogram(**kw), dims, (1.0, 2.0, 0.5), -0.5, spectrum=False)
+    b.state_tensor().copy_(a.state_tensor())
+    b.adopt_state()
+    assert np.array_equal(b.realize(5, 0, 2), za)
+    a.close()
+    b.close()

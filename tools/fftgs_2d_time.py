@@ -1,11 +1,13 @@
-"""FFTGS on 2-D grids (rocFFT pipeline): ms per realisation.  python3 tools/fftgs_2d_time.py"""
+"""FFTGS on grids outside the power-of-two 3-D pipeline: ms per realisation on the library's own generic passes (sizes
+2^a 3^b 5^c: fftgs_generic.h) or on rocFFT (GSS_FFTGS_PATH=rocfft, and every other size).
+python3 tools/fftgs_2d_time.py; GSS_FFTGS_PATH=rocfft python3 tools/fftgs_2d_time.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")]
 import numpy as np, torch, gss
 from gss.engine import FFTGSHandle
-for dims in ((1024, 1024), (2048, 2048), (4096, 4096), (1000, 1000), (100, 100), (256, 256, 256), (200, 200, 200),
-             (500, 500, 500), (300, 300, 100), (512, 512, 512)):
+for dims in ((100, 100), (1000, 1000), (1024, 1024), (4096, 1024), (2048, 2048), (4096, 4096), (200, 200, 200),
+             (300, 300, 100), (300, 300, 300), (500, 500, 500), (256, 256, 256), (512, 512, 512)):
     vg = gss.ExponentialVariogram(range=dims[0] / 10.0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h = FFTGSHandle(vg, dims)
