@@ -557,6 +557,7 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   if (h->ndim == 3) GSS_TRY(gen_upload_table(h->gtab[2], p3, s));
   GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)gg.nhp * gg.n2 * gg.n3));
   GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));   // the padding columns stay zero
+  GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)gg.nhp * gg.n2 * gg.n3));   // amplitudes in the last pass's tile order
   const int lx = 104 * 1024;   // (one fixed bound for every handle: the attribute belongs to the function, not to the launch)
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_PHILOX>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_ARRAY>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
@@ -599,10 +600,10 @@ static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s) {
   const size_t lds = gen_axis_lds(pl, txlog);
   if (txlog == 3)
     hipLaunchKernelGGL((gen_axis_kernel<MODE, 3>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh(), h->mean);
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
   else
     hipLaunchKernelGGL((gen_axis_kernel<MODE, 2>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh(), h->mean);
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
 }
 
 // fft.jl:96-103 on the generic passes
@@ -712,6 +713,17 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
       hipLaunchKernelGGL(ff_tile_fh2_kernel<3>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
     else
       hipLaunchKernelGGL(ff_tile_fh2_kernel<2>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
+    GSS_HIP(hipGetLastError());
+  }
+  if (h->generic) {
+    const int axis = h->ndim == 3 ? 2 : 1;
+    const int64_t nt = (int64_t)h->gg.nhp * h->gg.n2 * h->gg.n3;
+    if (h->g_txlog[axis] == 3)
+      hipLaunchKernelGGL(gen_tile_fh_kernel<3>, dim3(grid_blocks(nt)), dim3(256), 0, s, h->gg, axis, h->gp[axis].L, h->Fh(),
+                         h->Fh_tiled.as<double>());
+    else
+      hipLaunchKernelGGL(gen_tile_fh_kernel<2>, dim3(grid_blocks(nt)), dim3(256), 0, s, h->gg, axis, h->gp[axis].L, h->Fh(),
+                         h->Fh_tiled.as<double>());
     GSS_HIP(hipGetLastError());
   }
   h->ready = true;

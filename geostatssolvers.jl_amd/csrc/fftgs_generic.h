@@ -85,17 +85,24 @@ __device__ __forceinline__ void g_dft(double2 (&v)[R]) {
 // (conjugated for the inverse), outputs n = (jj div Ns) Ns R + jj mod Ns + r Ns.  A thread keeps its items (at most
 // MAXI: the tile holds at most 4 096 elements for 512 threads, 2 048 for 256) in registers across the barrier that
 // separates the reads of the tile from its writes.
+// a / b for 0 <= a < 4 096, 1 <= b <= 2 048 without an integer division (~25 instructions, three per item, next to a
+// butterfly of ~40): (a + 1/2) / b stays at least 1 / (2 b) away from every integer, far more than single precision can
+// be off, so the truncation is exact -- checked exhaustively over that whole range on the host
+// (tests/test_oracle_kat.py::test_float_division_trick_of_the_generic_fft_passes).
+__device__ __forceinline__ int g_div(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }
+
 template <int R, bool INV, int NT>
 __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int nstr, int L, const double2* T, int Ns, int tid) {
   constexpr int MAXI = (8 + R - 1) / R;      // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256))
   const int LR = L / R;
   const int nitems = nlines * LR;
+  const float inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns;
   double2 v[MAXI][R];
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int it = tid + i * NT;
     if (it < nitems) {
-      const int l = it % nlines, jj = it / nlines;
+      const int jj = g_div(it, inv_nl), l = it - jj * nlines;
 #pragma unroll
       for (int r = 0; r < R; ++r) v[i][r] = buf[l * lstr + (jj + r * LR) * nstr];
     }
@@ -105,8 +112,8 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int n
   for (int i = 0; i < MAXI; ++i) {
     const int it = tid + i * NT;
     if (it < nitems) {
-      const int l = it % nlines, jj = it / nlines;
-      const int k = jj % Ns;
+      const int jj = g_div(it, inv_nl), l = it - jj * nlines;
+      const int k = jj - g_div(jj, inv_ns) * Ns;
 #pragma unroll
       for (int r = 1; r < R; ++r) {
         double2 w = T[(r - 1) * Ns + k];
@@ -266,13 +273,15 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   } else {
     g_transform<false, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
     if (MODE == 2) {
-      // fft.jl:163: P = F exp(i angle(X)); the amplitudes in their natural layout Fh[(kz n2 + ky) nh + kx]
+      // fft.jl:163: P = F exp(i angle(X)); the amplitudes in the order of the tile's elements (gen_tile_fh_kernel):
+      // one contiguous, aligned run of L * TX doubles per workgroup
+      const double* fh = Fh + (int64_t)blockIdx.x * ((int64_t)L << TXLOG);
       for (int e = tid; e < L * TX; e += GEN_ANT) {
         const int c = e & (TX - 1), j = e >> TXLOG;
         const int kx = t * TX + c;
         if (kx < g.nh) {
           const int ky = axis == 1 ? j : o, kz = axis == 1 ? 0 : j;
-          const double f = Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx];
+          const double f = fh[e];
           const double2 x = buf[e];
           const double mag2 = x.x * x.x + x.y * x.y;
           double2 pz;
@@ -298,6 +307,28 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   for (int e = tid; e < L * TX; e += GEN_ANT) {
     const int c = e & (TX - 1), j = e >> TXLOG;
     gbase[(int64_t)j * lstride + c] = buf[e];
+  }
+}
+
+// Fh (natural layout, the handle's state) -> the order in which the workgroups of the last-axis pass read it:
+// dst[(o * ntx + t) * L * TX + j * TX + c] = Fh[(kz n2 + ky) nh + kx], kx = t TX + c (0 beyond nh), (ky, kz) = (j, 0) for
+// the y axis of a 2-D grid and (o, j) for the z axis
+template <int TXLOG>
+__global__ __launch_bounds__(256) void gen_tile_fh_kernel(GenGrid g, int axis, int L, const double* __restrict__ Fh,
+                                                          double* __restrict__ dst) {
+  constexpr int TX = 1 << TXLOG;
+  const int ntx = g.nhp >> TXLOG;
+  const int nouter = axis == 1 ? g.n3 : g.n2;
+  const int64_t per_tile = (int64_t)L << TXLOG;
+  const int64_t total = (int64_t)nouter * ntx * per_tile;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t tile = e / per_tile;
+    const int w = (int)(e - tile * per_tile);
+    const int c = w & (TX - 1), j = w >> TXLOG;
+    const int t = (int)(tile % ntx), o = (int)(tile / ntx);
+    const int kx = t * TX + c;
+    const int ky = axis == 1 ? j : o, kz = axis == 1 ? 0 : j;
+    dst[e] = kx < g.nh ? Fh[((int64_t)kz * g.n2 + ky) * g.nh + kx] : 0.0;
   }
 }
 

@@ -225,3 +225,14 @@ def test_block_support_kats():
         mu_0, var_0 = K.exactsolve(variant, vg, x, z, cent, **kw)
         tol = 1e-5 if vg.nugget == 0 else np.inf     # with a nugget C(V, V) -> sill - nugget, not sill: only the mean converges
         assert np.max(np.abs(mu_s - mu_0)) < 1e-6 and np.max(np.abs(var_s - var_0)) < tol   # (2)
+
+
+def test_float_division_trick_of_the_generic_fft_passes():
+    """csrc/fftgs_generic.h, `g_div`: a / b as trunc((a + 1/2) * (1 / b)) in single precision, for every operand pair a pass
+    can produce (items below 4 096, line counts and strides up to 2 048).  IEEE single precision on the host is what the
+    device computes (no fast-math): exhaustive."""
+    a = np.arange(0, 4096, dtype=np.int32)
+    for b in range(1, 2049):
+        inv = np.float32(1.0) / np.float32(b)
+        q = ((a.astype(np.float32) + np.float32(0.5)) * inv).astype(np.int32)
+        assert np.array_equal(q, a // b), b

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""A few FFTGS realisations on a grid of the generic pipeline (default 300^3) and nothing else: the workload of
+rocprofv3 kernel traces / PMC passes of fftgs_generic.h.  tools/fftgs_gen_one.py [n1 n2 [n3]] [realisations]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import gss  # noqa: E402
+from gss.engine import FFTGSHandle  # noqa: E402
+
+args = [int(a) for a in sys.argv[1:]]
+dims = tuple(args[:3]) if len(args) >= 3 else (300, 300, 300)
+n = args[3] if len(args) > 3 else 6
+f = FFTGSHandle(gss.ExponentialVariogram(range=dims[0] / 10.0), dims)
+N = 1
+for d in dims:
+    N *= d
+out = torch.empty((1, N), dtype=torch.float64, device="cuda")
+for r in range(n):
+    f.realize(4, r, 1, out=out)
+torch.cuda.synchronize()
+print("variance", float((out[0] * out[0]).sum() / (N - 1)))
+f.close()
