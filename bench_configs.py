@@ -306,7 +306,13 @@ def cfg_fftgs_generic(a, gss, _lib):
             "metric": "ms per realisation", "rows": rows}
 
 
-def cfg_bigk(a, gss, _lib):
+def cfg_hugek(a, gss, _lib):
+    """The functional path beyond 256 neighbours (`krig_local_big_kernel`: one workgroup per point, scalar root-free
+    Cholesky in LDS up to ~180 rows, in an HBM slab beyond) with its roofline, so that the path has a number: k = 300, 512."""
+    return cfg_bigk(a, gss, _lib, ks=(300, 512))
+
+
+def cfg_bigk(a, gss, _lib, ks=(96, 128, 256)):
     """Moving neighbourhoods with more than 64 neighbours (krig.jl:201-210, ui.jl:16-23 accept any count): UK degree 1,
     5 000 3-D data, Matern-3/2, k = 96 / 128 / 256.  One JSON object with a row per k."""
     from gss.engine import KrigHandle, UK
@@ -317,8 +323,9 @@ def cfg_bigk(a, gss, _lib):
     z = 1.0 + 0.03 * x[:, 0] - 0.02 * x[:, 1] + 0.01 * x[:, 2] + np.random.default_rng(60).normal(size=n)
     h = KrigHandle(gss.MaternVariogram(range=30.0, order=1.5), UK, x, z, degree=1, factor=False)
     rows = []
-    for k in (96, 128, 256):
-        m = (20_000 if a.quick else 200_000) if k <= 128 else (10_000 if a.quick else 100_000)
+    for k in ks:
+        m = (20_000 if a.quick else 200_000) if k <= 128 else ((10_000 if a.quick else 100_000) if k <= 256 else
+                                                               (2_000 if a.quick else 20_000))
         x0 = np.random.default_rng(7).uniform(0, 100, (m, 3))
         x0d = torch.as_tensor(x0, device="cuda")
         h.predict_knn(x0d[:2000], k)
@@ -686,7 +693,7 @@ def main():
     torch.cuda.set_device(0)
     import gss
     from gss import _lib
-    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "api": cfg_api, "fftgs_gen": cfg_fftgs_generic, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
+    fns = {"1h": cfg1_host, "2": cfg2_fftgs, "2h": cfg2_host, "3": cfg3_lugs, "4": cfg4_local, "4full": cfg4_full, "api": cfg_api, "hugek": cfg_hugek, "fftgs_gen": cfg_fftgs_generic, "idw": cfg_idw, "lwr": cfg_lwr, "sgs": cfg_sgs, "est_all": cfg_est_all, "cond_fftgs": cfg_cond_fftgs, "bigk": cfg_bigk, "lu": cfg_lu, "sgs_bigk": cfg_sgs_bigk}
     for c in a.configs.split(","):
         print(json.dumps(fns[c](a, gss, _lib)), flush=True)
 
