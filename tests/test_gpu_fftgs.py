@@ -474,7 +474,8 @@ def test_config3_full_size_realisation_against_host_fft():
 # ---- generic pipeline (fftgs_generic.h): 2-D grids and sizes 2^a 3^b 5^c on the library's own Stockham passes ----------
 
 GENERIC_GRIDS = [(100, 100), (60, 50), (50, 64), (64, 64), (1000, 36), (36, 1000), (4096, 16), (250, 250),
-                 (48, 36, 30), (100, 100, 100), (20, 18, 10), (64, 48, 40), (30, 625, 8)]
+                 (48, 36, 30), (100, 100, 100), (20, 18, 10), (64, 48, 40), (30, 625, 8),
+                 (4, 2), (6, 3), (8, 8, 8), (16, 16, 16), (4, 1024)]
 
 
 @pytest.mark.parametrize("dims", GENERIC_GRIDS)
