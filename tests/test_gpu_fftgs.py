@@ -442,12 +442,23 @@ def test_config3_full_size_realisation_against_two_other_implementations(monkeyp
     h2.close()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("GSS_TEST_HOST_512") != "1",
-                    reason="minutes of host FFTs and 20 GiB of host memory: opt in with GSS_TEST_HOST_512=1")
+def _host_can_do_512():
+    import os
+    if os.environ.get("GSS_TEST_HOST_512") == "0":
+        return False
+    try:
+        import psutil
+        return psutil.virtual_memory().available > 48 * 2 ** 30 and (os.cpu_count() or 1) >= 8
+    except Exception:                                   # noqa: BLE001
+        return os.environ.get("GSS_TEST_HOST_512") == "1"
+
+
+@pytest.mark.skipif(not _host_can_do_512(), reason="needs ~20 GiB of free host memory and a few cores for 512^3 host FFTs "
+                                                   "(GSS_TEST_HOST_512=0 switches it off)")
 def test_config3_full_size_realisation_against_host_fft():
     """configs[2] at full size against the host: fft.jl:163-170 through scipy's threaded pocketfft (complex-to-complex,
-    as the reference), the spectrum taken from the device handle (oracle-checked at 16 M cells above).  Run once per
-    round; the result is recorded in profiles/."""
+    as the reference), the spectrum taken from the device handle (oracle-checked at 16 M cells above).  A few seconds on
+    the GPU box's host cores (8.3e-14 in round 4, profiles/r04_fftgs_512_host_parity.txt)."""
     import os
     import scipy.fft
     import gss
