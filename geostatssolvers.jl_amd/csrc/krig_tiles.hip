@@ -12,8 +12,8 @@ int32_t krig_local_tiles_launch(const VgDev& vg, const LocalSpec& sp, int dim, c
                                 uint8_t* status, hipStream_t s) {
   GSS_REQUIRE(k > LMAX_K && k <= 256, "krig_local_tiles_launch: %d neighbours outside 65..256", k);
   TilesArgs a;
-  a.ntmax = k <= 128 ? 8 : 16;                 // 4 waves (three workgroups per CU) / 8 waves (one)
-  const int per_cu = a.ntmax == 8 ? 3 : 1;
+  a.ntmax = k <= 96 ? 6 : (k <= 128 ? 8 : 16);   // 3 waves (four workgroups per CU) / 4 waves (three) / 8 waves (one)
+  const int per_cu = a.ntmax == 6 ? 4 : (a.ntmax == 8 ? 3 : 1);
   a.blocks = (int64_t)256 * per_cu * 2;        // two rounds of resident workgroups, points handed out by stride
   if (a.blocks > m) a.blocks = m;
   a.s = s; a.vg = &vg; a.sp = &sp;

@@ -18,8 +18,9 @@ namespace gss {
 //      (the pivot row: at most NTMAX + 1 tiles, register images, conflict-free);
 //   3. every wave updates its own columns, A_ij -= U_Ki'U_Kj (operand -U_Ki from the pivot row), B_i -= U_Ki'Y_K.
 // Two workgroup barriers per step; nothing but the pivot row ever leaves the registers.  The Gram matrix Y'Y is summed
-// over the waves and wave 0 finishes as gram_finish does for the small kernel.  k <= 128: 4 waves (3 workgroups per
-// CU), k <= 192: 6 waves, k <= 256: 8 waves (one workgroup per CU).  Beyond 256 neighbours: krig_local_big_kernel.
+// over the waves and wave 0 finishes as gram_finish does for the small kernel.  k <= 96: 3 waves (round 4: with six tile
+// columns the fourth wave of the 128-neighbour instantiation owns nothing; 192 threads make four workgroups per CU),
+// k <= 128: 4 waves (3 workgroups per CU), k <= 256: 8 waves (one workgroup per CU).  Beyond 256: krig_local_big_kernel.
 // ---------------------------------------------------------------------------------------------
 template <int NTMAX>
 struct TilesLds {
@@ -36,7 +37,7 @@ struct TilesLds {
 };
 
 template <int DIM, int KIND, int NTMAX>
-__global__ __launch_bounds__(32 * NTMAX, NTMAX == 8 ? 3 : 2) void krig_local_tiles_kernel(
+__global__ __launch_bounds__(32 * NTMAX, NTMAX <= 8 ? 3 : 2) void krig_local_tiles_kernel(
     VgDev vg, LocalSpec sp, const double* __restrict__ xdata, const double* __restrict__ z,
     const double* __restrict__ drift_data, const double* __restrict__ x0, const double* __restrict__ drift_dom, int64_t m,
     int k, int minneighbors, const int* __restrict__ idx, const int* __restrict__ count, double* __restrict__ mean_out,
@@ -277,7 +278,8 @@ static int32_t tiles_launch_nt(int ntmax, int64_t blocks, hipStream_t s, const V
     hipLaunchKernelGGL((krig_local_tiles_kernel<DIM, KIND, NT>), dim3((unsigned)blocks), dim3(32 * NT), lds, s, vg,   \
                        sp, xdata, z, drift_data, x0, drift_dom, m, k, minneighbors, idx, count, mean, var, status);   \
   } while (0)
-  if (ntmax == 8) GSS_TILES_LAUNCH(8);
+  if (ntmax == 6) GSS_TILES_LAUNCH(6);
+  else if (ntmax == 8) GSS_TILES_LAUNCH(8);
   else GSS_TILES_LAUNCH(16);
 #undef GSS_TILES_LAUNCH
   GSS_HIP(hipGetLastError());
