@@ -307,9 +307,10 @@ def cfg_fftgs_generic(a, gss, _lib):
 
 
 def cfg_hugek(a, gss, _lib):
-    """The functional path beyond 256 neighbours (`krig_local_big_kernel`: one workgroup per point, scalar root-free
-    Cholesky in LDS up to ~180 rows, in an HBM slab beyond) with its roofline, so that the path has a number: k = 300, 512."""
-    return cfg_bigk(a, gss, _lib, ks=(300, 512))
+    """Beyond 256 neighbours: 257 .. 768 on `krig_local_slab_kernel` (round 4: the tile algorithm with the triangle in a
+    per-workgroup slab of global memory), 769 .. 4 096 on the functional `krig_local_big_kernel` (one workgroup per point,
+    unblocked root-free Cholesky through an HBM slab), each with its roofline: k = 300, 512, 768, 1 000."""
+    return cfg_bigk(a, gss, _lib, ks=(300, 512, 768, 1000))
 
 
 def cfg_bigk(a, gss, _lib, ks=(96, 128, 256)):
@@ -325,7 +326,7 @@ def cfg_bigk(a, gss, _lib, ks=(96, 128, 256)):
     rows = []
     for k in ks:
         m = (20_000 if a.quick else 200_000) if k <= 128 else ((10_000 if a.quick else 100_000) if k <= 256 else
-                                                               (2_000 if a.quick else 20_000))
+                                                               ((2_000 if a.quick else 20_000) if k <= 768 else 2_000))
         x0 = np.random.default_rng(7).uniform(0, 100, (m, 3))
         x0d = torch.as_tensor(x0, device="cuda")
         h.predict_knn(x0d[:2000], k)

@@ -124,4 +124,11 @@ int32_t krig_local_tiles_launch(const VgDev& vg, const LocalSpec& sp, int dim, c
                                 int minneighbors, const int* idx, const int* count, double* mean, double* var,
                                 uint8_t* status, hipStream_t s);
 
+// 257 .. 768 neighbours (krig_slab.hip): the same block algorithm with the tile triangle in a per-workgroup slab of global
+// memory (round 4).  Synchronises s before it returns (the slabs are scratch of the call).
+int32_t krig_local_slab_launch(const VgDev& vg, const LocalSpec& sp, int dim, const double* xdata, const double* z,
+                               const double* drift_data, const double* x0, const double* drift_dom, int64_t m, int k,
+                               int minneighbors, const int* idx, const int* count, double* mean, double* var,
+                               uint8_t* status, hipStream_t s);
+
 }  // namespace gss

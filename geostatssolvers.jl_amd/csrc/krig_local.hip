@@ -595,6 +595,13 @@ int32_t krig_local_dev(const VgDev& vg, int variant, int nc, int dim, const sign
       if (piped) GSS_TRY(pipe->deliver(off, mv, s));
       continue;
     }
+    if (big && k <= 768 && !std::getenv("GSS_KRIG_SLAB_OFF")) {
+      // 257 .. 768 neighbours: the tile algorithm with the triangle in a per-workgroup slab (krig_slab.hip)
+      GSS_TRY(krig_local_slab_launch(vg, sp, dim, xdata, z, drift_data, x0 + off * dim, dd, mv, k, minneighbors, idx, cnt,
+                                     mean + off, var + off, st, s));
+      if (piped) GSS_TRY(pipe->deliver(off, mv, s));
+      continue;
+    }
     if (big) {
       const int64_t rows = (int64_t)k + 2 + nc;
       const int64_t need = (int64_t)k * (k + 1) / 2 + (int64_t)(2 + nc) * k + k;

@@ -205,3 +205,50 @@ def test_block_support_in_moving_neighbourhoods_every_kernel():
     h.close()
     rmu, rvar, _ = K.approxsolve(K.OK, cases[1][1], x, z, x0, 12, support=(cell, nsub))
     assert np.max(np.abs(var_p - rvar)) > 1e-3
+
+
+@pytest.mark.parametrize("variant,deg,kind,vkw,dim,k", [
+    (K.UK, 1, "matern", dict(range=30.0, nu=1.5), 3, 512), (K.OK, None, "spherical", dict(range=40.0, nugget=0.05), 2, 700),
+    (K.SK, None, "exponential", dict(range=25.0), 3, 768), (K.OK, None, "gaussian", dict(range=8.0, nugget=0.3), 3, 300)])
+def test_slab_kernel_257_to_768_neighbours(variant, deg, kind, vkw, dim, k):
+    """257 .. 768 neighbours run the tile algorithm with the block triangle in a per-workgroup slab of global memory
+    (csrc/krig_slab.hip; round 4 -- until then the unblocked column sweep of krig_local_big_kernel, 25 x slower at 512).
+    Against the oracle, 1e-9 (1e-6 for the Gaussian model), estimation points at data locations included (C(0) = sill);
+    ragged neighbour counts under a ball; and the same call on the column sweep (GSS_KRIG_SLAB_OFF=1, read per call)."""
+    import os
+    import gss
+    from gss.engine import KrigHandle
+    ctor = dict(gaussian=gss.GaussianVariogram, exponential=gss.ExponentialVariogram, spherical=gss.SphericalVariogram,
+                matern=gss.MaternVariogram)[kind]
+    okw = dict(vkw)
+    gkw = dict(vkw)
+    if "nu" in gkw:
+        gkw["order"] = gkw.pop("nu")
+    gvg, ovg = ctor(**gkw), Variogram(kind, **okw)
+    rng = np.random.default_rng(k + dim)
+    n = 1600
+    x = rng.uniform(0, 100, (n, dim))
+    z = rng.normal(size=n) + 0.02 * x[:, 0]
+    x0 = np.concatenate([x[:5], rng.uniform(0, 100, (45, dim))])
+    tol = 1e-6 if kind == "gaussian" else 1e-9
+    h = KrigHandle(gvg, variant, x, z, mean=0.3 if variant == K.SK else None, degree=deg, factor=False)
+    mu, var, st = h.predict_knn(x0, k)[:3]
+    rmu, rvar, rst = K.approxsolve(variant, ovg, x, z, x0, k, mean=0.3 if variant == K.SK else 0.0, degree=deg)[:3]
+    assert np.array_equal(st, rst) and not st.any()
+    assert np.max(np.abs(mu - rmu)) < tol * max(1.0, np.max(np.abs(rmu))) and np.max(np.abs(var - rvar)) < tol
+    # a ball that leaves between 257 and k neighbours, and too few for some points
+    radius = 38.0 if dim == 3 else 30.0
+    mub, varb, stb = h.predict_knn(x0, k, minneighbors=280, radius=radius)[:3]
+    rb = K.approxsolve(variant, ovg, x, z, x0, k, minneighbors=280, radius=radius, mean=0.3 if variant == K.SK else 0.0,
+                       degree=deg)
+    assert np.array_equal(stb, rb[2])
+    okb = stb == 0
+    if okb.any():
+        assert np.max(np.abs(mub[okb] - rb[0][okb])) < tol * 10 and np.max(np.abs(varb[okb] - rb[1][okb])) < tol * 10
+    try:
+        os.environ["GSS_KRIG_SLAB_OFF"] = "1"
+        mu2, var2, st2 = h.predict_knn(x0, k)[:3]
+    finally:
+        os.environ.pop("GSS_KRIG_SLAB_OFF", None)
+    assert np.array_equal(st2, st) and np.max(np.abs(mu2 - mu)) < tol and np.max(np.abs(var2 - var)) < tol
+    h.close()
