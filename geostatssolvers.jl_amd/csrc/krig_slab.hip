@@ -28,15 +28,21 @@ namespace gss {
 constexpr int SLAB_KMAX = 768;
 constexpr int SLAB_NTMAX = SLAB_KMAX / 16;            // 48 tile columns: the pivot row is 98 KB of the CU's 160 KB of LDS
 constexpr int SLAB_W = 8;                             // waves per workgroup
+// LDS of a workgroup, sized by the launch's neighbour count (ntm = ceil(k / 16) tile columns)
 struct SlabLds {
-  static constexpr int NX = 0;                                   // KMAX x 3 neighbour coordinates
-  static constexpr int PV = NX + SLAB_KMAX * 3;                  // pivot row: NTMAX tiles + Y_K; before step 0 the staged
-  static constexpr int VS = PV + (SLAB_NTMAX + 1) * 256;         //   right-hand-side columns (LMAX_RHS x KMAX)
-  static constexpr int SS = VS + 256;                            // 16 x 17 scratch of the diagonal factorisation
-  static constexpr int GG = SS + 272;                            // 16 x 17 Gram matrix
-  static constexpr int GP = GG + 272;                            // W partial Gram tiles
-  static constexpr int DOUBLES = GP + SLAB_W * 256;
-  static_assert(LMAX_RHS * SLAB_KMAX <= (SLAB_NTMAX + 1) * 256, "right-hand-side staging does not fit the pivot row");
+  int NX, PV, VS, SS, GG, GP, DOUBLES, KROW;
+  __host__ __device__ explicit SlabLds(int ntm) {
+    KROW = 16 * ntm;                                       // stride of the staged right-hand-side columns
+    NX = 0;                                                // KROW x 3 neighbour coordinates
+    PV = NX + KROW * 3;                                    // pivot row: ntm tiles + Y_K; before step 0 the staged
+    int pv = (ntm + 1) * 256;                              //   right-hand-side columns (LMAX_RHS x KROW)
+    if (pv < LMAX_RHS * KROW) pv = LMAX_RHS * KROW;
+    VS = PV + pv;
+    SS = VS + 256;                                         // 16 x 17 scratch of the diagonal factorisation
+    GG = SS + 272;                                         // 16 x 17 Gram matrix
+    GP = GG + 272;                                         // W partial Gram tiles
+    DOUBLES = GP + SLAB_W * 256;
+  }
 };
 // tiles of a slab: the upper block triangle row by row, then the right-hand-side tiles
 __host__ __device__ inline int slab_tix(int i, int j, int nt) { return i * nt - (i * (i - 1)) / 2 + (j - i); }
@@ -49,15 +55,17 @@ __global__ __launch_bounds__(64 * SLAB_W) void krig_local_slab_kernel(
     int k, int minneighbors, const int* __restrict__ idx, const int* __restrict__ count, double* __restrict__ mean_out,
     double* __restrict__ var_out, uint8_t* __restrict__ status_out, double* __restrict__ slabs, int64_t slab_stride) {
 #ifndef GSS_HOST_SANITIZER_BUILD
-  using L = SlabLds;
-  constexpr int W = SLAB_W, KMAX = SLAB_KMAX;
+  constexpr int W = SLAB_W;
+  const int ntm = (k + 15) >> 4;                  // tile columns the launch is sized for
+  const SlabLds L(ntm);
+  const int KMAX = L.KROW;
   extern __shared__ double sl_sm[];
-  double* nx = sl_sm + L::NX;
-  double* P = sl_sm + L::PV;
-  double* Vs = sl_sm + L::VS;
-  double* S = sl_sm + L::SS;
-  double (*G)[17] = reinterpret_cast<double (*)[17]>(sl_sm + L::GG);
-  double* Gp = sl_sm + L::GP;
+  double* nx = sl_sm + L.NX;
+  double* P = sl_sm + L.PV;
+  double* Vs = sl_sm + L.VS;
+  double* S = sl_sm + L.SS;
+  double (*G)[17] = reinterpret_cast<double (*)[17]>(sl_sm + L.GG);
+  double* Gp = sl_sm + L.GP;
   __shared__ signed char se[LMAX_NC][4];
   __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(64 * SLAB_W) void krig_local_slab_kernel(
       if ((K + 1) % W == wave) {
         const d4_t B = tile_load(slab + (int64_t)(ntri + K) * 256, lane);
         const d4_t Y = xty(V, B, zero4);
-        tile_store(P + SLAB_NTMAX * 256, Y, lane);
+        tile_store(P + ntm * 256, Y, lane);
         Gt = xty(Y, Y, Gt);
       }
       __syncthreads();
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(64 * SLAB_W) void krig_local_slab_kernel(
         for (int ib = K + 1 + wave; ib < nt; ib += W) {   // right-hand-side tiles
           double* tp = slab + (int64_t)(ntri + ib) * 256;
           const d4_t B = tile_load(tp, lane);
-          tile_store(tp, xty(-tile_load(P + ib * 256, lane), tile_load(P + SLAB_NTMAX * 256, lane), B), lane);
+          tile_store(tp, xty(-tile_load(P + ib * 256, lane), tile_load(P + ntm * 256, lane), B), lane);
         }
       }
       __syncthreads();
@@ -267,9 +275,10 @@ static int32_t slab_launch(int64_t blocks, hipStream_t s, const VgDev& vg, const
                            const double* z, const double* drift_data, const double* x0, const double* drift_dom, int64_t m,
                            int k, int minneighbors, const int* idx, const int* count, double* mean, double* var,
                            uint8_t* status, double* scratch) {
-  const size_t lds = sizeof(double) * (size_t)SlabLds::DOUBLES;
+  const size_t lds = sizeof(double) * (size_t)SlabLds((k + 15) / 16).DOUBLES;
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(krig_local_slab_kernel<DIM, KIND>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * (size_t)SlabLds(SLAB_NTMAX).DOUBLES)));
   hipLaunchKernelGGL((krig_local_slab_kernel<DIM, KIND>), dim3((unsigned)blocks), dim3(64 * SLAB_W), lds, s, vg, sp, xdata, z,
                      drift_data, x0, drift_dom, m, k, minneighbors, idx, count, mean, var, status, scratch,
                      slab_doubles((k + 15) / 16));
@@ -282,7 +291,9 @@ int32_t krig_local_slab_launch(const VgDev& vg, const LocalSpec& sp, int dim, co
                                int minneighbors, const int* idx, const int* count, double* mean, double* var,
                                uint8_t* status, hipStream_t s) {
   GSS_REQUIRE(k > 256 && k <= SLAB_KMAX, "krig_local_slab_launch: %d neighbours outside 257..%d", k, SLAB_KMAX);
-  int64_t blocks = 256;   // one workgroup per CU (100 KB of LDS); points handed out by stride
+  // One workgroup per CU.  (LDS sized by k would let two share a CU up to ~370 neighbours, but the kernel needs ~230
+  // registers per lane; capped at 128 it spills 94 and ran 13-17 % slower with two workgroups per CU: measured, round 4.)
+  int64_t blocks = 256;
   if (blocks > m) blocks = m;
   DevBuf scratch;
   GSS_TRY(scratch.alloc(sizeof(double) * (size_t)(blocks * slab_doubles((k + 15) / 16))));
