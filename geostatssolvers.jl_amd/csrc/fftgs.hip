@@ -479,6 +479,7 @@ static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
 }
 
 // ---- generic pipeline (fftgs_generic.h) ---------------------------------------------------------------------------------
+static hipStream_t slab_stream(int i);   // helper streams of the slab order (defined with the fused pipeline below)
 static bool gen_plan(int L, GenPlan* pl) {
   std::memset(pl, 0, sizeof(*pl));
   pl->L = L;
@@ -589,21 +590,21 @@ static void gen_launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
 }
 // strided pass `MODE` along y (axis 1) or z (axis 2)
 template <int MODE>
-static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s) {
+static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 = 0, int slab_nt = 0) {
   const GenGrid& g = h->gg;
   const GenPlan& pl = h->gp[axis];
   const int txlog = h->g_txlog[axis];
   const int nouter = axis == 1 ? g.n3 : g.n2;
   const int64_t ostride = axis == 1 ? (int64_t)g.n2 * g.nhp : (int64_t)g.nhp;
   const int64_t lstride = axis == 1 ? (int64_t)g.nhp : (int64_t)g.n2 * g.nhp;
-  const unsigned blocks = (unsigned)(nouter * (g.nhp >> txlog));
+  const unsigned blocks = (unsigned)(nouter * (slab_nt > 0 ? slab_nt : (g.nhp >> txlog)));
   const size_t lds = gen_axis_lds(pl, txlog);
   if (txlog == 3)
     hipLaunchKernelGGL((gen_axis_kernel<MODE, 3>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt);
   else
     hipLaunchKernelGGL((gen_axis_kernel<MODE, 2>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt);
 }
 
 // fft.jl:96-103 on the generic passes
@@ -622,9 +623,51 @@ static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, 
   if (noise) gen_launch_p1<FF_SRC_ARRAY>(h, seed, (uint32_t)real, noise, s);
   else gen_launch_p1<FF_SRC_PHILOX>(h, seed, (uint32_t)real, nullptr, s);
   if (h->ndim == 3) {
-    gen_launch_axis<0>(h, 1, s);
-    gen_launch_axis<2>(h, 2, s);
-    gen_launch_axis<1>(h, 1, s);
+    // The slab order of the power-of-two pipeline (fftgs_fused_rest: the three strided passes slab by slab over the x
+    // tiles, slabs alternating over the caller's and the helper streams) is available here as an A/B switch only:
+    // measured (round 4, bit-identical fields) 500^3 2.96 ms with it against 2.79 without, 400^3 1.62 / 1.64 -- these
+    // passes are not bound by memory alone (GP3 is two transforms and the phase step per trip), so what the cache
+    // saves the extra launches give back.  GSS_FFTGS_GEN_SLAB=<tiles of the 512^3 measure per slab> switches it on.
+    static const int slab = env_int("GSS_FFTGS_GEN_SLAB", 0);
+    static const int slab_streams = env_int("GSS_FFTGS_SLAB_STREAMS", 3);
+    const GenGrid& g = h->gg;
+    const bool can_slab = slab > 0 && h->g_txlog[1] == 3 && h->g_txlog[2] == 3 && h->X.bytes > ((size_t)200 << 20);
+    if (can_slab) {
+      const int ntx = g.nhp >> 3;
+      // slabs of about the same bytes as two tiles of the 512^3 buffer (67 MB)
+      int per = (int)(((size_t)64 << 20) / ((size_t)g.n2 * g.n3 * 128)) * slab / 2;
+      if (per < 1) per = 1;
+      int ns = slab_streams < 1 ? 1 : (slab_streams > gss_fftgs::SLAB_MAX_STREAMS ? gss_fftgs::SLAB_MAX_STREAMS : slab_streams);
+      hipStream_t side[gss_fftgs::SLAB_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+      for (int i = 1; i < ns; ++i) {
+        side[i] = slab_stream(i);
+        if (!side[i]) ns = i;
+      }
+      if (ns > 1 && !h->slab_e0) {
+        GSS_HIP(hipEventCreateWithFlags(&h->slab_e0, hipEventDisableTiming));
+        for (int i = 1; i < ns; ++i) GSS_HIP(hipEventCreateWithFlags(&h->slab_e[i], hipEventDisableTiming));
+      }
+      if (ns > 1) {
+        GSS_HIP(hipEventRecord(h->slab_e0, s));
+        for (int i = 1; i < ns; ++i) GSS_HIP(hipStreamWaitEvent(side[i], h->slab_e0, 0));
+      }
+      int islab = 0;
+      for (int t0 = 0; t0 < ntx; t0 += per, ++islab) {
+        const int nt = t0 + per <= ntx ? per : ntx - t0;
+        hipStream_t st = (islab % ns) ? side[islab % ns] : s;
+        gen_launch_axis<0>(h, 1, st, t0, nt);
+        gen_launch_axis<2>(h, 2, st, t0, nt);
+        gen_launch_axis<1>(h, 1, st, t0, nt);
+      }
+      for (int i = 1; i < ns; ++i) {
+        GSS_HIP(hipEventRecord(h->slab_e[i], side[i]));
+        GSS_HIP(hipStreamWaitEvent(s, h->slab_e[i], 0));
+      }
+    } else {
+      gen_launch_axis<0>(h, 1, s);
+      gen_launch_axis<2>(h, 2, s);
+      gen_launch_axis<1>(h, 1, s);
+    }
   } else {
     gen_launch_axis<2>(h, 1, s);
   }

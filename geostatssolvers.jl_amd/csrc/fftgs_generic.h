@@ -249,10 +249,13 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
 // ---- strided passes.  MODE 0: forward, 1: inverse, 2: forward, phase with Fh, inverse.  Tile (o, t): TX columns
 // t TX .. of line o of the axis; element j of the line at X + o * ostride + j * lstride.  LDS: T[tlen] | buf[L * TX],
 // element (j, c) at j * TX + c.
+// slab_nt > 0: only the x tiles slab_t0 .. slab_t0 + slab_nt - 1 (the slab order of the three strided passes, as in the
+// power-of-two pipeline: what a pass has written is read back by the next from the memory-side cache)
 template <int MODE, int TXLOG>
 __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl, int axis, const double2* __restrict__ atw,
                                                            int64_t ostride, int64_t lstride, double2* __restrict__ X,
-                                                           const double* __restrict__ Fh, double mean) {
+                                                           const double* __restrict__ Fh, double mean, int slab_t0,
+                                                           int slab_nt) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   constexpr int TX = 1 << TXLOG;
   const int L = pl.L;
@@ -260,7 +263,9 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   double2* buf = gsm + pl.tlen;
   const int tid = threadIdx.x;
   const int ntx = g.nhp >> TXLOG;
-  const int t = blockIdx.x % ntx, o = blockIdx.x / ntx;
+  const int tpo = slab_nt > 0 ? slab_nt : ntx;            // tiles per line of the axis in this launch
+  const int t = slab_t0 + (int)(blockIdx.x % (unsigned)tpo), o = (int)(blockIdx.x / (unsigned)tpo);
+  const int tile = o * ntx + t;                            // (the amplitudes are tiled over the whole buffer)
   double2* gbase = X + (int64_t)o * ostride + (int64_t)t * TX;
   for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
   for (int e = tid; e < L * TX; e += GEN_ANT) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
     if (MODE == 2) {
       // fft.jl:163: P = F exp(i angle(X)); the amplitudes in the order of the tile's elements (gen_tile_fh_kernel):
       // one contiguous, aligned run of L * TX doubles per workgroup
-      const double* fh = Fh + (int64_t)blockIdx.x * ((int64_t)L << TXLOG);
+      const double* fh = Fh + (int64_t)tile * ((int64_t)L << TXLOG);
       for (int e = tid; e < L * TX; e += GEN_ANT) {
         const int c = e & (TX - 1), j = e >> TXLOG;
         const int kx = t * TX + c;
