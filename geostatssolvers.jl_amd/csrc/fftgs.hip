@@ -212,6 +212,12 @@ struct gss_fftgs {
   GenPlan gp[3];
   DevBuf gtab[3];
   int g_rows = 1, g_txlog[3] = {3, 3, 3};
+  bool g_tg = false;   // x passes read their tables from global memory (long lines)
+  // long y lines of 2-D grids (1 024 < n2 <= 4 096): n2 = L1 L2, plans and tables of the two short transforms, W_n2
+  bool g_long = false;
+  GenLong gl;
+  GenPlan gpl[2];
+  DevBuf gltab[2], gtwl;
   // slab order of the strided passes: slab i runs on stream i mod ns (0 = the caller's, the others are helper streams
   // of the process, slab_stream()); the events that fence them belong to the handle
   static constexpr int SLAB_MAX_STREAMS = 4;
@@ -525,7 +531,7 @@ static int32_t gen_upload_table(DevBuf& buf, const GenPlan& pl, hipStream_t s) {
   return GSS_OK;
 }
 
-static size_t gen_x_lds(const GenPlan& pl, int rows) { return sizeof(double2) * (size_t)(pl.L + pl.tlen + rows * pl.L); }
+static size_t gen_x_lds(const GenPlan& pl, int rows, bool tg) { return sizeof(double2) * (size_t)((tg ? 0 : pl.L + pl.tlen) + rows * pl.L); }
 static size_t gen_axis_lds(const GenPlan& pl, int txlog) { return sizeof(double2) * (size_t)(pl.tlen + (pl.L << txlog)); }
 
 // 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c: n1 even with n1 / 2 <= 2 048,
@@ -534,9 +540,26 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   const char* e = std::getenv("GSS_FFTGS_PATH");
   if (e && std::strcmp(e, "rocfft") == 0) return GSS_OK;
   const GridSpec& g = h->g;
-  if (h->fused || h->ndim < 2 || (g.n1 & 1) || g.n1 / 2 > 2048 || g.n1 < 4 || g.n2 > 1024 || g.n3 > 1024) return GSS_OK;
+  if (h->fused || h->ndim < 2 || (g.n1 & 1) || g.n1 / 2 > 2048 || g.n1 < 4 || g.n3 > 1024) return GSS_OK;
+  const bool lng = h->ndim == 2 && g.n2 > 1024;
+  if (g.n2 > (lng ? 4096 : 1024)) return GSS_OK;
   GenPlan p1, p2, p3;
   if (!gen_plan((int)(g.n1 / 2), &p1) || !gen_plan((int)g.n2, &p2)) return GSS_OK;
+  if (lng) {
+    // n2 = L1 L2 with both factors <= 64 (L2 the largest such divisor); tiles of at most 4 096 elements
+    GenLong& gl = h->gl;
+    gl.L2 = 0;
+    for (int d = 64; d >= 2; --d)
+      if (g.n2 % d == 0 && g.n2 / d <= 64) { gl.L2 = d; break; }
+    if (gl.L2 == 0) return GSS_OK;
+    gl.L1 = (int)g.n2 / gl.L2;
+    if (!gen_plan(gl.L1, &h->gpl[0]) || !gen_plan(gl.L2, &h->gpl[1])) return GSS_OK;
+    gl.NB = gl.NC = 1;
+    for (int d = 1; d <= gl.L2; ++d)
+      if (gl.L2 % d == 0 && gl.L1 * d <= 512) gl.NB = d;
+    for (int d = 1; d <= gl.L1; ++d)
+      if (gl.L1 % d == 0 && gl.L2 * d <= 512) gl.NC = d;
+  }
   if (h->ndim == 3 && !gen_plan((int)g.n3, &p3)) return GSS_OK;
   if (h->ndim == 2) std::memset(&p3, 0, sizeof(p3));
   h->gp[0] = p1; h->gp[1] = p2; h->gp[2] = p3;
@@ -550,25 +573,52 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   h->g_rows = (int)(2048 / p1.L);
   if (h->g_rows > 16) h->g_rows = 16;
   if (h->g_rows < 1) h->g_rows = 1;
+  {
+    // tables in the LDS unless they cost occupancy: more workgroups per CU (of 160 KB, at most 8) without them
+    const int with = (int)((size_t)(160 << 10) / gen_x_lds(p1, h->g_rows, false));
+    const int without = (int)((size_t)(160 << 10) / gen_x_lds(p1, h->g_rows, true));
+    static const int tg_env = env_int("GSS_FFTGS_GEN_TG", -1);
+    h->g_tg = tg_env >= 0 ? tg_env != 0 : (with <= 2 && without > with);   // (three and more: measured neutral, 1 000^2)
+  }
   h->g_txlog[1] = p2.L <= 512 ? 3 : 2;
   h->g_txlog[2] = (h->ndim == 3 && p3.L > 512) ? 2 : 3;
   GSS_TRY(upload_twiddles(h->tw1, gg.n1, s));
   GSS_TRY(gen_upload_table(h->gtab[0], p1, s));
-  GSS_TRY(gen_upload_table(h->gtab[1], p2, s));
+  if (lng) {
+    GSS_TRY(gen_upload_table(h->gltab[0], h->gpl[0], s));
+    GSS_TRY(gen_upload_table(h->gltab[1], h->gpl[1], s));
+    std::vector<double> w((size_t)2 * g.n2);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int64_t k = 0; k < g.n2; ++k) {
+      const long double a = two_pi * (long double)k / (long double)g.n2;
+      w[2 * k] = (double)cosl(a);
+      w[2 * k + 1] = (double)(-sinl(a));
+    }
+    GSS_TRY(h->gtwl.alloc(sizeof(double) * w.size()));
+    GSS_HIP(hipMemcpyAsync(h->gtwl.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, s));
+    GSS_HIP(hipStreamSynchronize(s));
+  } else {
+    GSS_TRY(gen_upload_table(h->gtab[1], p2, s));
+  }
   if (h->ndim == 3) GSS_TRY(gen_upload_table(h->gtab[2], p3, s));
   GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)gg.nhp * gg.n2 * gg.n3));
   GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));   // the padding columns stay zero
   GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)gg.nhp * gg.n2 * gg.n3));   // amplitudes in the last pass's tile order
   const int lx = 104 * 1024;   // (one fixed bound for every handle: the attribute belongs to the function, not to the launch)
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_PHILOX>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_ARRAY>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_COV>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
-  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_PHILOX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_ARRAY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_fwd_kernel<FF_SRC_COV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_x_inv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lx));
   const int la = 96 * 1024;
 #define GSS_GEN_ATTR(MODE, TXL) \
   GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_axis_kernel<MODE, TXL>), hipFuncAttributeMaxDynamicSharedMemorySize, la))
   GSS_GEN_ATTR(0, 3); GSS_GEN_ATTR(1, 3); GSS_GEN_ATTR(2, 3); GSS_GEN_ATTR(0, 2); GSS_GEN_ATTR(1, 2); GSS_GEN_ATTR(2, 2);
 #undef GSS_GEN_ATTR
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_long_outer_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, la));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_long_outer_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, la));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_long_inner_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, la));
+  GSS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_long_inner_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, la));
+  h->g_long = lng;
   h->generic = true;
   return GSS_OK;
 }
@@ -578,15 +628,23 @@ static void gen_launch_p1(gss_fftgs* h, uint64_t seed, uint32_t real, const doub
   const GenGrid& g = h->gg;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
-  hipLaunchKernelGGL((gen_x_fwd_kernel<SRC>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows), s, g, h->gp[0],
-                     h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
+  if (h->g_tg)
+    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, true>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0],
+                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
+  else
+    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, false>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0],
+                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
 }
 static void gen_launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
   const GenGrid& g = h->gg;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
-  hipLaunchKernelGGL(gen_x_inv_kernel, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows), s, g, h->gp[0], h->g_rows,
-                     h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
+  if (h->g_tg)
+    hipLaunchKernelGGL(gen_x_inv_kernel<true>, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0], h->g_rows,
+                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
+  else
+    hipLaunchKernelGGL(gen_x_inv_kernel<false>, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0], h->g_rows,
+                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
 }
 // strided pass `MODE` along y (axis 1) or z (axis 2)
 template <int MODE>
@@ -607,12 +665,32 @@ static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 =
                        ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt);
 }
 
+// the y pass of a 2-D grid with long lines (fftgs_generic.h: outer / inner / outer); MODE 0: forward only, left in the
+// order frequency c + L1 d at row L2 c + d
+template <int MODE>
+static void gen_launch_long(gss_fftgs* h, hipStream_t s) {
+  const GenGrid& g = h->gg;
+  const GenLong& gl = h->gl;
+  const unsigned ntx = (unsigned)(g.nhp >> 3);
+  const size_t lo = sizeof(double2) * (size_t)(h->gpl[0].tlen + gl.L1 * gl.NB * 8);
+  const size_t li = sizeof(double2) * (size_t)(h->gpl[1].tlen + gl.L2 * gl.NC * 8);
+  hipLaunchKernelGGL(gen_long_outer_kernel<false>, dim3(ntx * (unsigned)(gl.L2 / gl.NB)), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
+                     h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>());
+  hipLaunchKernelGGL(gen_long_inner_kernel<MODE>, dim3(ntx * (unsigned)(gl.L1 / gl.NC)), dim3(GEN_ANT), li, s, g, h->gpl[1], gl,
+                     h->gltab[1].as<double2>(), h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
+  if (MODE == 2)
+    hipLaunchKernelGGL(gen_long_outer_kernel<true>, dim3(ntx * (unsigned)(gl.L2 / gl.NB)), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
+                       h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>());
+}
+
 // fft.jl:96-103 on the generic passes
 static int32_t fftgs_spectrum_generic(gss_fftgs* h, double* partial, hipStream_t s) {
   gen_launch_p1<FF_SRC_COV>(h, 0, 0, nullptr, s);
-  gen_launch_axis<0>(h, 1, s);
+  if (h->g_long) gen_launch_long<0>(h, s);
+  else gen_launch_axis<0>(h, 1, s);
   if (h->ndim == 3) gen_launch_axis<0>(h, 2, s);
-  hipLaunchKernelGGL(gen_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->gg, h->X.as<double2>(), h->Fh(), partial);
+  hipLaunchKernelGGL(gen_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->gg, h->X.as<double2>(), h->Fh(), partial,
+                     h->g_long ? h->gl.L1 : 0, h->g_long ? h->gl.L2 : 0);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
@@ -668,6 +746,8 @@ static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, 
       gen_launch_axis<2>(h, 2, s);
       gen_launch_axis<1>(h, 1, s);
     }
+  } else if (h->g_long) {
+    gen_launch_long<2>(h, s);
   } else {
     gen_launch_axis<2>(h, 1, s);
   }
@@ -761,7 +841,10 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
   if (h->generic) {
     const int axis = h->ndim == 3 ? 2 : 1;
     const int64_t nt = (int64_t)h->gg.nhp * h->gg.n2 * h->gg.n3;
-    if (h->g_txlog[axis] == 3)
+    if (h->g_long)
+      hipLaunchKernelGGL(gen_tile_fh_long_kernel, dim3(grid_blocks(nt)), dim3(256), 0, s, h->gg, h->gl, h->Fh(),
+                         h->Fh_tiled.as<double>());
+    else if (h->g_txlog[axis] == 3)
       hipLaunchKernelGGL(gen_tile_fh_kernel<3>, dim3(grid_blocks(nt)), dim3(256), 0, s, h->gg, axis, h->gp[axis].L, h->Fh(),
                          h->Fh_tiled.as<double>());
     else

@@ -91,20 +91,25 @@ __device__ __forceinline__ void g_dft(double2 (&v)[R]) {
 // (tests/test_oracle_kat.py::test_float_division_trick_of_the_generic_fft_passes).
 __device__ __forceinline__ int g_div(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }
 
+// Line l starts at buf[(l mod lmod) + (l div lmod) * lstr_hi]: lmod = 1, lstr_hi = M for the rows of the x passes; lmod =
+// nlines for a tile whose lines are its columns and column groups (the strided passes); lmod = TX, lstr_hi = L2 TX for the
+// inner transforms of a long line (gen_long_inner_kernel).
 template <int R, bool INV, int NT>
-__device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int nstr, int L, const double2* T, int Ns, int tid) {
+__device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int lstr_hi, int nstr, int L, const double2* T,
+                                       int Ns, int tid) {
   constexpr int MAXI = (8 + R - 1) / R;      // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256))
   const int LR = L / R;
   const int nitems = nlines * LR;
-  const float inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns;
+  const float inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns, inv_lm = 1.0f / (float)lmod;
   double2 v[MAXI][R];
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int it = tid + i * NT;
     if (it < nitems) {
       const int jj = g_div(it, inv_nl), l = it - jj * nlines;
+      const int lh = g_div(l, inv_lm), lb = (l - lh * lmod) + lh * lstr_hi;
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[i][r] = buf[l * lstr + (jj + r * LR) * nstr];
+      for (int r = 0; r < R; ++r) v[i][r] = buf[lb + (jj + r * LR) * nstr];
     }
   }
   __syncthreads();
@@ -113,6 +118,7 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int n
     const int it = tid + i * NT;
     if (it < nitems) {
       const int jj = g_div(it, inv_nl), l = it - jj * nlines;
+      const int lh = g_div(l, inv_lm), lb = (l - lh * lmod) + lh * lstr_hi;
       const int k = jj - g_div(jj, inv_ns) * Ns;
 #pragma unroll
       for (int r = 1; r < R; ++r) {
@@ -123,25 +129,25 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lstr, int n
       g_dft<R, INV>(v[i]);
       const int j0 = (jj - k) * R + k;
 #pragma unroll
-      for (int r = 0; r < R; ++r) buf[l * lstr + (j0 + r * Ns) * nstr] = v[i][r];
+      for (int r = 0; r < R; ++r) buf[lb + (j0 + r * Ns) * nstr] = v[i][r];
     }
   }
   __syncthreads();
 }
 
 template <bool INV, int NT>
-__device__ __forceinline__ void g_transform(double2* buf, int nlines, int lstr, int nstr, const GenPlan& pl, const double2* T,
-                                            int tid) {
+__device__ __forceinline__ void g_transform(double2* buf, int nlines, int lmod, int lstr_hi, int nstr, const GenPlan& pl,
+                                            const double2* T, int tid) {
   int Ns = 1;
   for (int p = 0; p < pl.npass; ++p) {
     const int R = pl.radix[p];
     const double2* Tp = T + pl.toff[p];
     switch (R) {
-      case 2: g_pass<2, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
-      case 3: g_pass<3, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
-      case 4: g_pass<4, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
-      case 5: g_pass<5, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
-      default: g_pass<8, INV, NT>(buf, nlines, lstr, nstr, pl.L, Tp, Ns, tid); break;
+      case 2: g_pass<2, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 3: g_pass<3, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 4: g_pass<4, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 5: g_pass<5, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      default: g_pass<8, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
     }
     Ns *= R;
   }
@@ -150,22 +156,26 @@ __device__ __forceinline__ void g_transform(double2* buf, int nlines, int lstr, 
 constexpr int GEN_XNT = 256;     // x passes: rows * M <= 2 048
 constexpr int GEN_ANT = 512;     // strided passes: TX * L <= 4 096
 
-// ---- GP1.  LDS: tw[M] | T[tlen] | buf[rows * M] ------------------------------------------------------------------------
-template <int SRC>
+// ---- GP1.  LDS: tw[M] | T[tlen] | buf[rows * M]; TG: buf only, the two tables are read where they lie in global memory
+// (long lines: with the tables a 2 048-point line takes 98 KB, one workgroup = one wave per SIMD on a CU; without them
+// 32 KB, five workgroups -- the tables are 64 KB shared by every workgroup and stay in the L2) -------------------------------
+template <int SRC, bool TG>
 __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
                                                             const double2* __restrict__ xtw, uint64_t seed, uint32_t real,
                                                             const double* __restrict__ noise, double2* __restrict__ X,
                                                             VgDev vg) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
-  double2* tw = gsm;
-  double2* T = gsm + M;
-  double2* buf = T + pl.tlen;
+  const double2* tw = TG ? tw1 : gsm;
+  const double2* T = TG ? xtw : gsm + M;
+  double2* buf = TG ? gsm : gsm + M + pl.tlen;
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * rows;
-  for (int k = tid; k < M; k += GEN_XNT) tw[k] = tw1[k];
-  for (int k = tid; k < pl.tlen; k += GEN_XNT) T[k] = xtw[k];
+  if (!TG) {
+    for (int k = tid; k < M; k += GEN_XNT) gsm[k] = tw1[k];
+    for (int k = tid; k < pl.tlen; k += GEN_XNT) gsm[M + k] = xtw[k];
+  }
   for (int e = tid; e < rows * M; e += GEN_XNT) {
     const int row = e / M, n = e - row * M;
     const int64_t grow = row0 + row;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
     buf[e] = x;
   }
   __syncthreads();
-  g_transform<false, GEN_XNT>(buf, rows, M, 1, pl, T, tid);
+  g_transform<false, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
   // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2 for k = 0 .. M, the pair (k, M - k) together
   const int half = M / 2;
   for (int t = tid; t < rows * (half + 1); t += GEN_XNT) {
@@ -207,21 +217,24 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
   }
 }
 
-// ---- GP5.  LDS: tw[M] | T[tlen] | buf[rows * M] ------------------------------------------------------------------------
+// ---- GP5.  LDS: tw[M] | T[tlen] | buf[rows * M] (TG: as in GP1) ---------------------------------------------------------
+template <bool TG>
 __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
                                                             const double2* __restrict__ xtw, const double2* __restrict__ X,
                                                             double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
-  double2* tw = gsm;
-  double2* T = gsm + M;
-  double2* buf = T + pl.tlen;
+  const double2* tw = TG ? tw1 : gsm;
+  const double2* T = TG ? xtw : gsm + M;
+  double2* buf = TG ? gsm : gsm + M + pl.tlen;
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * rows;
-  for (int k = tid; k < M; k += GEN_XNT) tw[k] = tw1[k];
-  for (int k = tid; k < pl.tlen; k += GEN_XNT) T[k] = xtw[k];
-  __syncthreads();
+  if (!TG) {
+    for (int k = tid; k < M; k += GEN_XNT) gsm[k] = tw1[k];
+    for (int k = tid; k < pl.tlen; k += GEN_XNT) gsm[M + k] = xtw[k];
+    __syncthreads();
+  }
   // Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})), k = 0 .. M - 1
   for (int e = tid; e < rows * M; e += GEN_XNT) {
     const int row = e / M, k = e - row * M;
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
     buf[e] = v;
   }
   __syncthreads();
-  g_transform<true, GEN_XNT>(buf, rows, M, 1, pl, T, tid);
+  g_transform<true, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
   double2* o2 = reinterpret_cast<double2*>(out);
   for (int e = tid; e < rows * M; e += GEN_XNT) {
     const int row = e / M, n = e - row * M;
@@ -274,9 +287,9 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   }
   __syncthreads();
   if (MODE == 1) {
-    g_transform<true, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+    g_transform<true, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
   } else {
-    g_transform<false, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+    g_transform<false, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
     if (MODE == 2) {
       // fft.jl:163: P = F exp(i angle(X)); the amplitudes in the order of the tile's elements (gen_tile_fh_kernel):
       // one contiguous, aligned run of L * TX doubles per workgroup
@@ -306,12 +319,135 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
         }
       }
       __syncthreads();
-      g_transform<true, GEN_ANT>(buf, TX, 1, TX, pl, T, tid);
+      g_transform<true, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
     }
   }
   for (int e = tid; e < L * TX; e += GEN_ANT) {
     const int c = e & (TX - 1), j = e >> TXLOG;
     gbase[(int64_t)j * lstride + c] = buf[e];
+  }
+}
+
+// ---- long lines: the y axis of a 2-D grid with 1 024 < n2 <= 4 096 (2 048^2, 4 096^2, 3 000 x 2 000 ...) -------------------
+// A column tile of such a line does not fit the LDS, so the line is split n2 = L1 L2 (both <= 64; y = L2 a + b, frequency
+// k = c + L1 d) and its transform X^[c + L1 d] = sum_b W_L2^(b d) [ W_n2^(b c) sum_a x[L2 a + b] W_L1^(a c) ] runs as
+//   outer (forward)  : for NB values of b, L1-point transforms over a (rows L2 apart), times W_n2^(b c), stored in place
+//                      (frequency index c where a was)
+//   inner            : for NC values of c, L2-point transforms over b (L2 consecutive rows) -> frequency c + L1 d at row
+//                      L2 c + d; MODE 2 continues in the same trip with the phase step and the inverse inner transforms
+//   outer (inverse)  : times conj W_n2^(b c), inverse L1-point transforms over c -> natural order
+// i.e. the pass GP3 of a 2-D grid becomes three trips over the buffer (five passes per realisation in all); the rows of
+// every tile are 128-byte pieces exactly as in the other strided passes.  twl = exp(-2 pi i k / n2), k < n2 (global; b c <
+// L2 L1 = n2, so the product indexes it directly).
+struct GenLong {
+  int L1, L2;      // n2 = L1 * L2
+  int NB;          // values of b per outer tile (divides L2; TX * L1 * NB <= 4 096)
+  int NC;          // values of c per inner tile (divides L1; TX * L2 * NC <= 4 096)
+};
+
+template <bool INV>
+__global__ __launch_bounds__(GEN_ANT) void gen_long_outer_kernel(GenGrid g, GenPlan pl, GenLong lg,
+                                                                 const double2* __restrict__ atw, const double2* __restrict__ twl,
+                                                                 double2* __restrict__ X) {
+  extern __shared__ __attribute__((aligned(16))) double2 gsm[];
+  constexpr int TX = 8;
+  const int L1 = lg.L1, L2 = lg.L2, NB = lg.NB;
+  double2* T = gsm;
+  double2* buf = gsm + pl.tlen;
+  const int tid = threadIdx.x;
+  const int ntx = g.nhp >> 3;
+  const int t = blockIdx.x % ntx, b0 = (blockIdx.x / ntx) * NB;
+  double2* gbase = X + (int64_t)t * TX;
+  const int nel = L1 * NB * TX;
+  for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
+  // element e = (a * NB + bb) * TX + c  <->  row L2 a + b0 + bb, column t TX + c
+  for (int e = tid; e < nel; e += GEN_ANT) {
+    const int c = e & 7, q = e >> 3;
+    const int a = q / NB, bb = q - a * NB;
+    double2 x = gbase[(int64_t)(L2 * a + b0 + bb) * g.nhp + c];
+    if (INV) {   // undo the forward twiddle before the inverse transform over the frequency index a = c'
+      double2 w = twl[(b0 + bb) * a];
+      w.y = -w.y;
+      x = cmul(x, w);
+    }
+    buf[e] = x;
+  }
+  __syncthreads();
+  g_transform<INV, GEN_ANT>(buf, NB * TX, NB * TX, 0, NB * TX, pl, T, tid);
+  for (int e = tid; e < nel; e += GEN_ANT) {
+    const int c = e & 7, q = e >> 3;
+    const int a = q / NB, bb = q - a * NB;
+    double2 x = buf[e];
+    if (!INV) x = cmul(x, twl[(b0 + bb) * a]);
+    gbase[(int64_t)(L2 * a + b0 + bb) * g.nhp + c] = x;
+  }
+}
+
+// MODE 0: forward inner transforms only (spectrum build); MODE 2: forward, phase with Fh (tiled: gen_tile_fh_long_kernel),
+// inverse.  Tile: columns t TX .., rows L2 c0 .. L2 (c0 + NC) - 1 (consecutive); element e = (cc * L2 + b) * TX + col.
+template <int MODE>
+__global__ __launch_bounds__(GEN_ANT) void gen_long_inner_kernel(GenGrid g, GenPlan pl, GenLong lg,
+                                                                 const double2* __restrict__ atw, double2* __restrict__ X,
+                                                                 const double* __restrict__ Fh, double mean) {
+  extern __shared__ __attribute__((aligned(16))) double2 gsm[];
+  constexpr int TX = 8;
+  const int L2 = lg.L2, NC = lg.NC;
+  double2* T = gsm;
+  double2* buf = gsm + pl.tlen;
+  const int tid = threadIdx.x;
+  const int ntx = g.nhp >> 3;
+  const int t = blockIdx.x % ntx, c0 = (blockIdx.x / ntx) * NC;
+  double2* gbase = X + (int64_t)L2 * c0 * g.nhp + (int64_t)t * TX;
+  const int nel = NC * L2 * TX;
+  for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
+  for (int e = tid; e < nel; e += GEN_ANT) buf[e] = gbase[(int64_t)(e >> 3) * g.nhp + (e & 7)];
+  __syncthreads();
+  g_transform<false, GEN_ANT>(buf, NC * TX, TX, L2 * TX, TX, pl, T, tid);
+  if (MODE == 2) {
+    const double* fh = Fh + (int64_t)blockIdx.x * nel;
+    for (int e = tid; e < nel; e += GEN_ANT) {
+      const int col = e & 7;
+      if (t * TX + col < g.nh) {
+        const double f = fh[e];
+        const double2 x = buf[e];
+        const double mag2 = x.x * x.x + x.y * x.y;
+        double2 pz;
+        if (mag2 > 0.0) {
+          double y = __builtin_amdgcn_rsq(mag2);
+          double er = fma(-(mag2 * y), y, 1.0);
+          y = fma(0.5 * y, er, y);
+          er = fma(-(mag2 * y), y, 1.0);
+          y = fma(0.5 * y, er, y);
+          const double inv = f * y;
+          pz = make_double2(x.x * inv, x.y * inv);
+        } else {
+          pz = make_double2(f, 0.0);
+        }
+        if (blockIdx.x == 0 && e == 0) pz = make_double2(mean, 0.0);   // (kx, ky) = (0, 0): c = 0, d = 0, column 0
+        buf[e] = pz;
+      }
+    }
+    __syncthreads();
+    g_transform<true, GEN_ANT>(buf, NC * TX, TX, L2 * TX, TX, pl, T, tid);
+  }
+  for (int e = tid; e < nel; e += GEN_ANT) gbase[(int64_t)(e >> 3) * g.nhp + (e & 7)] = buf[e];
+}
+
+// amplitudes in the order of gen_long_inner_kernel's tiles: dst[(cg * ntx + t) * NC L2 TX + (cc L2 + d) TX + col] =
+// Fh[(c0 + cc + L1 d) nh + t TX + col]
+__global__ __launch_bounds__(256) void gen_tile_fh_long_kernel(GenGrid g, GenLong lg, const double* __restrict__ Fh,
+                                                               double* __restrict__ dst) {
+  const int ntx = g.nhp >> 3;
+  const int64_t per_tile = (int64_t)lg.NC * lg.L2 * 8;
+  const int64_t total = (int64_t)(lg.L1 / lg.NC) * ntx * per_tile;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t tile = e / per_tile;
+    const int w = (int)(e - tile * per_tile);
+    const int col = w & 7, q = w >> 3;
+    const int cc = q / lg.L2, d = q - cc * lg.L2;
+    const int t = (int)(tile % ntx), cg = (int)(tile / ntx);
+    const int kx = t * 8 + col, ky = cg * lg.NC + cc + lg.L1 * d;
+    dst[e] = kx < g.nh ? Fh[(int64_t)ky * g.nh + kx] : 0.0;
   }
 }
 
@@ -339,14 +475,16 @@ __global__ __launch_bounds__(256) void gen_tile_fh_kernel(GenGrid g, int axis, i
 
 // spectrum build: Fh[idx] = sqrt(|X|) from the padded buffer (natural order), DC = 0 (fft.jl:102-103); partial sums of
 // F^2 over the FULL spectrum as in fftgs_amp_kernel
+// (L1 > 0: the y axis was transformed as a long line, frequency c + L1 d sits at row L2 c + d)
 __global__ __launch_bounds__(256) void gen_amp_kernel(GenGrid g, const double2* __restrict__ X, double* __restrict__ Fh,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial, int L1, int L2) {
   __shared__ double red[256];
   const int64_t NH = (int64_t)g.nh * g.n2 * g.n3;
   double acc = 0.0;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
     const int kx = (int)(idx % g.nh);
-    const int64_t r = idx / g.nh;
+    int64_t r = idx / g.nh;
+    if (L1 > 0) r = (int64_t)L2 * (r % L1) + r / L1;
     const double2 x = X[r * g.nhp + kx];
     double f = sqrt(sqrt(x.x * x.x + x.y * x.y));
     if (idx == 0) f = 0.0;

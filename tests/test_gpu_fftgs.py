@@ -486,7 +486,9 @@ def test_config3_full_size_realisation_against_host_fft():
 
 GENERIC_GRIDS = [(100, 100), (60, 50), (50, 64), (64, 64), (1000, 36), (36, 1000), (4096, 16), (250, 250),
                  (48, 36, 30), (100, 100, 100), (20, 18, 10), (64, 48, 40), (30, 625, 8),
-                 (4, 2), (6, 3), (8, 8, 8), (16, 16, 16), (4, 1024)]
+                 (4, 2), (6, 3), (8, 8, 8), (16, 16, 16), (4, 1024),
+                 # long y lines (1 024 < n2 <= 4 096): the split n2 = L1 L2 of fftgs_generic.h
+                 (64, 2048), (2048, 2048), (16, 4096), (100, 3000), (36, 1500), (250, 1280), (1024, 4096)]
 
 
 @pytest.mark.parametrize("dims", GENERIC_GRIDS)

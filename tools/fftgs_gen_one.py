@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few FFTGS realisations on a grid of the generic pipeline (default 300^3) and nothing else: the workload of
-rocprofv3 kernel traces / PMC passes of fftgs_generic.h.  tools/fftgs_gen_one.py [n1 n2 [n3]] [realisations]"""
+rocprofv3 kernel traces / PMC passes of fftgs_generic.h.  tools/fftgs_gen_one.py [n1 n2 n3 | n1xn2] [realisations]"""
 import os
 import sys
 
@@ -12,9 +12,13 @@ import torch  # noqa: E402
 import gss  # noqa: E402
 from gss.engine import FFTGSHandle  # noqa: E402
 
-args = [int(a) for a in sys.argv[1:]]
-dims = tuple(args[:3]) if len(args) >= 3 else (300, 300, 300)
-n = args[3] if len(args) > 3 else 6
+if len(sys.argv) > 1 and "x" in sys.argv[1]:
+    dims = tuple(int(a) for a in sys.argv[1].split("x"))
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+else:
+    args = [int(a) for a in sys.argv[1:]]
+    dims = tuple(args[:3]) if len(args) >= 3 else (300, 300, 300)
+    n = args[3] if len(args) > 3 else 6
 f = FFTGSHandle(gss.ExponentialVariogram(range=dims[0] / 10.0), dims)
 N = 1
 for d in dims:
