@@ -525,6 +525,49 @@ def test_generic_pipeline_matches_oracle_and_rocfft_path(dims, monkeypatch):
     h2.close()
 
 
+def _random_shapes():
+    """Forty grid shapes drawn once (fixed seed): 1-D, 2-D and 3-D, axis lengths from smooth numbers (2^a 3^b 5^c, the
+    generic passes: every radix order, odd half lengths, the long-line split), powers of two (fused pipeline) and
+    arbitrary integers (rocFFT), at most 3 million cells."""
+    rng = np.random.default_rng(20260405)
+    smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(8) for c in range(6)
+                     if 2 <= 2 ** a * 3 ** b * 5 ** c <= 4096})
+    shapes = []
+    while len(shapes) < 40:
+        nd = int(rng.choice([1, 2, 2, 2, 3, 3]))
+        cap = {1: 4096, 2: 4096, 3: 200}[nd]
+        dims = []
+        for _ in range(nd):
+            kind = rng.integers(0, 10)
+            if kind < 7:
+                n = int(rng.choice([v for v in smooth if v <= cap]))
+            elif kind < 8:
+                n = int(2 ** rng.integers(1, int(np.log2(cap)) + 1))
+            else:
+                n = int(rng.integers(2, cap + 1))
+            dims.append(n)
+        if 2 <= int(np.prod(dims)) <= 3_000_000 and tuple(dims) not in shapes:
+            shapes.append(tuple(dims))
+    return shapes
+
+
+@pytest.mark.parametrize("dims", _random_shapes(), ids=lambda d: "x".join(map(str, d)))
+def test_any_grid_shape_matches_oracle(dims):
+    """Whatever pipeline the library picks for a shape (fused power-of-two passes, generic Stockham passes with or without
+    the long-line split, rocFFT), spectrum and realisations are the oracle's: 1e-12 of max F / 1e-9."""
+    N = int(np.prod(dims))
+    kw = dict(range=max(2.0, 0.15 * dims[0]), sill=0.9, nugget=0.1)
+    pre = O.preprocess(Variogram("exponential", **kw), dims, mean=-0.2)
+    h = _handle("exponential", dims, mean=-0.2, **kw)
+    F = h.spectrum()
+    assert np.max(np.abs(F - pre.F.ravel())) < 1e-12 * pre.F.max()
+    z = h.realize(3, 1, 2)
+    assert np.max(np.abs(z - O.realize(pre, 3, 1, 2))) < 1e-9
+    noise = np.random.default_rng(N).uniform(size=(1, N))
+    assert np.max(np.abs(h.realize(0, 0, 1, noise=noise)[0] - O.solvesingle(pre, noise[0]))) < 1e-9
+    h.close()
+
+
 def test_generic_pipeline_with_anisotropy_spacing_and_state_adoption():
     """The reference's anisotropic case (`GaussianVariogram(MetricBall((20., 5.)))` on 100 x 100, test/simulation/fft.jl:
     8-12) and a grid with unequal spacing on the generic passes (Gaussian model: 1e-6, module docstring), and a handle
