@@ -252,3 +252,35 @@ def test_slab_kernel_257_to_768_neighbours(variant, deg, kind, vkw, dim, k):
         os.environ.pop("GSS_KRIG_SLAB_OFF", None)
     assert np.array_equal(st2, st) and np.max(np.abs(mu2 - mu)) < tol and np.max(np.abs(var2 - var)) < tol
     h.close()
+
+
+@pytest.mark.parametrize("k", [63, 64, 65, 80, 81, 96, 97, 112, 113, 128, 129, 144, 240, 255, 256, 257, 272, 400, 767, 768,
+                               769, 800])
+def test_every_kernel_boundary_with_ragged_neighbour_counts(k):
+    """maxneighbors on both sides of every switch of the moving-neighbourhood dispatch (64 | 65: one wave per point ->
+    register tiles; 96 | 97 and 128 | 129: 3 -> 4 -> 8 waves; 256 | 257: tiles -> slab kernel; 768 | 769: slab -> scalar
+    kernel), with a ball that leaves the counts anywhere between minneighbors and k inside one launch, universal kriging
+    of degree 1, a nugget, and estimation points on data locations.  Indices bit-exact, estimates 1e-9."""
+    import gss
+    from gss.engine import KrigHandle
+    rng = np.random.default_rng(1000 + k)
+    n, m = max(1200, 2 * k), 48
+    x = rng.uniform(0, 100, (n, 3))
+    z = rng.normal(size=n) + 0.03 * x[:, 1]
+    x0 = rng.uniform(5, 95, (m, 3))
+    x0[:3] = x[:3]
+    x0[-4:] = rng.uniform(400, 500, (4, 3))            # nothing inside the ball: missing
+    # radius so that a typical ball holds about 0.8 k samples: some lists are full, most are cut short
+    radius = (0.8 * k / n * 100.0 ** 3 * 3.0 / (4.0 * np.pi)) ** (1.0 / 3.0)
+    vkw = dict(range=35.0, sill=1.3, nugget=0.05)
+    h = KrigHandle(gss.SphericalVariogram(**vkw), K.UK, x, z, degree=1, factor=False)
+    mu, var, st, idx, cnt = h.predict_knn(x0, k, minneighbors=5, radius=radius, return_idx=True)
+    h.close()
+    rmu, rvar, rst, ridx, rcnt = K.approxsolve(K.UK, Variogram("spherical", **vkw), x, z, x0, k, 5, degree=1,
+                                               radius=radius, return_idx=True)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and np.array_equal(st, rst)
+    assert st[-4:].all() and cnt[:-4].min() < cnt[:-4].max()
+    ok = st == 0
+    assert ok.sum() >= m - 8
+    assert np.max(np.abs(mu[ok] - rmu[ok])) < 1e-9 * max(1.0, np.max(np.abs(rmu[ok])))
+    assert np.max(np.abs(var[ok] - rvar[ok])) < 1e-9
