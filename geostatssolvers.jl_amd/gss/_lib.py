@@ -18,7 +18,7 @@ except Exception:  # pragma: no cover - torch is optional for pure C-ABI use
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libgss_hip.so"))
+LIB_PATH = os.environ.get("GSS_LIB_PATH") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libgss_hip.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_ALLOC = range(7)
