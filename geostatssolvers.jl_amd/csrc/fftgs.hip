@@ -151,10 +151,11 @@ __global__ __launch_bounds__(256) void fftgs_expand_kernel(GridSpec g, const dou
   }
 }
 
+// (blockIdx.y: member of a batch of realisations, sources sbs and destinations n doubles apart)
 __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ src, const int64_t* __restrict__ inds,
-                                                     int64_t n, double* __restrict__ dst) {
+                                                     int64_t n, double* __restrict__ dst, int64_t sbs = 0) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[inds[i]];
+  if (i < n) dst[(int64_t)blockIdx.y * n + i] = src[(int64_t)blockIdx.y * sbs + inds[i]];
 }
 
 static std::once_flag g_rocfft_once;
@@ -213,6 +214,8 @@ struct gss_fftgs {
   DevBuf gtab[3];
   int g_rows = 1, g_txlog[3] = {3, 3, 3};
   bool g_tg = false;   // x passes read their tables from global memory (long lines)
+  int g_batch = 1;     // realisations per launch (small grids: X holds g_batch half-spectrum buffers, g_xbs elements apart)
+  int64_t g_xbs = 0;
   // long y lines of 2-D grids (1 024 < n2 <= 4 096): n2 = L1 L2, plans and tables of the two short transforms, W_n2
   bool g_long = false;
   GenLong gl;
@@ -416,10 +419,15 @@ static int32_t launch_axis_mode(gss_fftgs* h, int axis, hipStream_t s, int slab_
 // y and z); everything else, and GSS_FFTGS_PATH=rocfft, stays on the rocFFT pipeline.
 static int32_t fftgs_setup_fused(gss_fftgs* h, hipStream_t s) {
   const char* e = std::getenv("GSS_FFTGS_PATH");
-  if (e && std::strcmp(e, "rocfft") == 0) return GSS_OK;
+  if (e && (std::strcmp(e, "rocfft") == 0 || std::strcmp(e, "generic") == 0)) return GSS_OK;
   const GridSpec& g = h->g;
   if (h->ndim != 3 || !pow2(g.n1) || !pow2(g.n2) || !pow2(g.n3)) return GSS_OK;
   if (g.n1 < 32 || g.n1 > 1024 || g.n2 < 16 || g.n2 > 1024 || g.n3 < 16 || g.n3 > 1024) return GSS_OK;
+  // Small grids are left to the generic passes, where eight and more realisations share every launch (measured, ms per
+  // realisation, fused / generic: 32^3 0.019 / 0.003, 64^3 0.024 / 0.011, 128 x 128 x 64 0.049 / 0.034, 128^3 0.064 /
+  // 0.059, 256 x 128 x 128 0.095 / 0.127): up to a 12 MiB half spectrum.  GSS_FFTGS_PATH=fused keeps them here.
+  const bool force = e && std::strcmp(e, "fused") == 0;
+  if (!force && sizeof(double2) * (size_t)((g.nh + 7) / 8 * 8) * g.n2 * g.n3 <= ((size_t)12 << 20)) return GSS_OK;
   FusedGrid f;
   f.n1 = (int)g.n1; f.n2 = (int)g.n2; f.n3 = (int)g.n3;
   f.l1 = ilog2(g.n1); f.l2 = ilog2(g.n2); f.l3 = ilog2(g.n3);
@@ -601,7 +609,19 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
     GSS_TRY(gen_upload_table(h->gtab[1], p2, s));
   }
   if (h->ndim == 3) GSS_TRY(gen_upload_table(h->gtab[2], p3, s));
-  GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)gg.nhp * gg.n2 * gg.n3));
+  // Small grids do not fill the device (100 x 100: seven workgroups in GP1) and their three or five launches cost more
+  // than their work: up to g_batch realisations share every launch (blockIdx.y), each with a half-spectrum buffer of its
+  // own -- as many as fit 96 MiB (the buffers of a batch stay in the memory-side cache between the passes), at most 64.
+  h->g_xbs = (int64_t)gg.nhp * gg.n2 * gg.n3;
+  {
+    static const int batch_env = env_int("GSS_FFTGS_GEN_BATCH", 0);
+    int64_t b = ((int64_t)96 << 20) / (int64_t)(sizeof(double2) * (size_t)h->g_xbs);
+    if (b > 64) b = 64;
+    if (batch_env > 0) b = batch_env;
+    if (b < 1) b = 1;
+    h->g_batch = (int)b;
+  }
+  GSS_TRY(h->X.alloc(sizeof(double2) * (size_t)h->g_xbs * h->g_batch));
   GSS_TRY(dev_zero_bytes(h->X.p, h->X.bytes, s));   // the padding columns stay zero
   GSS_TRY(h->Fh_tiled.alloc(sizeof(double) * (size_t)gg.nhp * gg.n2 * gg.n3));   // amplitudes in the last pass's tile order
   const int lx = 104 * 1024;   // (one fixed bound for every handle: the attribute belongs to the function, not to the launch)
@@ -623,32 +643,35 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   return GSS_OK;
 }
 
+// (nb: realisations in this launch, grid y)
 template <int SRC>
-static void gen_launch_p1(gss_fftgs* h, uint64_t seed, uint32_t real, const double* noise, hipStream_t s) {
+static void gen_launch_p1(gss_fftgs* h, uint64_t seed, uint32_t real, const double* noise, hipStream_t s, int nb = 1) {
   const GenGrid& g = h->gg;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
   if (h->g_tg)
-    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, true>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0],
-                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
+    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, true>), dim3(gx, nb), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0],
+                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg,
+                       h->g_xbs);
   else
-    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, false>), dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0],
-                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg);
+    hipLaunchKernelGGL((gen_x_fwd_kernel<SRC, false>), dim3(gx, nb), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0],
+                       h->g_rows, h->tw1.as<double2>(), h->gtab[0].as<double2>(), seed, real, noise, h->X.as<double2>(), h->vg,
+                       h->g_xbs);
 }
-static void gen_launch_p5(gss_fftgs* h, double* z, hipStream_t s) {
+static void gen_launch_p5(gss_fftgs* h, double* z, hipStream_t s, int nb = 1) {
   const GenGrid& g = h->gg;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const unsigned gx = (unsigned)((nrows + h->g_rows - 1) / h->g_rows);
   if (h->g_tg)
-    hipLaunchKernelGGL(gen_x_inv_kernel<true>, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0], h->g_rows,
-                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
+    hipLaunchKernelGGL(gen_x_inv_kernel<true>, dim3(gx, nb), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, true), s, g, h->gp[0], h->g_rows,
+                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z, h->g_xbs, h->N);
   else
-    hipLaunchKernelGGL(gen_x_inv_kernel<false>, dim3(gx), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0], h->g_rows,
-                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z);
+    hipLaunchKernelGGL(gen_x_inv_kernel<false>, dim3(gx, nb), dim3(GEN_XNT), gen_x_lds(h->gp[0], h->g_rows, false), s, g, h->gp[0], h->g_rows,
+                       h->tw1.as<double2>(), h->gtab[0].as<double2>(), h->X.as<double2>(), z, h->g_xbs, h->N);
 }
 // strided pass `MODE` along y (axis 1) or z (axis 2)
 template <int MODE>
-static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 = 0, int slab_nt = 0) {
+static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 = 0, int slab_nt = 0, int nb = 1) {
   const GenGrid& g = h->gg;
   const GenPlan& pl = h->gp[axis];
   const int txlog = h->g_txlog[axis];
@@ -658,29 +681,29 @@ static void gen_launch_axis(gss_fftgs* h, int axis, hipStream_t s, int slab_t0 =
   const unsigned blocks = (unsigned)(nouter * (slab_nt > 0 ? slab_nt : (g.nhp >> txlog)));
   const size_t lds = gen_axis_lds(pl, txlog);
   if (txlog == 3)
-    hipLaunchKernelGGL((gen_axis_kernel<MODE, 3>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt);
+    hipLaunchKernelGGL((gen_axis_kernel<MODE, 3>), dim3(blocks, nb), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt, h->g_xbs);
   else
-    hipLaunchKernelGGL((gen_axis_kernel<MODE, 2>), dim3(blocks), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
-                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt);
+    hipLaunchKernelGGL((gen_axis_kernel<MODE, 2>), dim3(blocks, nb), dim3(GEN_ANT), lds, s, g, pl, axis, h->gtab[axis].as<double2>(),
+                       ostride, lstride, h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, slab_t0, slab_nt, h->g_xbs);
 }
 
 // the y pass of a 2-D grid with long lines (fftgs_generic.h: outer / inner / outer); MODE 0: forward only, left in the
 // order frequency c + L1 d at row L2 c + d
 template <int MODE>
-static void gen_launch_long(gss_fftgs* h, hipStream_t s) {
+static void gen_launch_long(gss_fftgs* h, hipStream_t s, int nb = 1) {
   const GenGrid& g = h->gg;
   const GenLong& gl = h->gl;
   const unsigned ntx = (unsigned)(g.nhp >> 3);
   const size_t lo = sizeof(double2) * (size_t)(h->gpl[0].tlen + gl.L1 * gl.NB * 8);
   const size_t li = sizeof(double2) * (size_t)(h->gpl[1].tlen + gl.L2 * gl.NC * 8);
-  hipLaunchKernelGGL(gen_long_outer_kernel<false>, dim3(ntx * (unsigned)(gl.L2 / gl.NB)), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
-                     h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>());
-  hipLaunchKernelGGL(gen_long_inner_kernel<MODE>, dim3(ntx * (unsigned)(gl.L1 / gl.NC)), dim3(GEN_ANT), li, s, g, h->gpl[1], gl,
-                     h->gltab[1].as<double2>(), h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean);
+  hipLaunchKernelGGL(gen_long_outer_kernel<false>, dim3(ntx * (unsigned)(gl.L2 / gl.NB), nb), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
+                     h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>(), h->g_xbs);
+  hipLaunchKernelGGL(gen_long_inner_kernel<MODE>, dim3(ntx * (unsigned)(gl.L1 / gl.NC), nb), dim3(GEN_ANT), li, s, g, h->gpl[1], gl,
+                     h->gltab[1].as<double2>(), h->X.as<double2>(), h->Fh_tiled.as<double>(), h->mean, h->g_xbs);
   if (MODE == 2)
-    hipLaunchKernelGGL(gen_long_outer_kernel<true>, dim3(ntx * (unsigned)(gl.L2 / gl.NB)), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
-                       h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>());
+    hipLaunchKernelGGL(gen_long_outer_kernel<true>, dim3(ntx * (unsigned)(gl.L2 / gl.NB), nb), dim3(GEN_ANT), lo, s, g, h->gpl[0], gl,
+                       h->gltab[0].as<double2>(), h->gtwl.as<double2>(), h->X.as<double2>(), h->g_xbs);
 }
 
 // fft.jl:96-103 on the generic passes
@@ -696,10 +719,12 @@ static int32_t fftgs_spectrum_generic(gss_fftgs* h, double* partial, hipStream_t
 }
 
 // one realisation (fft.jl:163-170): five passes on 3-D grids, three on 2-D grids
-static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z, hipStream_t s) {
+// nb > 1: realisations real .. real + nb - 1 in the same launches (noise arrays and outputs N doubles apart)
+static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, const double* noise, double* z, hipStream_t s,
+                                     int nb = 1) {
   ProfScope ps("fftgs_generic", s);
-  if (noise) gen_launch_p1<FF_SRC_ARRAY>(h, seed, (uint32_t)real, noise, s);
-  else gen_launch_p1<FF_SRC_PHILOX>(h, seed, (uint32_t)real, nullptr, s);
+  if (noise) gen_launch_p1<FF_SRC_ARRAY>(h, seed, (uint32_t)real, noise, s, nb);
+  else gen_launch_p1<FF_SRC_PHILOX>(h, seed, (uint32_t)real, nullptr, s, nb);
   if (h->ndim == 3) {
     // The slab order of the power-of-two pipeline (fftgs_fused_rest: the three strided passes slab by slab over the x
     // tiles, slabs alternating over the caller's and the helper streams) is available here as an A/B switch only:
@@ -709,7 +734,7 @@ static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, 
     static const int slab = env_int("GSS_FFTGS_GEN_SLAB", 0);
     static const int slab_streams = env_int("GSS_FFTGS_SLAB_STREAMS", 3);
     const GenGrid& g = h->gg;
-    const bool can_slab = slab > 0 && h->g_txlog[1] == 3 && h->g_txlog[2] == 3 && h->X.bytes > ((size_t)200 << 20);
+    const bool can_slab = slab > 0 && nb == 1 && h->g_txlog[1] == 3 && h->g_txlog[2] == 3 && h->X.bytes > ((size_t)200 << 20);
     if (can_slab) {
       const int ntx = g.nhp >> 3;
       // slabs of about the same bytes as two tiles of the 512^3 buffer (67 MB)
@@ -742,16 +767,16 @@ static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, 
         GSS_HIP(hipStreamWaitEvent(s, h->slab_e[i], 0));
       }
     } else {
-      gen_launch_axis<0>(h, 1, s);
-      gen_launch_axis<2>(h, 2, s);
-      gen_launch_axis<1>(h, 1, s);
+      gen_launch_axis<0>(h, 1, s, 0, 0, nb);
+      gen_launch_axis<2>(h, 2, s, 0, 0, nb);
+      gen_launch_axis<1>(h, 1, s, 0, 0, nb);
     }
   } else if (h->g_long) {
-    gen_launch_long<2>(h, s);
+    gen_launch_long<2>(h, s, nb);
   } else {
-    gen_launch_axis<2>(h, 1, s);
+    gen_launch_axis<2>(h, 1, s, 0, 0, nb);
   }
-  gen_launch_p5(h, z, s);
+  gen_launch_p5(h, z, s, nb);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }
@@ -1123,14 +1148,22 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
       continue;
     }
     if (h->generic) {
+      // a batch: consecutive realisations whose outputs are consecutive (the caller's array, or one chunk of the ring)
+      int64_t nb = h->g_batch;
+      if (noise && host) nb = 1;                           // (host noise is staged one realisation at a time)
+      if (nb > nreals - r) nb = nreals - r;
+      if (os.on && nb > os.chunk - r % os.chunk) nb = os.chunk - r % os.chunk;
+      if (inds && nb > 1 && h->Z.bytes < sizeof(double) * (size_t)N * (size_t)nb)
+        GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N * (size_t)h->g_batch));
       double* zf = inds ? h->Z.as<double>() : dst;
-      GSS_TRY(fftgs_generic_realize(h, seed, first_real + r, nz, zf, s));
+      GSS_TRY(fftgs_generic_realize(h, seed, first_real + r, nz, zf, s, (int)nb));
       if (inds) {
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, zf, si.as<int64_t>(),
-                           ninds, dst);
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256), (unsigned)nb), dim3(256), 0, s, zf,
+                           si.as<int64_t>(), ninds, dst, N);
         GSS_HIP(hipGetLastError());
       }
-      GSS_TRY(os.done(r, s));
+      GSS_TRY(os.done(r + nb - 1, s));
+      r += nb - 1;
       continue;
     }
     double* u = h->U.as<double>();

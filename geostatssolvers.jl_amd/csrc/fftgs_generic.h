@@ -163,7 +163,7 @@ template <int SRC, bool TG>
 __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
                                                             const double2* __restrict__ xtw, uint64_t seed, uint32_t real,
                                                             const double* __restrict__ noise, double2* __restrict__ X,
-                                                            VgDev vg) {
+                                                            VgDev vg, int64_t xbs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
   const double2* tw = TG ? tw1 : gsm;
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * rows;
+  // blockIdx.y: member of a batch of realisations (consecutive realisation numbers, noise arrays and X buffers xbs apart)
+  real += blockIdx.y;
+  X += (int64_t)blockIdx.y * xbs;
+  if (SRC == FF_SRC_ARRAY) noise += (int64_t)blockIdx.y * (2 * nrows * M);
   if (!TG) {
     for (int k = tid; k < M; k += GEN_XNT) gsm[k] = tw1[k];
     for (int k = tid; k < pl.tlen; k += GEN_XNT) gsm[M + k] = xtw[k];
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
 template <bool TG>
 __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan pl, int rows, const double2* __restrict__ tw1,
                                                             const double2* __restrict__ xtw, const double2* __restrict__ X,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, int64_t xbs, int64_t obs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
   const double2* tw = TG ? tw1 : gsm;
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
   const int tid = threadIdx.x;
   const int64_t nrows = (int64_t)g.n2 * g.n3;
   const int64_t row0 = (int64_t)blockIdx.x * rows;
+  X += (int64_t)blockIdx.y * xbs;      // batch member: its X buffer, its output (obs doubles apart)
+  out += (int64_t)blockIdx.y * obs;
   if (!TG) {
     for (int k = tid; k < M; k += GEN_XNT) gsm[k] = tw1[k];
     for (int k = tid; k < pl.tlen; k += GEN_XNT) gsm[M + k] = xtw[k];
@@ -268,7 +274,7 @@ template <int MODE, int TXLOG>
 __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl, int axis, const double2* __restrict__ atw,
                                                            int64_t ostride, int64_t lstride, double2* __restrict__ X,
                                                            const double* __restrict__ Fh, double mean, int slab_t0,
-                                                           int slab_nt) {
+                                                           int slab_nt, int64_t xbs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   constexpr int TX = 1 << TXLOG;
   const int L = pl.L;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   const int tpo = slab_nt > 0 ? slab_nt : ntx;            // tiles per line of the axis in this launch
   const int t = slab_t0 + (int)(blockIdx.x % (unsigned)tpo), o = (int)(blockIdx.x / (unsigned)tpo);
   const int tile = o * ntx + t;                            // (the amplitudes are tiled over the whole buffer)
-  double2* gbase = X + (int64_t)o * ostride + (int64_t)t * TX;
+  double2* gbase = X + (int64_t)blockIdx.y * xbs + (int64_t)o * ostride + (int64_t)t * TX;
   for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
   for (int e = tid; e < L * TX; e += GEN_ANT) {
     const int c = e & (TX - 1), j = e >> TXLOG;
@@ -348,7 +354,7 @@ struct GenLong {
 template <bool INV>
 __global__ __launch_bounds__(GEN_ANT) void gen_long_outer_kernel(GenGrid g, GenPlan pl, GenLong lg,
                                                                  const double2* __restrict__ atw, const double2* __restrict__ twl,
-                                                                 double2* __restrict__ X) {
+                                                                 double2* __restrict__ X, int64_t xbs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   constexpr int TX = 8;
   const int L1 = lg.L1, L2 = lg.L2, NB = lg.NB;
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_long_outer_kernel(GenGrid g, GenP
   const int tid = threadIdx.x;
   const int ntx = g.nhp >> 3;
   const int t = blockIdx.x % ntx, b0 = (blockIdx.x / ntx) * NB;
-  double2* gbase = X + (int64_t)t * TX;
+  double2* gbase = X + (int64_t)blockIdx.y * xbs + (int64_t)t * TX;
   const int nel = L1 * NB * TX;
   for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
   // element e = (a * NB + bb) * TX + c  <->  row L2 a + b0 + bb, column t TX + c
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_long_outer_kernel(GenGrid g, GenP
 template <int MODE>
 __global__ __launch_bounds__(GEN_ANT) void gen_long_inner_kernel(GenGrid g, GenPlan pl, GenLong lg,
                                                                  const double2* __restrict__ atw, double2* __restrict__ X,
-                                                                 const double* __restrict__ Fh, double mean) {
+                                                                 const double* __restrict__ Fh, double mean, int64_t xbs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   constexpr int TX = 8;
   const int L2 = lg.L2, NC = lg.NC;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_long_inner_kernel(GenGrid g, GenP
   const int tid = threadIdx.x;
   const int ntx = g.nhp >> 3;
   const int t = blockIdx.x % ntx, c0 = (blockIdx.x / ntx) * NC;
-  double2* gbase = X + (int64_t)L2 * c0 * g.nhp + (int64_t)t * TX;
+  double2* gbase = X + (int64_t)blockIdx.y * xbs + (int64_t)L2 * c0 * g.nhp + (int64_t)t * TX;
   const int nel = NC * L2 * TX;
   for (int k = tid; k < pl.tlen; k += GEN_ANT) T[k] = atw[k];
   for (int e = tid; e < nel; e += GEN_ANT) buf[e] = gbase[(int64_t)(e >> 3) * g.nhp + (e & 7)];
