@@ -10,10 +10,7 @@ for dims in ((32, 32, 32), (64, 64, 64), (128, 64, 64), (128, 128, 64), (128, 12
     R = 128 if N <= 2 ** 21 else 32
     res = {}
     for path in ("fused", "generic"):
-        if path == "generic":
-            os.environ["GSS_FFTGS_PATH"] = "generic"
-        else:
-            os.environ.pop("GSS_FFTGS_PATH", None)
+        os.environ["GSS_FFTGS_PATH"] = path
         h = FFTGSHandle(gss.ExponentialVariogram(range=dims[0] / 10.0), dims)
         out = torch.empty((R, N), dtype=torch.float64, device="cuda")
         h.realize(1, 0, R, out=out)
