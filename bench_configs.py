@@ -265,7 +265,7 @@ def cfg_api(a, gss, _lib):
 
 def cfg_fftgs_generic(a, gss, _lib):
     """FFTGS on grids outside the power-of-two 3-D pipeline -- the reference's own test grids are 100 x 100
-    (test/simulation/fft.jl:4,11,26) -- on the library's generic Stockham passes (sizes 2^a 3^b 5^c, fftgs_generic.h)
+    (test/simulation/fft.jl:4,11,26) -- on the library's generic Stockham passes (sizes 2^a 3^b 5^c 7^d, fftgs_generic.h)
     and, beside it, on the rocFFT pipeline of the same library (GSS_FFTGS_PATH=rocfft, read at handle creation)."""
     from gss.engine import FFTGSHandle
     rows = []
@@ -303,7 +303,7 @@ def cfg_fftgs_generic(a, gss, _lib):
                      "roofline": {"bound": "hbm", "achieved": round(32.0 * N / (g["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK,
                                   "unit": "GB/s", "frac": round(32.0 * N / (g["ms"] * 1e-3) / 1e9 / HBM_PEAK, 4),
                                   "algorithmic_bytes": 32.0 * N}})
-    return {"config": "FFTGS on 2-D grids and on sizes 2^a 3^b 5^c: the library's generic passes against its rocFFT pipeline",
+    return {"config": "FFTGS on 2-D grids and on sizes 2^a 3^b 5^c 7^d: the library's generic passes against its rocFFT pipeline",
             "metric": "ms per realisation", "rows": rows}
 
 

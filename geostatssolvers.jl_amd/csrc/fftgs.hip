@@ -206,7 +206,7 @@ struct gss_fftgs {
   DevBuf xtw;                   // per-pass twiddle tables of the Stockham x passes
   int x_rows = 8;               // x lines per workgroup of the Stockham x passes (rows * M / 8 <= 256)
   int txy_log = 3, txz_log = 3; // log2 of the tile width (columns) of the y and z passes
-  // generic pipeline (2-D grids, sizes 2^a 3^b 5^c: fftgs_generic.h): Stockham plans per axis and their twiddle tables;
+  // generic pipeline (2-D grids, sizes 2^a 3^b 5^c 7^d: fftgs_generic.h): Stockham plans per axis and their twiddle tables;
   // the half-spectrum buffer is X, the amplitudes are read from the state in their natural layout
   bool generic = false;
   GenGrid gg;
@@ -498,6 +498,7 @@ static bool gen_plan(int L, GenPlan* pl) {
   std::memset(pl, 0, sizeof(*pl));
   pl->L = L;
   int n = L, np = 0;
+  while (n % 7 == 0 && np < GEN_MAX_PASSES - 4) { pl->radix[np++] = 7; n /= 7; }
   while (n % 5 == 0) { pl->radix[np++] = 5; n /= 5; if (np >= GEN_MAX_PASSES - 4) break; }
   while (n % 3 == 0 && np < GEN_MAX_PASSES - 4) { pl->radix[np++] = 3; n /= 3; }
   int e = 0;
@@ -542,7 +543,7 @@ static int32_t gen_upload_table(DevBuf& buf, const GenPlan& pl, hipStream_t s) {
 static size_t gen_x_lds(const GenPlan& pl, int rows, bool tg) { return sizeof(double2) * (size_t)((tg ? 0 : pl.L + pl.tlen) + rows * pl.L); }
 static size_t gen_axis_lds(const GenPlan& pl, int txlog) { return sizeof(double2) * (size_t)(pl.tlen + (pl.L << txlog)); }
 
-// 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c: n1 even with n1 / 2 <= 2 048,
+// 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c 7^d: n1 even with n1 / 2 <= 2 048,
 // the other axes <= 1 024.  Everything else stays on rocFFT.
 static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   const char* e = std::getenv("GSS_FFTGS_PATH");

@@ -1,5 +1,5 @@
 // FFTGS on the library's own passes for grids the power-of-two pipeline (fftgs_fused.h) does not take: 2-D grids and
-// 3-D grids whose sizes are products of 2, 3 and 5 -- the reference's own test grids are 100 x 100
+// 3-D grids whose sizes are products of 2, 3, 5 and 7 -- the reference's own test grids are 100 x 100
 // (/root/reference/test/simulation/fft.jl:4,11,26), and 200^3 / 300^3 / 500^3 are the round numbers users pick.
 //
 // Same mathematics and the same pass structure as the fused pipeline (fft.jl:96-103 for the spectrum, :163-170 for a
@@ -12,7 +12,7 @@
 //   GP5  x lines : real-inverse pre-processing -> half-length inverse FFT -> realisation   (8N r + 8N w)
 // i.e. five passes (three on 2-D grids) against the eight full-volume passes of noise kernel + rocFFT R2C + phase kernel
 // + rocFFT C2R.  What differs from the power-of-two passes is the transform inside a pass: Stockham autosort passes of
-// radix 2, 3, 4, 5 or 8 chosen at run time from the factorisation of the line length, natural order in and out on every
+// radix 2, 3, 4, 5, 7 or 8 chosen at run time from the factorisation of the line length, natural order in and out on every
 // axis (so the amplitudes Fh are read in their natural layout -- the state buffer of the handle -- and no permuted copy
 // exists), every pass in place in LDS with the items of a thread held in registers between the read and the write of
 // the tile.  A line is at most 2 048 complex elements (x: n1 / 2) or 1 024 (y, z); everything else stays on rocFFT.
@@ -71,13 +71,35 @@ __device__ __forceinline__ void g_dft5(double2 (&v)[5]) {
   v[2] = make_double2(a2.x + b2.x, a2.y + b2.y);
   v[3] = make_double2(a2.x - b2.x, a2.y - b2.y);
 }
+template <bool INV>
+__device__ __forceinline__ void g_dft7(double2 (&v)[7]) {
+  const double c1 = 0.62348980185873353053, c2 = -0.22252093395631440429, c3 = -0.90096886790241912624;   // cos(2 pi k / 7)
+  const double s1 = 0.78183148246802980871, s2 = 0.97492791218182360702, s3 = 0.43388373911755812048;    // sin(2 pi k / 7)
+  const double2 t1 = make_double2(v[1].x + v[6].x, v[1].y + v[6].y), d1 = make_double2(v[1].x - v[6].x, v[1].y - v[6].y);
+  const double2 t2 = make_double2(v[2].x + v[5].x, v[2].y + v[5].y), d2 = make_double2(v[2].x - v[5].x, v[2].y - v[5].y);
+  const double2 t3 = make_double2(v[3].x + v[4].x, v[3].y + v[4].y), d3 = make_double2(v[3].x - v[4].x, v[3].y - v[4].y);
+  const double2 a1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+  const double2 a2 = make_double2(v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+  const double2 a3 = make_double2(v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+  const double2 b1 = mul_mi<INV>(make_double2(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y));
+  const double2 b2 = mul_mi<INV>(make_double2(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y));
+  const double2 b3 = mul_mi<INV>(make_double2(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y));
+  v[0] = make_double2(v[0].x + t1.x + t2.x + t3.x, v[0].y + t1.y + t2.y + t3.y);
+  v[1] = make_double2(a1.x + b1.x, a1.y + b1.y);
+  v[6] = make_double2(a1.x - b1.x, a1.y - b1.y);
+  v[2] = make_double2(a2.x + b2.x, a2.y + b2.y);
+  v[5] = make_double2(a2.x - b2.x, a2.y - b2.y);
+  v[3] = make_double2(a3.x + b3.x, a3.y + b3.y);
+  v[4] = make_double2(a3.x - b3.x, a3.y - b3.y);
+}
 template <int R, bool INV>
 __device__ __forceinline__ void g_dft(double2 (&v)[R]) {
   if constexpr (R == 2) x_dft<1, INV>(v);
   else if constexpr (R == 4) x_dft<2, INV>(v);
   else if constexpr (R == 8) x_dft<3, INV>(v);
   else if constexpr (R == 3) g_dft3<INV>(v);
-  else g_dft5<INV>(v);
+  else if constexpr (R == 5) g_dft5<INV>(v);
+  else g_dft7<INV>(v);
 }
 
 // One Stockham pass of radix R over `nlines` lines of length L, in place: element n of line l at
@@ -147,6 +169,7 @@ __device__ __forceinline__ void g_transform(double2* buf, int nlines, int lmod, 
       case 3: g_pass<3, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
       case 4: g_pass<4, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
       case 5: g_pass<5, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 7: g_pass<7, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
       default: g_pass<8, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
     }
     Ns *= R;

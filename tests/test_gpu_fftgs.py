@@ -486,13 +486,15 @@ def test_config3_full_size_realisation_against_host_fft():
     assert err < 1e-9
 
 
-# ---- generic pipeline (fftgs_generic.h): 2-D grids and sizes 2^a 3^b 5^c on the library's own Stockham passes ----------
+# ---- generic pipeline (fftgs_generic.h): 2-D grids and sizes 2^a 3^b 5^c 7^d on the library's own Stockham passes ----------
 
 GENERIC_GRIDS = [(100, 100), (60, 50), (50, 64), (64, 64), (1000, 36), (36, 1000), (4096, 16), (250, 250),
                  (48, 36, 30), (100, 100, 100), (20, 18, 10), (64, 48, 40), (30, 625, 8),
                  (4, 2), (6, 3), (8, 8, 8), (16, 16, 16), (4, 1024),
                  # long y lines (1 024 < n2 <= 4 096): the split n2 = L1 L2 of fftgs_generic.h
-                 (64, 2048), (2048, 2048), (16, 4096), (100, 3000), (36, 1500), (250, 1280), (1024, 4096)]
+                 (64, 2048), (2048, 2048), (16, 4096), (100, 3000), (36, 1500), (250, 1280), (1024, 4096),
+                 # radix 7 (140, 210, 280, 350, 420, 700 ...)
+                 (70, 98), (140, 140), (28, 49, 14), (686, 20), (98, 2744), (14, 7, 7), (210, 210, 70), (350, 700)]
 
 
 @pytest.mark.parametrize("dims", GENERIC_GRIDS)
@@ -531,12 +533,12 @@ def test_generic_pipeline_matches_oracle_and_rocfft_path(dims, monkeypatch):
 
 
 def _random_shapes():
-    """Forty grid shapes drawn once (fixed seed): 1-D, 2-D and 3-D, axis lengths from smooth numbers (2^a 3^b 5^c, the
+    """Forty grid shapes drawn once (fixed seed): 1-D, 2-D and 3-D, axis lengths from smooth numbers (2^a 3^b 5^c 7^d, the
     generic passes: every radix order, odd half lengths, the long-line split), powers of two (fused pipeline) and
     arbitrary integers (rocFFT), at most 3 million cells."""
     rng = np.random.default_rng(20260405)
-    smooth = sorted({2 ** a * 3 ** b * 5 ** c for a in range(13) for b in range(8) for c in range(6)
-                     if 2 <= 2 ** a * 3 ** b * 5 ** c <= 4096})
+    smooth = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(5)
+                     if 2 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
     shapes = []
     while len(shapes) < 40:
         nd = int(rng.choice([1, 2, 2, 2, 3, 3]))

@@ -1,5 +1,5 @@
 """FFTGS on grids outside the power-of-two 3-D pipeline: ms per realisation on the library's own generic passes (sizes
-2^a 3^b 5^c: fftgs_generic.h) or on rocFFT (GSS_FFTGS_PATH=rocfft, and every other size).
+2^a 3^b 5^c 7^d: fftgs_generic.h) or on rocFFT (GSS_FFTGS_PATH=rocfft, and every other size).
 python3 tools/fftgs_2d_time.py; GSS_FFTGS_PATH=rocfft python3 tools/fftgs_2d_time.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
