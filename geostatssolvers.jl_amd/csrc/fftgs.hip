@@ -516,6 +516,7 @@ static bool gen_plan(int L, GenPlan* pl) {
     Ns *= pl->radix[p];
   }
   pl->tlen = off;
+  pl->has7 = np > 0 && pl->radix[0] == 7;
   return Ns == L;
 }
 
@@ -565,9 +566,9 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
     if (!gen_plan(gl.L1, &h->gpl[0]) || !gen_plan(gl.L2, &h->gpl[1])) return GSS_OK;
     gl.NB = gl.NC = 1;
     for (int d = 1; d <= gl.L2; ++d)
-      if (gl.L2 % d == 0 && gl.L1 * d <= 512) gl.NB = d;
+      if (gl.L2 % d == 0 && gl.L1 * d <= (h->gpl[0].has7 ? 448 : 512)) gl.NB = d;
     for (int d = 1; d <= gl.L1; ++d)
-      if (gl.L1 % d == 0 && gl.L2 * d <= 512) gl.NC = d;
+      if (gl.L1 % d == 0 && gl.L2 * d <= (h->gpl[1].has7 ? 448 : 512)) gl.NC = d;
   }
   if (h->ndim == 3 && !gen_plan((int)g.n3, &p3)) return GSS_OK;
   if (h->ndim == 2) std::memset(&p3, 0, sizeof(p3));
@@ -579,9 +580,9 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   gg.ndim = h->ndim;
   gg.c1 = (int)g.c1; gg.c2 = (int)g.c2; gg.c3 = (int)g.c3;
   gg.s1 = g.s1; gg.s2 = g.s2; gg.s3 = g.s3;
-  h->g_rows = (int)(2048 / p1.L);
+  h->g_rows = (int)((p1.has7 ? 1792 : 2048) / p1.L);
   if (h->g_rows > 16) h->g_rows = 16;
-  if (h->g_rows < 1) h->g_rows = 1;
+  if (h->g_rows < 1) return GSS_OK;          // (a line of 7 x 2^k > 1 792 elements: rocFFT)
   {
     // tables in the LDS unless they cost occupancy: more workgroups per CU (of 160 KB, at most 8) without them
     const int with = (int)((size_t)(160 << 10) / gen_x_lds(p1, h->g_rows, false));
@@ -589,8 +590,10 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
     static const int tg_env = env_int("GSS_FFTGS_GEN_TG", -1);
     h->g_tg = tg_env >= 0 ? tg_env != 0 : (with <= 2 && without > with);   // (three and more: measured neutral, 1 000^2)
   }
-  h->g_txlog[1] = p2.L <= 512 ? 3 : 2;
-  h->g_txlog[2] = (h->ndim == 3 && p3.L > 512) ? 2 : 3;
+  h->g_txlog[1] = p2.L <= (p2.has7 ? 448 : 512) ? 3 : 2;
+  h->g_txlog[2] = (h->ndim == 3 && p3.L > (p3.has7 ? 448 : 512)) ? 2 : 3;
+  if (!lng && p2.has7 && p2.L > 896) return GSS_OK;      // (980, 1 008: four columns of the line exceed 3 584 elements)
+  if (h->ndim == 3 && p3.has7 && p3.L > 896) return GSS_OK;
   GSS_TRY(upload_twiddles(h->tw1, gg.n1, s));
   GSS_TRY(gen_upload_table(h->gtab[0], p1, s));
   if (lng) {

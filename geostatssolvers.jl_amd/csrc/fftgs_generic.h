@@ -34,6 +34,7 @@ struct GenPlan {          // one axis: radices of the Stockham passes and where 
   int radix[GEN_MAX_PASSES];
   int toff[GEN_MAX_PASSES];
   int tlen;               // complex entries of the table: sum over the passes of (R - 1) * Ns
+  int has7;               // a radix-7 pass: tiles of this line hold at most 7 elements per thread (g_pass)
 };
 struct GenGrid {
   int n1, n2, n3;         // n1 fastest; n3 = 1 on 2-D grids
@@ -119,7 +120,10 @@ __device__ __forceinline__ int g_div(int a, float inv_b) { return (int)(((float)
 template <int R, bool INV, int NT>
 __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int lstr_hi, int nstr, int L, const double2* T,
                                        int Ns, int tid) {
-  constexpr int MAXI = (8 + R - 1) / R;      // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256))
+  // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256)) items; radix 7 holds one (two would be 112 registers and halve the
+  // occupancy of every launch, whatever its radices: measured 300^3 0.57 -> 0.83 ms): the host sizes the tiles of lines
+  // with a factor 7 to at most 7 items per thread-count (3 584 / 1 792 elements, GenPlan::has7)
+  constexpr int MAXI = R == 7 ? 1 : (8 + R - 1) / R;
   const int LR = L / R;
   const int nitems = nlines * LR;
   const float inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns, inv_lm = 1.0f / (float)lmod;

@@ -24,8 +24,20 @@ N = 1
 for d in dims:
     N *= d
 out = torch.empty((1, N), dtype=torch.float64, device="cuda")
+import time  # noqa: E402
+f.realize(4, 0, 1, out=out)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 for r in range(n):
     f.realize(4, r, 1, out=out)
 torch.cuda.synchronize()
+print("%.3f ms per realisation (one per call)" % ((time.perf_counter() - t0) / n * 1e3))
+big = torch.empty((n, N), dtype=torch.float64, device="cuda")
+f.realize(4, 0, n, out=big)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+f.realize(4, 0, n, out=big)
+torch.cuda.synchronize()
+print("%.3f ms per realisation (%d in one call)" % ((time.perf_counter() - t0) / n * 1e3, n))
 print("variance", float((out[0] * out[0]).sum() / (N - 1)))
 f.close()
