@@ -72,3 +72,33 @@ def test_no_dpp_read_follows_a_write_too_closely():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert int(r.stdout.split()[0]) > 1000, r.stdout        # the tile factorisations are in the library
+
+
+def test_register_budgets_of_the_occupancy_sensitive_kernels():
+    """A kernel's register count is the maximum over all its paths, so one added instantiation can halve the occupancy
+    of every launch without any test noticing (round 4: a second item per thread in the radix-7 pass took the strided
+    FFTGS passes from 116 to 146 registers, 300^3 0.57 -> 0.83 ms).  The budgets the measured numbers rest on, read from
+    the metadata of the built library (tools/kernel_resources.py)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    budgets = {"gen_axis_kernel": 128, "gen_long_inner_kernel": 128, "gen_long_outer_kernel": 128,   # 2 x 512 threads / CU
+               "gen_x_inv_kernel": 102, "gen_x_fwd_kernelILi0": 102,                                   # 5 x 256 threads / CU
+               "krig_local_mfma_kernel": 170, "krig_quadform_kernel": 256}                             # 3 and 2 waves per SIMD
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), _lib.LIB_PATH],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    seen = {k: 0 for k in budgets}
+    for line in r.stdout.splitlines():
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+)", line)
+        if not m:
+            continue
+        for k, cap in budgets.items():
+            if k in m.group(1):
+                seen[k] += 1
+                assert int(m.group(2)) <= cap, line
+    assert all(seen.values()), seen
