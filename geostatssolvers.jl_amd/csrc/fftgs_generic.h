@@ -193,6 +193,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
                                                             VgDev vg, int64_t xbs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
+  const float inv_m = 1.0f / (float)M;   // (rows * M <= 2 048: g_div is exact)
   const double2* tw = TG ? tw1 : gsm;
   const double2* T = TG ? xtw : gsm + M;
   double2* buf = TG ? gsm : gsm + M + pl.tlen;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
     for (int k = tid; k < pl.tlen; k += GEN_XNT) gsm[M + k] = xtw[k];
   }
   for (int e = tid; e < rows * M; e += GEN_XNT) {
-    const int row = e / M, n = e - row * M;
+    const int row = g_div(e, inv_m), n = e - row * M;
     const int64_t grow = row0 + row;
     double2 x = make_double2(0.0, 0.0);
     if (grow < nrows) {
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
   g_transform<false, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
   // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2 for k = 0 .. M, the pair (k, M - k) together
   const int half = M / 2;
+  const float inv_h1 = 1.0f / (float)(half + 1);
   for (int t = tid; t < rows * (half + 1); t += GEN_XNT) {
-    const int row = t / (half + 1), k = t - row * (half + 1);
+    const int row = g_div(t, inv_h1), k = t - row * (half + 1);
     const int64_t grow = row0 + row;
     if (grow >= nrows) continue;
     const double2* z = buf + row * M;
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
                                                             double* __restrict__ out, int64_t xbs, int64_t obs) {
   extern __shared__ __attribute__((aligned(16))) double2 gsm[];
   const int M = pl.L;
+  const float inv_m = 1.0f / (float)M;   // (rows * M <= 2 048: g_div is exact)
   const double2* tw = TG ? tw1 : gsm;
   const double2* T = TG ? xtw : gsm + M;
   double2* buf = TG ? gsm : gsm + M + pl.tlen;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
   }
   // Z'[k] = (Xk + conj(X_{M-k})) + i conj(w)^k (Xk - conj(X_{M-k})), k = 0 .. M - 1
   for (int e = tid; e < rows * M; e += GEN_XNT) {
-    const int row = e / M, k = e - row * M;
+    const int row = g_div(e, inv_m), k = e - row * M;
     const int64_t grow = row0 + row;
     double2 v = make_double2(0.0, 0.0);
     if (grow < nrows) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
   g_transform<true, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
   double2* o2 = reinterpret_cast<double2*>(out);
   for (int e = tid; e < rows * M; e += GEN_XNT) {
-    const int row = e / M, n = e - row * M;
+    const int row = g_div(e, inv_m), n = e - row * M;
     const int64_t grow = row0 + row;
     if (grow < nrows) o2[grow * M + n] = buf[e];
   }
