@@ -117,7 +117,10 @@ __device__ __forceinline__ int g_div(int a, float inv_b) { return (int)(((float)
 // Line l starts at buf[(l mod lmod) + (l div lmod) * lstr_hi]: lmod = 1, lstr_hi = M for the rows of the x passes; lmod =
 // nlines for a tile whose lines are its columns and column groups (the strided passes); lmod = TX, lstr_hi = L2 TX for the
 // inner transforms of a long line (gen_long_inner_kernel).
-template <int R, bool INV, int NT>
+// CL fixes the common layouts at compile time (the index arithmetic of an item is a third of its vector instructions):
+// CL >= 0: a column tile, nlines = lmod = nstr = 2^CL, lstr_hi = 0 (shifts and masks, no division); CL = -2: rows, lmod = 1,
+// nstr = 1, lstr_hi = the line length; CL = -1: general.
+template <int R, bool INV, int NT, int CL>
 __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int lstr_hi, int nstr, int L, const double2* T,
                                        int Ns, int tid) {
   // ceil(4096 / (R * 512)) = ceil(2048 / (R * 256)) items; radix 7 holds one (two would be 112 registers and halve the
@@ -125,17 +128,32 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int l
   // with a factor 7 to at most 7 items per thread-count (3 584 / 1 792 elements, GenPlan::has7)
   constexpr int MAXI = R == 7 ? 1 : (8 + R - 1) / R;
   const int LR = L / R;
-  const int nitems = nlines * LR;
+  const int nitems = (CL >= 0 ? LR << (CL >= 0 ? CL : 0) : nlines * LR);
   const float inv_nl = 1.0f / (float)nlines, inv_ns = 1.0f / (float)Ns, inv_lm = 1.0f / (float)lmod;
+  auto split = [&](int it, int& jj, int& lb) {   // item -> butterfly index within the line, offset of the line
+    if constexpr (CL >= 0) {
+      jj = it >> CL;
+      lb = it & ((1 << CL) - 1);
+    } else if constexpr (CL == -2) {
+      jj = g_div(it, inv_nl);
+      lb = (it - jj * nlines) * lstr_hi;
+    } else {
+      jj = g_div(it, inv_nl);
+      const int l = it - jj * nlines;
+      const int lh = g_div(l, inv_lm);
+      lb = (l - lh * lmod) + lh * lstr_hi;
+    }
+  };
+  auto at = [&](int lb, int n) { return CL >= 0 ? lb + (n << (CL >= 0 ? CL : 0)) : (CL == -2 ? lb + n : lb + n * nstr); };
   double2 v[MAXI][R];
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int it = tid + i * NT;
     if (it < nitems) {
-      const int jj = g_div(it, inv_nl), l = it - jj * nlines;
-      const int lh = g_div(l, inv_lm), lb = (l - lh * lmod) + lh * lstr_hi;
+      int jj, lb;
+      split(it, jj, lb);
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[i][r] = buf[lb + (jj + r * LR) * nstr];
+      for (int r = 0; r < R; ++r) v[i][r] = buf[at(lb, jj + r * LR)];
     }
   }
   __syncthreads();
@@ -143,8 +161,8 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int l
   for (int i = 0; i < MAXI; ++i) {
     const int it = tid + i * NT;
     if (it < nitems) {
-      const int jj = g_div(it, inv_nl), l = it - jj * nlines;
-      const int lh = g_div(l, inv_lm), lb = (l - lh * lmod) + lh * lstr_hi;
+      int jj, lb;
+      split(it, jj, lb);
       const int k = jj - g_div(jj, inv_ns) * Ns;
 #pragma unroll
       for (int r = 1; r < R; ++r) {
@@ -155,13 +173,13 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int l
       g_dft<R, INV>(v[i]);
       const int j0 = (jj - k) * R + k;
 #pragma unroll
-      for (int r = 0; r < R; ++r) buf[lb + (j0 + r * Ns) * nstr] = v[i][r];
+      for (int r = 0; r < R; ++r) buf[at(lb, j0 + r * Ns)] = v[i][r];
     }
   }
   __syncthreads();
 }
 
-template <bool INV, int NT>
+template <bool INV, int NT, int CL = -1>
 __device__ __forceinline__ void g_transform(double2* buf, int nlines, int lmod, int lstr_hi, int nstr, const GenPlan& pl,
                                             const double2* T, int tid) {
   int Ns = 1;
@@ -169,12 +187,12 @@ __device__ __forceinline__ void g_transform(double2* buf, int nlines, int lmod, 
     const int R = pl.radix[p];
     const double2* Tp = T + pl.toff[p];
     switch (R) {
-      case 2: g_pass<2, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
-      case 3: g_pass<3, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
-      case 4: g_pass<4, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
-      case 5: g_pass<5, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
-      case 7: g_pass<7, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
-      default: g_pass<8, INV, NT>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 2: g_pass<2, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 3: g_pass<3, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 4: g_pass<4, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 5: g_pass<5, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      case 7: g_pass<7, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
+      default: g_pass<8, INV, NT, CL>(buf, nlines, lmod, lstr_hi, nstr, pl.L, Tp, Ns, tid); break;
     }
     Ns *= R;
   }
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_fwd_kernel(GenGrid g, GenPlan p
     buf[e] = x;
   }
   __syncthreads();
-  g_transform<false, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
+  g_transform<false, GEN_XNT, -2>(buf, rows, 1, M, 1, pl, T, tid);
   // X[k] = ((Zk + conj(Z_{M-k})) - i w^k (Zk - conj(Z_{M-k}))) / 2 for k = 0 .. M, the pair (k, M - k) together
   const int half = M / 2;
   const float inv_h1 = 1.0f / (float)(half + 1);
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(GEN_XNT) void gen_x_inv_kernel(GenGrid g, GenPlan p
     buf[e] = v;
   }
   __syncthreads();
-  g_transform<true, GEN_XNT>(buf, rows, 1, M, 1, pl, T, tid);
+  g_transform<true, GEN_XNT, -2>(buf, rows, 1, M, 1, pl, T, tid);
   double2* o2 = reinterpret_cast<double2*>(out);
   for (int e = tid; e < rows * M; e += GEN_XNT) {
     const int row = g_div(e, inv_m), n = e - row * M;
@@ -323,9 +341,9 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
   }
   __syncthreads();
   if (MODE == 1) {
-    g_transform<true, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
+    g_transform<true, GEN_ANT, TXLOG>(buf, TX, TX, 0, TX, pl, T, tid);
   } else {
-    g_transform<false, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
+    g_transform<false, GEN_ANT, TXLOG>(buf, TX, TX, 0, TX, pl, T, tid);
     if (MODE == 2) {
       // fft.jl:163: P = F exp(i angle(X)); the amplitudes in the order of the tile's elements (gen_tile_fh_kernel):
       // one contiguous, aligned run of L * TX doubles per workgroup
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(GEN_ANT) void gen_axis_kernel(GenGrid g, GenPlan pl
         }
       }
       __syncthreads();
-      g_transform<true, GEN_ANT>(buf, TX, TX, 0, TX, pl, T, tid);
+      g_transform<true, GEN_ANT, TXLOG>(buf, TX, TX, 0, TX, pl, T, tid);
     }
   }
   for (int e = tid; e < L * TX; e += GEN_ANT) {
