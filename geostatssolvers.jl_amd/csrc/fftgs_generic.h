@@ -163,12 +163,15 @@ __device__ __forceinline__ void g_pass(double2* buf, int nlines, int lmod, int l
     if (it < nitems) {
       int jj, lb;
       split(it, jj, lb);
-      const int k = jj - g_div(jj, inv_ns) * Ns;
+      int k = 0;
+      if (Ns > 1) {   // (the first pass of a transform has unit twiddles: no table reads, no products)
+        k = jj - g_div(jj, inv_ns) * Ns;
 #pragma unroll
-      for (int r = 1; r < R; ++r) {
-        double2 w = T[(r - 1) * Ns + k];
-        if (INV) w.y = -w.y;
-        v[i][r] = cmul(v[i][r], w);
+        for (int r = 1; r < R; ++r) {
+          double2 w = T[(r - 1) * Ns + k];
+          if (INV) w.y = -w.y;
+          v[i][r] = cmul(v[i][r], w);
+        }
       }
       g_dft<R, INV>(v[i]);
       const int j0 = (jj - k) * R + k;
