@@ -224,18 +224,25 @@ __global__ __launch_bounds__(LUG_NT) void getrf_panel_grid_kernel(double* __rest
         s_row[wave] = brow;
       }
       __syncthreads();
-      if (tid == 0) {
-        double b = s_val[0];
-        long long br = s_row[0];
-        for (int w = 1; w < LUG_NT / 64; ++w)
-          if (s_val[w] > b || (s_val[w] == b && s_row[w] < br)) {
-            b = s_val[w];
-            br = s_row[w];
+      if (wave == 0) {   // the sixteen per-wave candidates, one per lane, reduced across lanes (not a serial scan by one thread)
+        constexpr int NW = LUG_NT / 64;
+        double b = lane < NW ? s_val[lane] : -2.0;
+        long long br = lane < NW ? s_row[lane] : m;
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+          const double ov = __shfl_xor(b, off);
+          const long long orow = __shfl_xor(br, off);
+          if (ov > b || (ov == b && orow < br)) {
+            b = ov;
+            br = orow;
           }
-        s_piv = br;
-        // (write-through stores: nothing dirty is left in this XCD's L2 for the barrier's release to write back)
-        __hip_atomic_store(&slot[wg].val, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&slot[wg].row, br, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+          s_piv = br;
+          // (write-through stores: nothing dirty is left in this XCD's L2 for the barrier's release to write back)
+          __hip_atomic_store(&slot[wg].val, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&slot[wg].row, br, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       __syncthreads();
       {
@@ -328,7 +335,8 @@ __global__ __launch_bounds__(LUG_NT) void getrf_panel_grid_kernel(double* __rest
           for (int c2 = c + 1; c2 < LU_NB; ++c2) a[q][c2] = fma(-l, s_urow[c2], a[q][c2]);
         }
       }
-      __syncthreads();   // s_urow / s_crow are rewritten by the next column
+      // (no barrier: s_urow / s_crow are rewritten by the next column's decision, which every wave reaches only through
+      //  that column's barriers)
     }
   });
   if (!dead) {
