@@ -270,7 +270,7 @@ def cfg_fftgs_generic(a, gss, _lib):
     from gss.engine import FFTGSHandle
     rows = []
     shapes = ((100, 100), (1000, 1000), (200, 200, 200), (300, 300, 300)) if a.quick else \
-        ((100, 100), (500, 500), (1000, 1000), (4096, 1024), (2048, 2048), (4096, 4096), (3000, 3000), (64, 64, 64),
+        ((1000,), (100, 100), (500, 500), (1000, 1000), (4096, 1024), (2048, 2048), (4096, 4096), (3000, 3000), (64, 64, 64),
          (100, 100, 100), (200, 200, 200), (300, 300, 300), (500, 500, 500))
     for dims in shapes:
         N = int(np.prod(dims))

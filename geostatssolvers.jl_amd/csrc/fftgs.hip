@@ -544,17 +544,19 @@ static int32_t gen_upload_table(DevBuf& buf, const GenPlan& pl, hipStream_t s) {
 static size_t gen_x_lds(const GenPlan& pl, int rows, bool tg) { return sizeof(double2) * (size_t)((tg ? 0 : pl.L + pl.tlen) + rows * pl.L); }
 static size_t gen_axis_lds(const GenPlan& pl, int txlog) { return sizeof(double2) * (size_t)(pl.tlen + (pl.L << txlog)); }
 
-// 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c 7^d: n1 even with n1 / 2 <= 2 048,
+// 1-D and 2-D grids and 3-D grids that the power-of-two pipeline does not take, sizes 2^a 3^b 5^c 7^d: n1 even with n1 / 2 <= 2 048,
 // the other axes <= 1 024.  Everything else stays on rocFFT.
 static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
   const char* e = std::getenv("GSS_FFTGS_PATH");
   if (e && std::strcmp(e, "rocfft") == 0) return GSS_OK;
   const GridSpec& g = h->g;
-  if (h->fused || h->ndim < 2 || (g.n1 & 1) || g.n1 / 2 > 2048 || g.n1 < 4 || g.n3 > 1024) return GSS_OK;
+  if (h->fused || (g.n1 & 1) || g.n1 / 2 > 2048 || g.n1 < 4 || g.n3 > 1024) return GSS_OK;
   const bool lng = h->ndim == 2 && g.n2 > 1024;
   if (g.n2 > (lng ? 4096 : 1024)) return GSS_OK;
   GenPlan p1, p2, p3;
-  if (!gen_plan((int)(g.n1 / 2), &p1) || !gen_plan((int)g.n2, &p2)) return GSS_OK;
+  std::memset(&p2, 0, sizeof(p2));
+  if (!gen_plan((int)(g.n1 / 2), &p1)) return GSS_OK;
+  if (h->ndim >= 2 && !gen_plan((int)g.n2, &p2)) return GSS_OK;   // (1-D grids: the x passes and an elementwise phase step)
   if (lng) {
     // n2 = L1 L2 with both factors <= 64 (L2 the largest such divisor); tiles of at most 4 096 elements
     GenLong& gl = h->gl;
@@ -571,7 +573,7 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
       if (gl.L1 % d == 0 && gl.L2 * d <= (h->gpl[1].has7 ? 448 : 512)) gl.NC = d;
   }
   if (h->ndim == 3 && !gen_plan((int)g.n3, &p3)) return GSS_OK;
-  if (h->ndim == 2) std::memset(&p3, 0, sizeof(p3));
+  if (h->ndim < 3) std::memset(&p3, 0, sizeof(p3));
   h->gp[0] = p1; h->gp[1] = p2; h->gp[2] = p3;
   GenGrid& gg = h->gg;
   gg.n1 = (int)g.n1; gg.n2 = (int)g.n2; gg.n3 = (int)g.n3;
@@ -609,7 +611,7 @@ static int32_t fftgs_setup_generic(gss_fftgs* h, hipStream_t s) {
     GSS_TRY(h->gtwl.alloc(sizeof(double) * w.size()));
     GSS_HIP(hipMemcpyAsync(h->gtwl.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, s));
     GSS_HIP(hipStreamSynchronize(s));
-  } else {
+  } else if (h->ndim >= 2) {
     GSS_TRY(gen_upload_table(h->gtab[1], p2, s));
   }
   if (h->ndim == 3) GSS_TRY(gen_upload_table(h->gtab[2], p3, s));
@@ -714,7 +716,7 @@ static void gen_launch_long(gss_fftgs* h, hipStream_t s, int nb = 1) {
 static int32_t fftgs_spectrum_generic(gss_fftgs* h, double* partial, hipStream_t s) {
   gen_launch_p1<FF_SRC_COV>(h, 0, 0, nullptr, s);
   if (h->g_long) gen_launch_long<0>(h, s);
-  else gen_launch_axis<0>(h, 1, s);
+  else if (h->ndim >= 2) gen_launch_axis<0>(h, 1, s);
   if (h->ndim == 3) gen_launch_axis<0>(h, 2, s);
   hipLaunchKernelGGL(gen_amp_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, h->gg, h->X.as<double2>(), h->Fh(), partial,
                      h->g_long ? h->gl.L1 : 0, h->g_long ? h->gl.L2 : 0);
@@ -775,6 +777,9 @@ static int32_t fftgs_generic_realize(gss_fftgs* h, uint64_t seed, int64_t real, 
       gen_launch_axis<2>(h, 2, s, 0, 0, nb);
       gen_launch_axis<1>(h, 1, s, 0, 0, nb);
     }
+  } else if (h->ndim == 1) {
+    hipLaunchKernelGGL(gen_phase1d_kernel, dim3((unsigned)((h->gg.nh + 255) / 256), nb), dim3(256), 0, s, h->gg, h->X.as<double2>(),
+                       h->Fh(), h->mean, h->g_xbs);
   } else if (h->g_long) {
     gen_launch_long<2>(h, s, nb);
   } else {
@@ -867,7 +872,7 @@ static int32_t fftgs_finish_state(gss_fftgs* h, hipStream_t s) {
       hipLaunchKernelGGL(ff_tile_fh2_kernel<2>, dim3(grid_blocks(nt)), dim3(256), 0, s, f, h->Fh(), h->Fh_tiled.as<double>());
     GSS_HIP(hipGetLastError());
   }
-  if (h->generic) {
+  if (h->generic && h->ndim >= 2) {
     const int axis = h->ndim == 3 ? 2 : 1;
     const int64_t nt = (int64_t)h->gg.nhp * h->gg.n2 * h->gg.n3;
     if (h->g_long)

@@ -508,6 +508,32 @@ __global__ __launch_bounds__(256) void gen_tile_fh_long_kernel(GenGrid g, GenLon
   }
 }
 
+// 1-D grids: the phase step between GP1 and GP5 (fft.jl:163), elementwise on the nh coefficients of every member of a
+// batch (blockIdx.y); Fh in its natural layout
+__global__ __launch_bounds__(256) void gen_phase1d_kernel(GenGrid g, double2* __restrict__ X, const double* __restrict__ Fh,
+                                                          double mean, int64_t xbs) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= g.nh) return;
+  double2* x = X + (int64_t)blockIdx.y * xbs + k;
+  const double2 v = *x;
+  const double f = Fh[k];
+  const double mag2 = v.x * v.x + v.y * v.y;
+  double2 pz;
+  if (mag2 > 0.0) {
+    double y = __builtin_amdgcn_rsq(mag2);
+    double er = fma(-(mag2 * y), y, 1.0);
+    y = fma(0.5 * y, er, y);
+    er = fma(-(mag2 * y), y, 1.0);
+    y = fma(0.5 * y, er, y);
+    const double inv = f * y;
+    pz = make_double2(v.x * inv, v.y * inv);
+  } else {
+    pz = make_double2(f, 0.0);
+  }
+  if (k == 0) pz = make_double2(mean, 0.0);
+  *x = pz;
+}
+
 // Fh (natural layout, the handle's state) -> the order in which the workgroups of the last-axis pass read it:
 // dst[(o * ntx + t) * L * TX + j * TX + c] = Fh[(kz n2 + ky) nh + kx], kx = t TX + c (0 beyond nh), (ky, kz) = (j, 0) for
 // the y axis of a 2-D grid and (o, j) for the z axis

@@ -494,7 +494,9 @@ GENERIC_GRIDS = [(100, 100), (60, 50), (50, 64), (64, 64), (1000, 36), (36, 1000
                  # long y lines (1 024 < n2 <= 4 096): the split n2 = L1 L2 of fftgs_generic.h
                  (64, 2048), (2048, 2048), (16, 4096), (100, 3000), (36, 1500), (250, 1280), (1024, 4096),
                  # radix 7 (140, 210, 280, 350, 420, 700 ...)
-                 (70, 98), (140, 140), (28, 49, 14), (686, 20), (98, 2744), (14, 7, 7), (210, 210, 70), (350, 700)]
+                 (70, 98), (140, 140), (28, 49, 14), (686, 20), (98, 2744), (14, 7, 7), (210, 210, 70), (350, 700),
+                 # 1-D grids (x passes and an elementwise phase step)
+                 (100,), (1000,), (4096,), (6,), (14,), (3000,), (4,)]
 
 
 @pytest.mark.parametrize("dims", GENERIC_GRIDS)
@@ -575,7 +577,7 @@ def test_any_grid_shape_matches_oracle(dims):
     h.close()
 
 
-@pytest.mark.parametrize("dims", [(60, 50), (100, 100), (24, 20, 18), (64, 2048)])
+@pytest.mark.parametrize("dims", [(60, 50), (100, 100), (24, 20, 18), (64, 2048), (500,)])
 def test_batched_realisations_equal_single_ones(dims, monkeypatch):
     """Small grids on the generic passes: up to 64 realisations share every launch (grid y).  Seventy realisations in one
     call (batches of 64 + 6, or fewer per batch on the larger grid) are bit-identical to seventy calls of one, from Philox
