@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256) void fftgs_apply_scale_kernel(double* __restri
 }
 
 // K7: X <- Fh * X / |X| (phase of the noise spectrum, amplitude of the covariance); DC <- mean
+// (blockIdx.y: member of a batch of realisations, half spectra NH apart)
 __global__ __launch_bounds__(256) void fftgs_phase_kernel(double2* __restrict__ X, const double* __restrict__ Fh,
                                                           int64_t NH, double mean) {
+  X += (int64_t)blockIdx.y * NH;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < NH; idx += (int64_t)gridDim.x * 256) {
     const double2 x = X[idx];
     const double f = Fh[idx];
@@ -172,9 +174,16 @@ using namespace gss;
 struct FftPlans {
   rocfft_plan fwd = nullptr, inv = nullptr;
   size_t work_bytes = 0;
+  // the same transforms for `batch` realisations at a time (small grids: the pipeline is four to ten launches whatever
+  // the grid, created on the first call with enough realisations)
+  rocfft_plan fwdB = nullptr, invB = nullptr;
+  int batch = 0;
+  size_t work_bytesB = 0;
   ~FftPlans() {
     if (fwd) rocfft_plan_destroy(fwd);
     if (inv) rocfft_plan_destroy(inv);
+    if (fwdB) rocfft_plan_destroy(fwdB);
+    if (invB) rocfft_plan_destroy(invB);
   }
 };
 
@@ -324,6 +333,51 @@ static int32_t ensure_rocfft(gss_fftgs* h) {
   return GSS_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
+// Batched plans of the rocFFT pipeline: 64 realisations per execution when the call has that many and 64 noise arrays
+// and half spectra fit 96 MiB, else 16, else none (0).  The plans live with the single ones (shared per grid size).
+static int32_t ensure_rocfft_batch(gss_fftgs* h, int64_t nreals, int* batch_out) {
+  *batch_out = 0;
+  const int env_b = env_int("GSS_FFTGS_ROCFFT_BATCH", -1);   // 0: off; n: that batch size (read per call)
+  const size_t per = sizeof(double) * ((size_t)h->N + 2 * (size_t)h->NH);
+  int want = 0;
+  for (int b : {64, 16})
+    if (nreals >= b && per * (size_t)b <= ((size_t)96 << 20)) { want = b; break; }
+  if (env_b == 0) want = 0;
+  if (env_b > 0) want = nreals >= env_b ? env_b : 0;
+  if (want == 0) return GSS_OK;
+  FftPlans* pl = h->plans.get();
+  if (pl->batch != want) {
+    if (pl->fwdB) rocfft_plan_destroy(pl->fwdB);
+    if (pl->invB) rocfft_plan_destroy(pl->invB);
+    pl->fwdB = pl->invB = nullptr;
+    pl->batch = 0;
+    size_t lengths[3] = {(size_t)h->g.n1, (size_t)h->g.n2, (size_t)h->g.n3};
+    GSS_FFT(rocfft_plan_create(&pl->fwdB, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_double, (size_t)h->ndim, lengths, (size_t)want, nullptr));
+    GSS_FFT(rocfft_plan_create(&pl->invB, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                               rocfft_precision_double, (size_t)h->ndim, lengths, (size_t)want, nullptr));
+    size_t w1 = 0, w2 = 0;
+    GSS_FFT(rocfft_plan_get_work_buffer_size(pl->fwdB, &w1));
+    GSS_FFT(rocfft_plan_get_work_buffer_size(pl->invB, &w2));
+    pl->work_bytesB = w1 > w2 ? w1 : w2;
+    pl->batch = want;
+  }
+  if (pl->work_bytesB > h->work.bytes) {
+    GSS_TRY(h->work.alloc(pl->work_bytesB));
+    GSS_FFT(rocfft_execution_info_set_work_buffer(h->info, h->work.p, pl->work_bytesB));
+  }
+  if (h->U.bytes < sizeof(double) * (size_t)h->N * (size_t)want) GSS_TRY(h->U.alloc(sizeof(double) * (size_t)h->N * (size_t)want));
+  if (h->Xn.bytes < sizeof(double) * 2 * (size_t)h->NH * (size_t)want)
+    GSS_TRY(h->Xn.alloc(sizeof(double) * 2 * (size_t)h->NH * (size_t)want));
+  *batch_out = want;
+  return GSS_OK;
+}
+
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 static int ilog2(int64_t v) {
   int l = 0;
@@ -380,10 +434,6 @@ static int32_t upload_x_tables(DevBuf& buf, int logM, hipStream_t s) {
 }
 
 static size_t ff_axis2_lds(int L, int txlog) { return sizeof(double2) * (size_t)(L / 2 + (L << txlog) + FF2_PAD); }
-static int env_int(const char* name, int dflt) {
-  const char* e = std::getenv(name);
-  return e && *e ? std::atoi(e) : dflt;
-}
 
 // strided pass `mode` (0 forward, 1 inverse, 2 forward-phase-inverse) along y (axis 1) or z (axis 2)
 template <int MODE>
@@ -1098,7 +1148,11 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
   GSS_REQUIRE(h->ready, "handle has no spectrum");
   if (nreals == 0) return GSS_OK;
   hipStream_t s = to_stream(stream);
-  if (!h->fused && !h->generic) GSS_TRY(ensure_rocfft(h));
+  int rbatch = 0;
+  if (!h->fused && !h->generic) {
+    GSS_TRY(ensure_rocfft(h));
+    GSS_TRY(ensure_rocfft_batch(h, nreals, &rbatch));
+  }
   const int64_t N = h->N;
   const int64_t npts = inds ? ninds : N;
   // Host arrays: the realisations leave chunk by chunk through a ring of at most three chunks (OutStream: the
@@ -1175,34 +1229,39 @@ int32_t gss_fftgs_realize(gss_fftgs_t* h, uint64_t seed, int64_t first_real, int
       r += nb - 1;
       continue;
     }
+    // rocFFT pipeline; `rbatch` realisations per execution while that many are left (and lie in one chunk of the ring)
+    int64_t nb = 1;
+    if (rbatch > 1 && !(noise && host) && nreals - r >= rbatch && (!os.on || os.chunk - r % os.chunk >= rbatch)) nb = rbatch;
+    if (inds && nb > 1 && h->Z.bytes < sizeof(double) * (size_t)N * (size_t)nb) GSS_TRY(h->Z.alloc(sizeof(double) * (size_t)N * (size_t)nb));
     double* u = h->U.as<double>();
     if (noise) {
       u = const_cast<double*>(nz);  // the forward transform does not overwrite its input
     } else {
       ProfScope ps("fftgs_noise", s);
-      GSS_TRY(philox_uniform_dev(seed, first_real + r, N, u, N, N, s));
+      GSS_TRY(philox_uniform_dev(seed, first_real + r, N, u, N, N, s, (int)nb, N));
     }
     {
       ProfScope ps("fftgs_fwd", s);
-      GSS_TRY(fft_exec(h, h->fwd, u, h->Xn.p, s));
+      GSS_TRY(fft_exec(h, nb > 1 ? h->plans->fwdB : h->fwd, u, h->Xn.p, s));
     }
     {
       ProfScope ps("fftgs_phase", s);
-      hipLaunchKernelGGL(fftgs_phase_kernel, dim3(grid_blocks(h->NH)), dim3(256), 0, s, h->Xn.as<double2>(), h->Fh(),
-                         h->NH, h->mean);
+      hipLaunchKernelGGL(fftgs_phase_kernel, dim3(grid_blocks(h->NH), (unsigned)nb), dim3(256), 0, s, h->Xn.as<double2>(),
+                         h->Fh(), h->NH, h->mean);
       GSS_HIP(hipGetLastError());
     }
     double* z = inds ? h->Z.as<double>() : dst;
     {
       ProfScope ps("fftgs_inv", s);
-      GSS_TRY(fft_exec(h, h->inv, h->Xn.p, z, s));
+      GSS_TRY(fft_exec(h, nb > 1 ? h->plans->invB : h->inv, h->Xn.p, z, s));
     }
     if (inds) {
-      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256)), dim3(256), 0, s, z, si.as<int64_t>(),
-                         ninds, dst);
+      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((ninds + 255) / 256), (unsigned)nb), dim3(256), 0, s, z,
+                         si.as<int64_t>(), ninds, dst, N);
       GSS_HIP(hipGetLastError());
     }
-    GSS_TRY(os.done(r, s));
+    GSS_TRY(os.done(r + nb - 1, s));
+    r += nb - 1;
   }
   return os.finish(s);
 }

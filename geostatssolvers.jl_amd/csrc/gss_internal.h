@@ -925,8 +925,9 @@ int32_t check_metric(int metric, double metric_param, int dim, double radius, co
 // ---------------------------------------------------------------------------------------------
 // noise (noise.hip)
 // ---------------------------------------------------------------------------------------------
+// (nreals > 1: realisations real .. real + nreals - 1 in one launch, outputs bstride doubles apart)
 int32_t philox_uniform_dev(uint64_t seed, int64_t real, int64_t n, double* out, int64_t ld_pad_n1, int64_t n1,
-                           hipStream_t s);
+                           hipStream_t s, int nreals = 1, int64_t bstride = 0);
 int32_t philox_normal_dev(uint64_t seed, int64_t real, int64_t n, double* out, hipStream_t s);
 
 }  // namespace gss

@@ -6,11 +6,15 @@ namespace gss {
 
 // element e of a realisation lives at out[(e / n1) * ld + e % n1]: ld > n1 gives the padded rows an
 // in-place real-to-complex transform wants
+// (blockIdx.y: consecutive realisation numbers, outputs `bstride` doubles apart)
 __global__ __launch_bounds__(256) void philox_uniform_kernel(uint64_t seed, uint32_t real, int64_t n,
-                                                             double* __restrict__ out, int64_t ld, int64_t n1) {
+                                                             double* __restrict__ out, int64_t ld, int64_t n1,
+                                                             int64_t bstride) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;  // block -> elements 2b, 2b+1
   const int64_t e0 = 2 * b;
   if (e0 >= n) return;
+  real += blockIdx.y;
+  out += (int64_t)blockIdx.y * bstride;
   double ua, ub;
   philox_pair(seed, real, STREAM_UNIFORM, (uint64_t)b, ua, ub);
   out[(e0 / n1) * ld + e0 % n1] = ua;
@@ -25,11 +29,11 @@ __global__ __launch_bounds__(256) void philox_normal_kernel(uint64_t seed, uint3
 }
 
 int32_t philox_uniform_dev(uint64_t seed, int64_t real, int64_t n, double* out, int64_t ld, int64_t n1,
-                           hipStream_t s) {
-  if (n <= 0) return GSS_OK;
+                           hipStream_t s, int nreals, int64_t bstride) {
+  if (n <= 0 || nreals <= 0) return GSS_OK;
   const int64_t nb = (n + 1) / 2;
-  hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, seed,
-                     (uint32_t)real, n, out, ld, n1);
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((nb + 255) / 256), (unsigned)nreals), dim3(256), 0, s, seed,
+                     (uint32_t)real, n, out, ld, n1, bstride);
   GSS_HIP(hipGetLastError());
   return GSS_OK;
 }

@@ -577,9 +577,10 @@ def test_any_grid_shape_matches_oracle(dims):
     h.close()
 
 
-@pytest.mark.parametrize("dims", [(60, 50), (100, 100), (24, 20, 18), (64, 2048), (500,)])
+@pytest.mark.parametrize("dims", [(60, 50), (100, 100), (24, 20, 18), (64, 2048), (500,), (101, 101), (51, 47, 23), (101,)])
 def test_batched_realisations_equal_single_ones(dims, monkeypatch):
-    """Small grids on the generic passes: up to 64 realisations share every launch (grid y).  Seventy realisations in one
+    """Small grids on the generic passes: up to 64 realisations share every launch (grid y) -- and on the rocFFT pipeline
+    (odd and non-smooth sizes: the last three shapes) 64 or 16 realisations share every plan execution.  Seventy realisations in one
     call (batches of 64 + 6, or fewer per batch on the larger grid) are bit-identical to seventy calls of one, from Philox
     and from supplied noise, into device memory, into host memory through a ring of small chunks (batches cut at the
     chunk ends: GSS_OUT_CHUNK_MB=1), and with an index subset; a few of them against the oracle."""
