@@ -342,9 +342,33 @@ class KrigingSolver(_Solver):
         lo, hi = parallel.shard_range(m, rank, ws)
         xdom = xdom_all[lo:hi]
         cols = {}
+        # Variables of one problem that share everything but their values (same samples, same variogram object, same
+        # variant / mean / degree / support, global neighbourhood) share the kriging system: the first one is fitted and
+        # predicted, the others are one batched product with the weights it implies (gss_krig_predict_global_batch, the
+        # conditional-FFTGS pattern) and take its variances -- the reference repeats the fit and the solves per variable
+        # (krig.jl:141-161), the numbers are the same.
+        shared = {}
         for var in problem.variables:
             q = pre[var]
             p = q["params"]
+            skey = None
+            if (q["maxneighbors"] is None and q["variant"] != EDK and p.get("support", "point") == "point"
+                    and hasattr(self.engine.Krig, "predict_global_batch")):
+                skey = (id(p["variogram"]), q["variant"], p["mean"], p["degree"], repr(p.get("support", "point")),
+                        q["x"].shape, q["x"].tobytes() if q["x"].size <= 1 << 20 else id(q["x"]))
+            if skey is not None and skey in shared and hi > lo:
+                h0, var0, st0 = shared[skey]
+                mu = np.asarray(h0.predict_global_batch(xdom, np.ascontiguousarray(q["z"], dtype=np.float64)[None, :]))[0]
+                mu = _mask_missing(mu, st0)
+                var_ = var0
+                if gather and ws > 1:
+                    mu = parallel.all_gather_concat(mu, m)
+                order = _path_order(p["path"], m, pdom)
+                if order is not None and (gather or ws == 1):
+                    mu = mu[order]
+                cols[var] = mu
+                cols[f"{var}_variance"] = var_.copy()
+                continue
             drift_data = drift_dom = None
             if q["variant"] == EDK:
                 drift_data = np.stack([[f(c) for f in p["drifts"]] for c in q["x"]]).astype(np.float64)
@@ -373,7 +397,13 @@ class KrigingSolver(_Solver):
                                                      distance=_distance(p))
                 else:
                     mu, var_, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
-            finally:
+            except BaseException:
+                h.close()
+                for h0, _, _ in shared.values():
+                    h0.close()
+                raise
+            keep = skey is not None and hi > lo and len(problem.variables) > 1
+            if not keep:
                 h.close()
             mu = _mask_missing(mu, st)                                 # `missing` krig.jl:213-214
             var_ = _mask_missing(var_, st)
@@ -383,8 +413,12 @@ class KrigingSolver(_Solver):
             order = _path_order(p["path"], m, pdom)
             if order is not None and (gather or ws == 1):              # results in traversal order, krig.jl:179-183
                 mu, var_ = mu[order], var_[order]
+            if keep:
+                shared[skey] = (h, var_, st)                           # (variances already gathered and ordered)
             cols[var] = mu
             cols[f"{var}_variance"] = var_                             # krig.jl:160
+        for h0, _, _ in shared.values():
+            h0.close()
         if gather or ws == 1:
             return georef(cols, pdom)                                  # krig.jl:163
         return georef(cols, PointSet(xdom))

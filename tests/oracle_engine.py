@@ -41,7 +41,8 @@ class _Krig:
                                radii=radii, return_idx=return_idx, distance=distance, support=getattr(self, "support", None))
 
     def predict_global_batch(self, xdom, zbatch):
-        return np.stack([OK_.exactsolve(self.variant, self.vg, self.x, zb, xdom, mean=self.mean)[0] for zb in zbatch])
+        return np.stack([OK_.exactsolve(self.variant, self.vg, self.x, zb, xdom, mean=self.mean, degree=self.degree)[0]
+                         for zb in zbatch])
 
 
 class _FFTGS:

@@ -213,3 +213,40 @@ def test_nearest_cell_of_a_cartesian_grid_is_arithmetic_and_follows_the_search_r
     view = DomainView(g, np.array([3, 10, 11, 40]))
     got = S._nearest_cells(OracleEngine, view, view.centroids(), np.array([[3.4, 0.2], [2.6, 1.4]]))
     assert np.array_equal(got, [0, 1])                   # positions inside the view
+
+
+def test_variables_that_share_samples_and_model_share_the_kriging_system():
+    """Several variables on the same samples with the same variogram object and a global neighbourhood: the first is fitted
+    and predicted, the others reuse its weights (one batched product) and its variances -- same numbers as a solve per
+    variable (krig.jl:141-161 repeats everything per variable).  A variable with a missing value, or with a model of its
+    own, does not share."""
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(0, 50, (40, 2))
+    tab = {"a": rng.normal(size=40), "b": rng.normal(size=40) + 2.0, "c": rng.normal(size=40)}
+    tab["c"][7] = np.nan                                                # its samples differ: fitted on its own
+    data = gss.georef(tab, xy)
+    dom = gss.PointSet(rng.uniform(0, 50, (60, 2)))
+    vg = gss.SphericalVariogram(range=20.0, nugget=0.1)
+    other = gss.SphericalVariogram(range=20.0, nugget=0.1)
+    for extra in (dict(), dict(mean=0.5), dict(degree=1)):
+        counted = []
+
+        class Counting(OracleEngine):
+            class Krig(OracleEngine.Krig):
+                def __init__(self, *a, **k):
+                    counted.append(1)
+                    super().__init__(*a, **k)
+
+        together = gss.solve(gss.EstimationProblem(data, dom, ("a", "b", "c")),
+                             gss.KrigingSolver(("a", dict(variogram=vg, **extra)), ("b", dict(variogram=vg, **extra)),
+                                               ("c", dict(variogram=vg, **extra)), engine=Counting))
+        assert len(counted) == 2                                        # a (shared with b) and c
+        for v in ("a", "b", "c"):
+            alone = gss.solve(gss.EstimationProblem(data, dom, v),
+                              gss.KrigingSolver((v, dict(variogram=vg, **extra)), engine=OracleEngine))
+            assert np.max(np.abs(together[v] - alone[v])) < 1e-10
+            assert np.max(np.abs(together[f"{v}_variance"] - alone[f"{v}_variance"])) < 1e-10
+        counted.clear()
+        gss.solve(gss.EstimationProblem(data, dom, ("a", "b")),
+                  gss.KrigingSolver(("a", dict(variogram=vg, **extra)), ("b", dict(variogram=other, **extra)), engine=Counting))
+        assert len(counted) == 2                                        # two model objects: two systems
