@@ -466,6 +466,19 @@ class _NeighborEstimator(_Solver):
         lo, hi = parallel.shard_range(m, rank, ws)
         xdom = xdom_all[lo:hi]
         cols, aux = {}, {}
+        # Scalar variables with the same parameters and the same valid samples share ONE search and ONE weight vector per
+        # point (value columns of gss_idw_predict_cols / gss_lwr_predict_cols): the first of them computes all of them.
+        # The reference repeats search and weights per variable (idw.jl:111-142); the numbers are the same.
+        def _key(v):
+            pv = self.params(v)
+            cv = problem.data[v]
+            if getattr(cv, "dtype", None) == object:
+                return None
+            valid = np.flatnonzero(~np.isnan(np.asarray(cv, dtype=np.float64)))
+            ident = lambda o: o if isinstance(o, (int, float, str, type(None))) else id(o)   # noqa: E731
+            return tuple(sorted((k, ident(x)) for k, x in pv.items())) + (valid.tobytes(),)
+        keys = {v: _key(v) for v in problem.variables}
+        batched = {}                                                     # var -> (mu, ax, st) computed with its group
         for var in problem.variables:
             p = self.params(var)
             col = problem.data[var]
@@ -496,7 +509,16 @@ class _NeighborEstimator(_Solver):
                 zin = np.log(np.stack([col[i].parts for i in inds], axis=1))     # (parts, n): log-parts as value columns
             else:
                 zin = zall[inds]
-            if hi > lo:
+            group = [v for v in problem.variables if keys[v] is not None and keys[v] == keys[var]] if not comp else [var]
+            if var in batched:
+                mu, ax, st = batched.pop(var)
+            elif hi > lo and len(group) > 1:
+                zs = np.stack([np.asarray(problem.data[v], dtype=np.float64)[inds] for v in group])
+                mus, ax, st = self._estimate(p, vdom.coords, zs, xdom, k, nmin, radius, radii)
+                for j, v in enumerate(group):
+                    batched[v] = (np.asarray(mus[j]), ax, st)
+                mu, ax, st = batched.pop(var)
+            elif hi > lo:
                 mu, ax, st = self._estimate(p, vdom.coords, zin, xdom, k, nmin, radius, radii)
             else:
                 mu = np.empty((zin.shape[0], 0)) if comp else np.empty(0)

@@ -332,3 +332,30 @@ def test_value_columns_share_one_search_and_one_weight_vector(k, n):
             md, ad, sd = fn(torch.as_tensor(x, device="cuda"), torch.as_tensor(Z, device="cuda"),
                             torch.as_tensor(c, device="cuda"), k, nmin, radius=ball, **kw)
             assert np.array_equal(md.cpu().numpy(), mu, equal_nan=True) and np.array_equal(sd.cpu().numpy(), st)
+
+
+@pytest.mark.parametrize("solver", ["idw", "lwr"])
+def test_variables_with_the_same_parameters_share_search_and_weights_through_solve(solver):
+    """`solve` with three scalar variables on the same samples and the same parameters: one search, one weight vector per
+    point, three value columns (one device call); a fourth variable with a missing value is estimated on its own.
+    Same numbers as a solve per variable."""
+    import gss
+    from gss import _lib
+    rng = np.random.default_rng(31)
+    n, m = 3000, 20000
+    xy = rng.uniform(0, 100, (n, 2))
+    tab = {k: rng.normal(size=n) + i for i, k in enumerate("abcd")}
+    tab["d"][5] = np.nan
+    data = gss.georef(tab, xy)
+    dom = gss.PointSet(rng.uniform(0, 100, (m, 2)))
+    S = gss.IDWSolver if solver == "idw" else gss.LWRSolver
+    params = dict(maxneighbors=12)
+    _lib.profile_reset(); _lib.profile_enable(True)
+    together = gss.solve(gss.EstimationProblem(data, dom, tuple("abcd")), S(*[(v, params) for v in "abcd"]))
+    _lib.profile_enable(False)
+    assert _lib.profile_read("knn")[1] == 2                              # {a, b, c} and d
+    aux = "distance" if solver == "idw" else "variance"
+    for v in "abcd":
+        alone = gss.solve(gss.EstimationProblem(data, dom, v), S((v, params)))
+        assert np.max(np.abs(together[v] - alone[v])) < 1e-9
+        assert np.max(np.abs(together[f"{v}_{aux}"] - alone[f"{v}_{aux}"])) < 1e-9
