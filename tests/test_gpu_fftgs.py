@@ -9,6 +9,8 @@ delta ~ 1e-16 N max|fft(C)|, and F = sqrt(|fft(C)|) turns an absolute error delt
 into sqrt(delta): the reference's own F is rounding noise there.  Stated tolerance for that model:
 F 1e-6 relative to max(F), realisations 1e-6 absolute (same level as the Gaussian kriging
 tolerance of SURVEY.md section 8c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -538,11 +540,13 @@ def _random_shapes():
     """Forty grid shapes drawn once (fixed seed): 1-D, 2-D and 3-D, axis lengths from smooth numbers (2^a 3^b 5^c 7^d, the
     generic passes: every radix order, odd half lengths, the long-line split), powers of two (fused pipeline) and
     arbitrary integers (rocFFT), at most 3 million cells."""
-    rng = np.random.default_rng(20260405)
+    # (GSS_TEST_SHAPES="count,seed": a longer hunt over other shapes)
+    count, seed = (int(v) for v in os.environ.get("GSS_TEST_SHAPES", "40,20260405").split(","))
+    rng = np.random.default_rng(seed)
     smooth = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(13) for b in range(8) for c in range(6) for d in range(5)
                      if 2 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
     shapes = []
-    while len(shapes) < 40:
+    while len(shapes) < count:
         nd = int(rng.choice([1, 2, 2, 2, 3, 3]))
         cap = {1: 4096, 2: 4096, 3: 200}[nd]
         dims = []
