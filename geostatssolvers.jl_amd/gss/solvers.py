@@ -336,11 +336,11 @@ class KrigingSolver(_Solver):
         rank; `gather=False` leaves every rank with its own block of points, in domain order."""
         pre = self.preprocess(problem)
         pdom = problem.domain
-        xdom_all = pdom.centroids()
-        m = xdom_all.shape[0]
+        m = pdom.nelements()
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(m, rank, ws)
-        xdom = xdom_all[lo:hi]
+        need_host = any(pre[v]["variant"] == EDK for v in problem.variables)
+        xdom = _domain_points(self.engine, pdom, lo, hi, need_host)
         cols = {}
         # Variables of one problem that share everything but their values (same samples, same variogram object, same
         # variant / mean / degree / support, global neighbourhood) share the kriging system: the first one is fitted and
@@ -358,7 +358,11 @@ class KrigingSolver(_Solver):
                         q["x"].shape, q["x"].tobytes() if q["x"].size <= 1 << 20 else id(q["x"]))
             if skey is not None and skey in shared and hi > lo:
                 h0, var0, st0 = shared[skey]
-                mu = np.asarray(h0.predict_global_batch(xdom, np.ascontiguousarray(q["z"], dtype=np.float64)[None, :]))[0]
+                zrow = np.ascontiguousarray(q["z"], dtype=np.float64)[None, :]
+                if hasattr(xdom, "is_cuda"):
+                    import torch
+                    zrow = torch.as_tensor(zrow, device=xdom.device)
+                mu = _host(h0.predict_global_batch(xdom, zrow))[0]
                 mu = _mask_missing(mu, st0)
                 var_ = var0
                 if gather and ws > 1:
@@ -395,6 +399,7 @@ class KrigingSolver(_Solver):
                         radius, radii = _ball(p["neighborhood"])
                         mu, var_, st = h.predict_knn(xdom, q["nmax"], q["minneighbors"], radius, radii, drift_dom,
                                                      distance=_distance(p))
+                    mu, var_, st = _host(mu), _host(var_), _host(st)
                 else:
                     mu, var_, st = np.empty(0), np.empty(0), np.empty(0, dtype=np.uint8)
             except BaseException:
@@ -421,7 +426,7 @@ class KrigingSolver(_Solver):
             h0.close()
         if gather or ws == 1:
             return georef(cols, pdom)                                  # krig.jl:163
-        return georef(cols, PointSet(xdom))
+        return georef(cols, PointSet(_host(xdom)))
 
 
 # ------------------------------------------------------------------------------------------
@@ -460,11 +465,10 @@ class _NeighborEstimator(_Solver):
     def solve(self, problem: EstimationProblem, gather: bool = True):
         pdom = problem.domain
         coords = problem.data.domain.centroids()
-        xdom_all = pdom.centroids()
-        m = xdom_all.shape[0]
+        m = pdom.nelements()
         rank, ws = parallel.world()
         lo, hi = parallel.shard_range(m, rank, ws)
-        xdom = xdom_all[lo:hi]
+        xdom = _domain_points(self.engine, pdom, lo, hi)
         cols, aux = {}, {}
         # Scalar variables with the same parameters and the same valid samples share ONE search and ONE weight vector per
         # point (value columns of gss_idw_predict_cols / gss_lwr_predict_cols): the first of them computes all of them.
@@ -515,11 +519,13 @@ class _NeighborEstimator(_Solver):
             elif hi > lo and len(group) > 1:
                 zs = np.stack([np.asarray(problem.data[v], dtype=np.float64)[inds] for v in group])
                 mus, ax, st = self._estimate(p, vdom.coords, zs, xdom, k, nmin, radius, radii)
+                mus, ax, st = _host(mus), _host(ax), _host(st)
                 for j, v in enumerate(group):
                     batched[v] = (np.asarray(mus[j]), ax, st)
                 mu, ax, st = batched.pop(var)
             elif hi > lo:
                 mu, ax, st = self._estimate(p, vdom.coords, zin, xdom, k, nmin, radius, radii)
+                mu, ax, st = _host(mu), _host(ax), _host(st)
             else:
                 mu = np.empty((zin.shape[0], 0)) if comp else np.empty(0)
                 ax, st = np.empty(0), np.empty(0, dtype=np.uint8)
@@ -542,7 +548,7 @@ class _NeighborEstimator(_Solver):
         cols.update(aux)                                                  # (; mus..., sigmas...) idw.jl:152
         if gather or ws == 1:
             return georef(cols, pdom)
-        return georef(cols, PointSet(xdom))
+        return georef(cols, PointSet(_host(xdom)))
 
     def _check(self, p):
         pass
@@ -572,7 +578,7 @@ class LWRSolver(_NeighborEstimator):
             # the host between the device's search and the device's normal equations (engine.lwr_callable)
             if not callable(wf) or not hasattr(self.engine, "lwr_callable"):
                 raise NotImplementedError("weightfun must be ExpWeight(a, p), TricubeWeight() or a callable h -> weight")
-            return self.engine.lwr_callable(x, z, xdom, k, nmin, wf, radius, radii, distance=_distance(p))
+            return self.engine.lwr_callable(x, z, _host(xdom), k, nmin, wf, radius, radii, distance=_distance(p))
         return self.engine.lwr(x, z, xdom, k, nmin, wf.spec(), radius, radii, distance=_distance(p))
 
 
@@ -690,6 +696,35 @@ class FFTGS(_Solver):
                 zu = parallel.all_gather_concat(zu, problem.nreals)
             reals[var] = [zu[r] for r in range(zu.shape[0])]
         return Ensemble(problem.domain, reals)
+
+
+def _domain_points(engine, pdom, lo, hi, need_host=False):
+    """Coordinates of domain elements lo .. hi-1 for an estimation call: for (views of) Cartesian grids on an engine that
+    takes device arrays, the tensor product of the per-axis centroids is formed in HBM (bit-identical values) -- 10^7
+    cells are 240 MB that would otherwise be generated on the host and copied; everything else, and `need_host`
+    (external drift functions are evaluated point by point in Python), gives the host array."""
+    if (not need_host and getattr(engine, "device_resident", False) and hasattr(parent(pdom), "spacing")
+            and pdom.nelements() >= 200_000):
+        c = _centroids_device(pdom)
+        return c[lo:hi] if (lo, hi) != (0, c.shape[0]) else c
+    return pdom.centroids()[lo:hi]
+
+
+def _host(a):
+    """numpy view of an engine result.  Device tensors come back in one copy; large ones through page-locked memory
+    (torch keeps such blocks for re-use), which the copy engine fills at the bus rate instead of the pageable path's
+    fraction of it."""
+    if not hasattr(a, "is_cuda"):
+        return np.asarray(a)
+    if not a.is_cuda:
+        return a.numpy()
+    if a.numel() * a.element_size() >= (4 << 20):
+        import torch
+        h = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
+        h.copy_(a, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return h.numpy()
+    return a.cpu().numpy()
 
 
 def _centroids_device(pdom):
