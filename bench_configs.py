@@ -259,8 +259,26 @@ def cfg_api(a, gss, _lib):
            "solve_s": round(dt_fapi, 3), "realisations_per_s_through_solve": round(R / dt_fapi, 2),
            "handle_level_s_same_destination_kind": round(dt_fh, 3), "handle_level_realisations_per_s": round(R / dt_fh, 2),
            "same_first_values": bool(np.array_equal(r0, out[0][:1000]))}
+    # estimation on a large Cartesian grid through solve: the domain points are formed in HBM, the table comes back through
+    # page-locked memory (configs[4]-like problem at 10^7 cells: 5 000 3-D data, 16 neighbours)
+    ge = 64 if a.quick else 216
+    rngg = np.random.default_rng(3)
+    gdata = gss.georef({"z": rngg.normal(size=5000)}, rngg.uniform(0, ge, (5000, 3)))
+    ggrid = gss.CartesianGrid(ge, ge, ge)
+    grows = {}
+    for name, solver in (("kriging_k16", gss.KrigingSolver(("z", dict(variogram=gss.MaternVariogram(range=30.0, order=1.5),
+                                                                       maxneighbors=16)))),
+                         ("idw_k16", gss.IDWSolver(("z", dict(maxneighbors=16))))):
+        gprob = gss.EstimationProblem(gdata, ggrid, "z")
+        gss.solve(gprob, solver)
+        sync(); t0 = time.perf_counter()
+        gsol = gss.solve(gprob, solver)
+        sync(); dtg = time.perf_counter() - t0
+        grows[name] = {"solve_s": round(dtg, 4), "cells_per_s": round(ge ** 3 / dtg, 1), "finite": bool(np.isfinite(gsol["z"]).all())}
+    grid_row = {"workload": "solve(EstimationProblem(5000 3-D data, CartesianGrid(%d^3)), .) with 16 neighbours, host table out" % ge,
+                **grows}
     return {"config": "front-end rows: the headline workloads through gss.solve(problem, solver)", "metric": "kriged points/s through solve",
-            "value": krig["points_per_s_through_solve"], "unit": "points/s", "kriging": krig, "fftgs": fft}
+            "value": krig["points_per_s_through_solve"], "unit": "points/s", "kriging": krig, "fftgs": fft, "grid_domain": grid_row}
 
 
 def cfg_fftgs_generic(a, gss, _lib):
