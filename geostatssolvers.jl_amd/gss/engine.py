@@ -29,6 +29,12 @@ def _vg_struct(vg, dim, extent=None):
     if getattr(vg, "kind", None) == "nested":
         # first structure carries the total nugget; every structure contributes c_i (sill_i - nugget_i); a Gaussian
         # structure's nugget is the regularised one (variograms.py: nugget + 1e-6 unless regularize=False)
+        for w, m in vg.terms:
+            if m.effective_nugget > m.sill:
+                # (a Gaussian structure with nugget = sill: the 1e-6 of the regularisation would make its structured part
+                #  negative -- the single model is refused by the library for the same reason)
+                raise ValueError(f"nested variogram: the (regularised) nugget {m.effective_nugget} of a {m.kind} structure "
+                                 f"exceeds its sill {m.sill}")
         terms = [(w, m) for w, m in vg.terms if w * (m.sill - m.effective_nugget) > 0.0]
         if not terms:
             raise ValueError("nested variogram without a structured (non-nugget) component")

@@ -100,6 +100,10 @@ def _make(kind, ball=None, *, sill=1.0, nugget=0.0, range=1.0, order=None, nu=No
         else:
             radii, range = ball.radii, 1.0
     o = order if order is not None else (nu if nu is not None else 1.0)
+    # gamma(h) = (sill - nugget) f(h) + nugget for h > 0: a nugget beyond the sill would make the structured part
+    # negative (no valid model; inside a nested model the device would otherwise drop the structure and keep its nugget)
+    if not (float(sill) > 0.0 and 0.0 <= float(nugget) <= float(sill)):
+        raise ValueError(f"variogram needs sill > 0 and 0 <= nugget <= sill (got sill={sill}, nugget={nugget})")
     return VariogramModel(kind, float(sill), float(nugget), float(range), float(o), radii, bool(regularize))
 
 

@@ -191,6 +191,10 @@ function cvariogram(γ, dim; extent=nothing)
   isstationary(γ) || throw(ArgumentError("variogram model must be stationary"))   # fft.jl:91-93, lu.jl:110
   if γ isa NestedVariogram       # gamma = sum c_i gamma_i: first structure carries the total nugget
     cs, γs = γ.cs, γ.γs
+    for g in γs      # a structure whose (regularised) nugget exceeds its sill has a negative structured part: refused, not dropped
+      effnugget(g) <= Float64(ustrip(sill(g))) ||
+        throw(ArgumentError("nested variogram: the (regularised) nugget of a structure exceeds its sill"))
+    end
     keep = [i for i in eachindex(γs) if cs[i] * (sill(γs[i]) - effnugget(γs[i])) > 0]
     length(keep) <= 4 || throw(ArgumentError("at most 4 nested structures are supported on the device"))
     k0, a0, r0, ν0, ir0 = structure(γs[keep[1]])

@@ -250,3 +250,19 @@ def test_variables_that_share_samples_and_model_share_the_kriging_system():
         gss.solve(gss.EstimationProblem(data, dom, ("a", "b")),
                   gss.KrigingSolver(("a", dict(variogram=vg, **extra)), ("b", dict(variogram=other, **extra)), engine=Counting))
         assert len(counted) == 2                                        # two model objects: two systems
+
+
+def test_models_with_a_nugget_beyond_the_sill_are_refused():
+    """A nugget above the sill makes the structured part of gamma negative; inside a nested model the device would have
+    dropped such a structure and kept its nugget (found by tools/hunt_covariance.py).  Refused at construction; a Gaussian
+    structure with nugget = sill is refused when the nested model is bound (its regularised nugget exceeds the sill)."""
+    with pytest.raises(ValueError, match="nugget"):
+        gss.ExponentialVariogram(sill=0.3, nugget=0.4)
+    with pytest.raises(ValueError, match="sill"):
+        gss.SphericalVariogram(sill=0.0)
+    ok = gss.SphericalVariogram(sill=1.0, nugget=1.0)                     # a pure nugget is a valid structure
+    assert ok.sill == ok.nugget
+    from gss.engine import _vg_struct
+    nested = 0.5 * gss.GaussianVariogram(sill=1.0, nugget=1.0) + gss.ExponentialVariogram(range=3.0)
+    with pytest.raises(ValueError, match="exceeds its sill"):
+        _vg_struct(nested, 2)
