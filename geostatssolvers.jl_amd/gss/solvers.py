@@ -703,8 +703,10 @@ def _domain_points(engine, pdom, lo, hi, need_host=False):
     takes device arrays, the tensor product of the per-axis centroids is formed in HBM (bit-identical values) -- 10^7
     cells are 240 MB that would otherwise be generated on the host and copied; everything else, and `need_host`
     (external drift functions are evaluated point by point in Python), gives the host array."""
-    if (not need_host and getattr(engine, "device_resident", False) and hasattr(parent(pdom), "spacing")
-            and pdom.nelements() >= 200_000):
+    import os
+    least = int(os.environ.get("GSS_SOLVE_DEVICE_POINTS", "200000"))      # elements from which the device forms them; 0: never
+    if (not need_host and least > 0 and getattr(engine, "device_resident", False) and hasattr(parent(pdom), "spacing")
+            and pdom.nelements() >= least):
         c = _centroids_device(pdom)
         return c[lo:hi] if (lo, hi) != (0, c.shape[0]) else c
     return pdom.centroids()[lo:hi]
