@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Random hunt through the front-end: the same random problem and solver solved by `gss.solve` on the device engine and on
+the oracle stand-in of the tests (tests/oracle_engine.py) -- estimation (kriging variants, IDW, LWR; grids, views, point
+sets; missing values; balls, metrics, paths) and simulation (FFTGS conditional or not, LUGS, SGS).
+python3 tools/hunt_solve.py [seed] [cases]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "geostatssolvers.jl_amd"), os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+
+import gss  # noqa: E402
+from oracle_engine import OracleEngine  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = np.random.default_rng(seed)
+MODELS = [gss.ExponentialVariogram, gss.SphericalVariogram, gss.MaternVariogram, gss.CubicVariogram, gss.PentasphericalVariogram]
+
+
+def model(dim, ext):
+    ctor = MODELS[int(rng.integers(0, len(MODELS)))]
+    kw = dict(sill=float(rng.uniform(0.5, 2.0)))
+    kw["nugget"] = kw["sill"] * float(rng.choice([0.0, 0.05, 0.3]))
+    if ctor is gss.MaternVariogram:
+        kw["order"] = float(rng.choice([0.5, 1.5, 2.5, 1.0]))
+    if dim > 1 and rng.random() < 0.3:
+        return ctor(gss.MetricBall(tuple(float(v) for v in rng.uniform(0.1, 0.6, dim) * ext)), **kw)
+    return ctor(range=float(rng.uniform(0.1, 0.6) * ext), **kw)
+
+
+def domain(dim, ext):
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        return gss.PointSet(rng.uniform(0, ext, (int(rng.integers(1, 400)), dim)))
+    dims = tuple(int(v) for v in rng.integers(2, {1: 300, 2: 25, 3: 9}[dim], dim))
+    g = gss.CartesianGrid(dims, tuple(float(v) for v in rng.uniform(-5, 5, dim)), tuple(ext / d for d in dims))
+    if kind == 2 and g.nelements() > 4:
+        return gss.view(g, np.sort(rng.choice(g.nelements(), int(rng.integers(1, g.nelements())), replace=False)))
+    return g
+
+
+def neighbourhood(dim, ext):
+    r = rng.random()
+    if r < 0.5:
+        return None
+    if r < 0.8 or dim == 1:
+        return gss.MetricBall(float(rng.uniform(0.2, 0.8) * ext))
+    return gss.MetricBall(tuple(float(v) for v in rng.uniform(0.2, 0.8, dim) * ext))
+
+
+worst = 0.0
+for it in range(cases):
+    dim = int(rng.integers(1, 4))
+    ext = float(rng.choice([1.0, 50.0, 1000.0]))
+    tag = ""
+    try:
+        if rng.random() < 0.6:                                   # ---------------- estimation
+            n = int(rng.integers(6, 150))
+            xy = rng.uniform(0, ext, (n, dim))
+            if dim == 1:
+                xy = np.sort(xy, axis=0) + np.arange(n)[:, None] * ext * 1e-4
+            tab = {"a": rng.normal(size=n), "b": rng.normal(size=n) + 1.0}
+            if rng.random() < 0.3:
+                tab["b"][rng.choice(n, 2, replace=False)] = np.nan
+            data = gss.georef(tab, xy)
+            dom = domain(dim, ext)
+            nb = neighbourhood(dim, ext)
+            kmax = None if rng.random() < 0.3 else int(rng.integers(1, n + 1))
+            est = int(rng.integers(0, 3))
+            if est == 0:
+                vg = model(dim, ext)
+                extra = [dict(), dict(mean=0.4), dict(degree=1), dict(degree=2 if dim < 3 else 1)][int(rng.integers(0, 4))]
+                ncoef = {0: 1, 1: dim + 1, 2: (dim + 1) * (dim + 2) // 2}.get(extra.get("degree", 0), 1)
+                if kmax is not None:
+                    kmax = max(kmax, ncoef + 3)
+                    if kmax > n:
+                        kmax = None
+                # (inside a ball a point may find fewer neighbours than drift terms: that system is singular, what comes back
+                #  is a flag on the device and whatever LAPACK makes of it in the oracle -- minneighbors keeps such points
+                #  `missing` on both sides, krig.jl:213-214)
+                nmin = 1
+                if kmax is not None:
+                    nmin = min(kmax, ncoef + 2) if nb is not None else (int(rng.integers(1, 4)) if kmax >= 6 else 1)
+                p = dict(variogram=vg, maxneighbors=kmax, neighborhood=nb if kmax is not None else None,
+                         minneighbors=nmin, **extra)
+                mk = lambda e: gss.KrigingSolver(("a", p), ("b", p), engine=e)                       # noqa: E731
+                # (the bar follows the conditioning of the data covariance, as in hunt_large_k.py)
+                cnd = float(np.linalg.cond(OracleEngine.cov_pairwise(vg, xy)))
+                tag = "kriging %s kmax %s nb %s dom %s n %d cond %.1e" % (extra, kmax, nb, type(dom).__name__, n, cnd)
+                tol = max(1e-7, 1e3 * 2.2e-16 * cnd)
+            elif est == 1:
+                p = dict(maxneighbors=kmax, neighborhood=nb, exponent=float(rng.choice([1, 2, 0.5])),
+                         distance=str(rng.choice(["euclidean", "cityblock", "chebyshev"])) if nb is None else "euclidean")
+                mk = lambda e: gss.IDWSolver(("a", p), ("b", p), engine=e)                           # noqa: E731
+                tag = "idw %s dom %s n %d" % (p, type(dom).__name__, n)
+                tol = 1e-9
+            else:
+                kk = None if kmax is None else max(kmax, dim + 5)
+                if kk is not None and kk > n:
+                    kk = None
+                p = dict(maxneighbors=kk, neighborhood=nb if kk is not None else None,
+                         weightfun=gss.TricubeWeight() if rng.random() < 0.5 else None,
+                         minneighbors=dim + 4 if kk is not None else 1)
+                mk = lambda e: gss.LWRSolver(("a", p), ("b", p), engine=e)                           # noqa: E731
+                tag = "lwr %s dom %s n %d" % (p, type(dom).__name__, n)
+                tol = 1e-6
+            prob = gss.EstimationProblem(data, dom, ("a", "b"))
+            d = gss.solve(prob, mk(None))
+            o = gss.solve(prob, mk(OracleEngine))
+            e = 0.0
+            for name in o.names():
+                dv, ov = np.asarray(d[name], dtype=float), np.asarray(o[name], dtype=float)
+                if not np.array_equal(np.isnan(dv), np.isnan(ov)):
+                    print("MISSING PATTERN", name, "case", it, tag); sys.exit(1)
+                okm = ~np.isnan(ov)
+                if okm.any():
+                    sc = np.maximum(1.0, np.abs(ov[okm]))
+                    if name.endswith("_variance") and est == 0:
+                        sc = np.maximum(sc, 1.0)
+                    e = max(e, float(np.max(np.abs(dv[okm] - ov[okm]) / sc)))
+        else:                                                    # ---------------- simulation
+            dims = tuple(int(v) for v in rng.integers(4, {1: 200, 2: 24, 3: 9}[dim], dim))
+            grid = gss.CartesianGrid(dims)
+            ext = float(max(dims))
+            nd = int(rng.integers(0, 6))
+            R = int(rng.integers(1, 5))
+            vg = model(dim, ext)
+            if nd:
+                pts = rng.uniform(0, 1, (nd, dim)) * np.array(dims)
+                prob = gss.SimulationProblem(gss.georef({"z": rng.normal(size=nd)}, pts), grid, ("z", float), R)
+            else:
+                prob = gss.SimulationProblem(grid, ("z", float), R)
+            sim = int(rng.integers(0, 3))
+            sd = int(rng.integers(0, 10_000))
+            if sim == 0:
+                mk = lambda e: gss.FFTGS(("z", dict(variogram=vg, mean=0.2)), rng=sd, engine=e)       # noqa: E731
+                tag = "fftgs dims %s nd %d" % (dims, nd)
+            elif sim == 1:
+                fact = "lu" if rng.random() < 0.3 else "cholesky"
+                mk = lambda e: gss.LUGS(("z", dict(variogram=vg, factorization=fact)), rng=sd, engine=e)   # noqa: E731
+                tag = "lugs %s dims %s nd %d" % (fact, dims, nd)
+            else:
+                p = dict(variogram=vg, maxneighbors=int(rng.integers(1, 20)), neighborhood=neighbourhood(dim, ext),
+                         path=str(rng.choice(["linear", "random"])))
+                mk = lambda e: gss.SGS(("z", p), rng=sd, engine=e)                                  # noqa: E731
+                tag = "sgs %s dims %s nd %d" % ({k: v for k, v in p.items() if k != "variogram"}, dims, nd)
+            tol = 1e-7
+            d = gss.solve(prob, mk(None))
+            o = gss.solve(prob, mk(OracleEngine))
+            e = float(np.max(np.abs(np.stack(d["z"]) - np.stack(o["z"]))))
+    except (AssertionError, ValueError, NotImplementedError) as ex:
+        # a refusal must be the same on both engines' front-end (it is raised before the engine is reached)
+        continue
+    worst = max(worst, e / tol)
+    if not e < tol:
+        print("MISMATCH %.3e case %d" % (e, it), tag); sys.exit(1)
+print("%d cases, worst error / tolerance %.3g" % (cases, worst))
