@@ -141,8 +141,11 @@ for it in range(cases):
             sim = int(rng.integers(0, 3))
             sd = int(rng.integers(0, 10_000))
             if sim == 0:
-                mk = lambda e: gss.FFTGS(("z", dict(variogram=vg, mean=0.2)), rng=sd, engine=e)       # noqa: E731
-                tag = "fftgs dims %s nd %d" % (dims, nd)
+                fp = dict(variogram=vg, mean=0.2)
+                if nd and rng.random() < 0.5:                    # conditioning by kriging in moving neighbourhoods
+                    fp.update(maxneighbors=int(rng.integers(1, nd + 1)), neighborhood=neighbourhood(dim, ext))
+                mk = lambda e: gss.FFTGS(("z", fp), rng=sd, engine=e)                                 # noqa: E731
+                tag = "fftgs dims %s nd %d %s" % (dims, nd, {k: v for k, v in fp.items() if k != "variogram"})
             elif sim == 1:
                 fact = "lu" if rng.random() < 0.3 else "cholesky"
                 # (`lu(C).L` with the permutation dropped is not canonical: where two candidates of a column tie to rounding
@@ -153,14 +156,19 @@ for it in range(cases):
                 mk = lambda e: gss.LUGS(("z", dict(variogram=vg, factorization=fact)), rng=sd, engine=e)   # noqa: E731
                 tag = "lugs %s dims %s nd %d" % (fact, dims, nd)
             else:
-                p = dict(variogram=vg, maxneighbors=int(rng.integers(1, 20)), neighborhood=neighbourhood(dim, ext),
-                         path=str(rng.choice(["linear", "random"])))
+                nbh = neighbourhood(dim, ext)
+                p = dict(variogram=vg, maxneighbors=int(rng.integers(1, 20)), neighborhood=nbh,
+                         path=str(rng.choice(["linear", "random"])),
+                         distance=str(rng.choice(["euclidean", "cityblock", "chebyshev"])) if nbh is None else "euclidean")
                 mk = lambda e: gss.SGS(("z", p), rng=sd, engine=e)                                  # noqa: E731
                 tag = "sgs %s dims %s nd %d" % ({k: v for k, v in p.items() if k != "variogram"}, dims, nd)
             tol = 1e-7
             d = gss.solve(prob, mk(None))
             o = gss.solve(prob, mk(OracleEngine))
-            e = float(np.max(np.abs(np.stack(d["z"]) - np.stack(o["z"]))))
+            D, O = np.stack(d["z"]).astype(float), np.stack(o["z"]).astype(float)
+            if not np.array_equal(np.isnan(D), np.isnan(O)):     # (cells no datum reaches are `missing` in the kriged parts)
+                print("MISSING PATTERN case", it, tag); sys.exit(1)
+            e = float(np.nanmax(np.abs(D - O))) if np.isfinite(O).any() else 0.0
             if sim == 1 and fact == "lu" and not e < tol:
                 # On a regular grid mirror-symmetric cells give partial pivoting columns whose two largest candidates
                 # agree to rounding (found by this hunt: 19 x 19 cells, relative gap 1.2e-13 in column 356 of 358); the
